@@ -1,0 +1,41 @@
+// Parameter block of the MFMA GEMM / implicit-conv core (gemm.hip).
+#pragma once
+#include "common.h"
+
+namespace cl {
+
+enum GemmMode {
+  GEMM_LINEAR = 0,   // A is row-major [M, K1]
+  GEMM_CONV_S1 = 1,  // A is NHWC [B,Hin,Win,C]; 3x3, stride 1, pad 1
+  GEMM_CONV_S2 = 2,  // 3x3, stride 2, pad 1 (Downsample, openaimodel.py:150)
+  GEMM_CONV_UP2 = 3, // 3x3 over the nearest-x2 upsampled input (Upsample, openaimodel.py:115-117)
+  GEMM_CONV_T2 = 4,  // 3x3 over the zero-stuffed x2 grid (= data-gradient of GEMM_CONV_S2)
+};
+
+enum GemmAct { ACT_NONE = 0, ACT_SILU = 1 };
+
+struct GemmParams {
+  // out[M,N] = act( A1 . W1^T + A2 . W2^T + bias[n] + rowbias[m / rows_per_batch, n] ) * alpha
+  //            + beta * residual[m, n]
+  const void* A1; long lda1; int K1;   // K1 = per-tap channels C in conv modes
+  const void* W1; long ldw1;           // [N, taps*K1], K contiguous
+  const void* A2; long lda2; int K2;   // optional second K segment (LoRA up-projection folded in)
+  const void* W2; long ldw2;
+  int M, N;
+  int mode;
+  int B, Hin, Win, Hout, Wout;         // conv geometry (A1 pixel stride = lda1)
+  const void* zero_page;               // >= 64 zero bytes, for halo taps
+  const float* bias;                   // [N] fp32 or null
+  const void* rowbias; long ldrb; int rows_per_batch;  // T [M/rows_per_batch, N] or null
+  const void* residual; long ldr;      // T [M, N] or null
+  float alpha, beta;
+  int act;
+  void* C; long ldc;
+  int out_f32;                         // store fp32 regardless of T
+  int atomic;                          // fp32 atomicAdd into C (split-K / grad accumulation)
+  int splitk;                          // >= 1
+};
+
+int launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);
+
+}  // namespace cl

@@ -1,0 +1,192 @@
+// Standalone GPU probe for the GEMM / implicit-conv core: checks every mode
+// against a CPU double reference on asymmetric random data and times a few
+// hot-path shapes.  Build: see tools/build_probes.sh.  Not part of the product.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../ctrlora_amd/csrc/gemm.h"
+
+using namespace cl;
+
+#define HIPCHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(2); } } while (0)
+
+static uint32_t rng_state = 12345;
+static float frand() { rng_state = rng_state * 1664525u + 1013904223u; return ((rng_state >> 8) & 0xffff) / 32768.0f - 1.0f; }
+static uint16_t h_f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
+static float h_bf2f(uint16_t v) { uint32_t u = ((uint32_t)v) << 16; float f; memcpy(&f, &u, 4); return f; }
+
+struct Buf {
+  std::vector<float> h;  // values as float (already rounded to storage precision)
+  void* d = nullptr; size_t n = 0; int dtype = 0;
+  void init(size_t n_, int dtype_, float scale = 1.0f, bool zero = false) {
+    n = n_; dtype = dtype_; h.resize(n);
+    for (size_t i = 0; i < n; ++i) { float v = zero ? 0.f : frand() * scale; h[i] = dtype == CL_BF16 ? h_bf2f(h_f2bf(v)) : v; }
+    upload();
+  }
+  void upload() {
+    if (!d) HIPCHK(hipMalloc(&d, n * (dtype == CL_BF16 ? 2 : 4) + 256));
+    if (dtype == CL_BF16) { std::vector<uint16_t> t(n); for (size_t i = 0; i < n; ++i) t[i] = h_f2bf(h[i]); HIPCHK(hipMemcpy(d, t.data(), n * 2, hipMemcpyHostToDevice)); }
+    else HIPCHK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
+  }
+  void download(int dt) {
+    if (dt == CL_BF16) { std::vector<uint16_t> t(n); HIPCHK(hipMemcpy(t.data(), d, n * 2, hipMemcpyDeviceToHost)); for (size_t i = 0; i < n; ++i) h[i] = h_bf2f(t[i]); }
+    else HIPCHK(hipMemcpy(h.data(), d, n * 4, hipMemcpyDeviceToHost));
+  }
+};
+
+static void* g_zero;
+static int g_fail = 0;
+
+static void report(const char* name, double num, double den, double tol) {
+  double rel = std::sqrt(num / (den + 1e-30));
+  bool ok = rel <= tol && std::isfinite(rel);
+  printf("[%s] %-44s rel_l2=%.3e (tol %.1e)\n", ok ? "PASS" : "FAIL", name, rel, tol);
+  if (!ok) g_fail++;
+}
+
+// ---------------- linear cases ----------------
+static void case_linear(const char* name, int dtype, int M, int N, int K1, int K2, bool bias, bool resid, bool rowb,
+                        int act, float alpha, float beta, bool out_f32, int splitk) {
+  Buf A1, W1, A2, W2, R, RB, C; std::vector<float> hb(N);
+  A1.init((size_t)M * K1, dtype); W1.init((size_t)N * K1, dtype, 0.1f);
+  if (K2) { A2.init((size_t)M * K2, dtype); W2.init((size_t)N * K2, dtype, 0.1f); }
+  const int rpb = 7; const int nb = (M + rpb - 1) / rpb;
+  if (resid) R.init((size_t)M * N, dtype);
+  if (rowb) RB.init((size_t)nb * N, dtype);
+  float* dbias = nullptr;
+  if (bias) { for (auto& v : hb) v = frand(); HIPCHK(hipMalloc(&dbias, N * 4)); HIPCHK(hipMemcpy(dbias, hb.data(), N * 4, hipMemcpyHostToDevice)); }
+  const bool atomic = splitk > 1;
+  const int odt = (out_f32 || atomic) ? CL_F32 : dtype;
+  C.init((size_t)M * N, odt, 1.0f, true);
+  GemmParams p{}; p.A1 = A1.d; p.lda1 = K1; p.K1 = K1; p.W1 = W1.d; p.ldw1 = K1;
+  if (K2) { p.A2 = A2.d; p.lda2 = K2; p.K2 = K2; p.W2 = W2.d; p.ldw2 = K2; }
+  p.M = M; p.N = N; p.mode = GEMM_LINEAR; p.zero_page = g_zero; p.bias = dbias;
+  if (rowb) { p.rowbias = RB.d; p.ldrb = N; p.rows_per_batch = rpb; }
+  if (resid) { p.residual = R.d; p.ldr = N; }
+  p.alpha = alpha; p.beta = beta; p.act = act; p.C = C.d; p.ldc = N; p.out_f32 = out_f32; p.atomic = atomic; p.splitk = splitk;
+  int rc = launch_gemm(p, dtype, 0);
+  HIPCHK(hipDeviceSynchronize());
+  if (rc) { printf("[FAIL] %s rc=%d\n", name, rc); g_fail++; return; }
+  C.download(odt);
+  double num = 0, den = 0;
+  for (int m = 0; m < M; ++m) for (int n = 0; n < N; ++n) {
+    double s = 0;
+    for (int k = 0; k < K1; ++k) s += (double)A1.h[(size_t)m * K1 + k] * W1.h[(size_t)n * K1 + k];
+    for (int k = 0; k < K2; ++k) s += (double)A2.h[(size_t)m * K2 + k] * W2.h[(size_t)n * K2 + k];
+    if (bias) s += hb[n];
+    if (rowb) s += RB.h[(size_t)(m / rpb) * N + n];
+    if (act == ACT_SILU) s = s / (1.0 + std::exp(-s));
+    s *= alpha;
+    if (resid) s += beta * R.h[(size_t)m * N + n];
+    double d = C.h[(size_t)m * N + n] - s; num += d * d; den += s * s;
+  }
+  report(name, num, den, odt == CL_BF16 ? 4e-3 : 2e-5);
+}
+
+// ---------------- conv cases ----------------
+static void case_conv(const char* name, int dtype, int mode, int B, int Hin, int Win, int C, int N) {
+  int Hout, Wout;
+  if (mode == GEMM_CONV_S1) { Hout = Hin; Wout = Win; }
+  else if (mode == GEMM_CONV_S2) { Hout = Hin / 2; Wout = Win / 2; }
+  else { Hout = 2 * Hin; Wout = 2 * Win; }
+  const int M = B * Hout * Wout;
+  Buf X, W, Cb; std::vector<float> hb(N);
+  X.init((size_t)B * Hin * Win * C, dtype); W.init((size_t)N * 9 * C, dtype, 0.1f);
+  for (auto& v : hb) v = frand();
+  float* dbias; HIPCHK(hipMalloc(&dbias, N * 4)); HIPCHK(hipMemcpy(dbias, hb.data(), N * 4, hipMemcpyHostToDevice));
+  Cb.init((size_t)M * N, CL_F32, 1.0f, true);
+  GemmParams p{}; p.A1 = X.d; p.lda1 = C; p.K1 = C; p.W1 = W.d; p.ldw1 = 9 * C; p.M = M; p.N = N; p.mode = mode;
+  p.B = B; p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout; p.zero_page = g_zero; p.bias = dbias;
+  p.alpha = 1.f; p.beta = 0.f; p.C = Cb.d; p.ldc = N; p.out_f32 = 1; p.splitk = 1;
+  int rc = launch_gemm(p, dtype, 0);
+  HIPCHK(hipDeviceSynchronize());
+  if (rc) { printf("[FAIL] %s rc=%d\n", name, rc); g_fail++; return; }
+  Cb.download(CL_F32);
+  double num = 0, den = 0;
+  for (int b = 0; b < B; ++b) for (int oy = 0; oy < Hout; ++oy) for (int ox = 0; ox < Wout; ++ox) for (int n = 0; n < N; ++n) {
+    double s = hb[n];
+    for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) {
+      int iy, ix; bool ok;
+      if (mode == GEMM_CONV_S1) { iy = oy + ky - 1; ix = ox + kx - 1; ok = iy >= 0 && iy < Hin && ix >= 0 && ix < Win; }
+      else if (mode == GEMM_CONV_S2) { iy = 2 * oy + ky - 1; ix = 2 * ox + kx - 1; ok = iy >= 0 && iy < Hin && ix >= 0 && ix < Win; }
+      else {
+        int vy = oy + ky - 1, vx = ox + kx - 1; ok = vy >= 0 && vy < 2 * Hin && vx >= 0 && vx < 2 * Win;
+        if (mode == GEMM_CONV_T2) ok = ok && !(vy & 1) && !(vx & 1);
+        iy = vy >> 1; ix = vx >> 1;
+      }
+      if (!ok) continue;
+      const float* xp = &X.h[(((size_t)b * Hin + iy) * Win + ix) * C];
+      const float* wp = &W.h[((size_t)n * 9 + ky * 3 + kx) * C];
+      for (int c = 0; c < C; ++c) s += (double)xp[c] * wp[c];
+    }
+    double d = Cb.h[(((size_t)b * Hout + oy) * Wout + ox) * N + n] - s; num += d * d; den += s * s;
+  }
+  report(name, num, den, 2e-5);
+}
+
+// ---------------- timing ----------------
+static void time_case(const char* name, int dtype, int mode, int M, int N, int K1, int B, int H, int W, int K2 = 0) {
+  Buf A, Wt, C, A2, W2;
+  const int taps = mode == GEMM_LINEAR ? 1 : 9;
+  A.init(mode == GEMM_LINEAR ? (size_t)M * K1 : (size_t)B * H * W * K1, dtype);
+  Wt.init((size_t)N * taps * K1, dtype, 0.05f);
+  if (K2) { A2.init((size_t)M * K2, dtype); W2.init((size_t)N * K2, dtype, 0.05f); }
+  C.init((size_t)M * N, dtype, 1.f, true);
+  GemmParams p{}; p.A1 = A.d; p.lda1 = K1; p.K1 = K1; p.W1 = Wt.d; p.ldw1 = taps * K1; p.M = M; p.N = N; p.mode = mode;
+  if (K2) { p.A2 = A2.d; p.lda2 = K2; p.K2 = K2; p.W2 = W2.d; p.ldw2 = K2; }
+  p.B = B; p.Hin = H; p.Win = W; p.Hout = H; p.Wout = W; p.zero_page = g_zero; p.alpha = 1.f; p.C = C.d; p.ldc = N; p.splitk = 1;
+  hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) launch_gemm(p, dtype, 0);
+  HIPCHK(hipDeviceSynchronize());
+  const int iters = 20;
+  HIPCHK(hipEventRecord(e0, 0));
+  for (int i = 0; i < iters; ++i) launch_gemm(p, dtype, 0);
+  HIPCHK(hipEventRecord(e1, 0)); HIPCHK(hipEventSynchronize(e1));
+  float ms; HIPCHK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+  double fl = 2.0 * M * N * ((double)taps * K1 + K2);
+  printf("[TIME] %-44s %8.3f ms  %8.1f TFLOP/s\n", name, ms, fl / ms * 1e-9);
+  hipFree(A.d); hipFree(Wt.d); hipFree(C.d); if (K2) { hipFree(A2.d); hipFree(W2.d); }
+}
+
+int main(int argc, char** argv) {
+  hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, 0));
+  printf("device: %s  CUs=%d  arch=%s\n", prop.name, prop.multiProcessorCount, prop.gcnArchName);
+  HIPCHK(hipMalloc(&g_zero, 4096)); HIPCHK(hipMemset(g_zero, 0, 4096));
+
+  case_linear("linear bf16 300x200x96 plain", CL_BF16, 300, 200, 96, 0, false, false, false, 0, 1.f, 0.f, true, 1);
+  case_linear("linear bf16 300x200x96 bf16-out", CL_BF16, 300, 200, 96, 0, false, false, false, 0, 1.f, 0.f, false, 1);
+  case_linear("linear bf16 bias+resid alpha/beta", CL_BF16, 257, 136, 160, 0, true, true, false, 0, 0.5f, 2.0f, true, 1);
+  case_linear("linear bf16 lora K2=64", CL_BF16, 300, 200, 96, 64, true, false, false, 0, 1.f, 0.f, true, 1);
+  case_linear("linear bf16 rowbias+silu", CL_BF16, 70, 72, 64, 0, true, false, true, ACT_SILU, 1.f, 0.f, true, 1);
+  case_linear("linear bf16 splitK=3 atomic", CL_BF16, 100, 64, 32 * 9, 0, false, false, false, 0, 1.f, 0.f, true, 3);
+  case_linear("linear bf16 big-tile 1000x520x256", CL_BF16, 3000, 1032, 256, 0, true, true, false, 0, 1.f, 1.f, true, 1);
+  case_linear("linear f32 130x72x48", CL_F32, 130, 72, 48, 0, true, true, false, 0, 1.f, 1.f, true, 1);
+  case_linear("linear f32 lora K2=16 big", CL_F32, 2100, 1032, 64, 16, true, false, false, 0, 1.f, 0.f, true, 1);
+  case_linear("linear bf16 M=8 (emb)", CL_BF16, 8, 1280, 320, 32, true, false, false, ACT_SILU, 1.f, 0.f, false, 1);
+
+  case_conv("conv3x3 s1 bf16 2x12x12x32->64", CL_BF16, GEMM_CONV_S1, 2, 12, 12, 32, 64);
+  case_conv("conv3x3 s1 bf16 big 2x40x40x64->136", CL_BF16, GEMM_CONV_S1, 2, 40, 40, 64, 136);
+  case_conv("conv3x3 s2 bf16 2x12x12x32->64", CL_BF16, GEMM_CONV_S2, 2, 12, 12, 32, 64);
+  case_conv("conv3x3 up2 bf16 2x6x6x32->64", CL_BF16, GEMM_CONV_UP2, 2, 6, 6, 32, 64);
+  case_conv("conv3x3 t2 bf16 2x6x6x32->64", CL_BF16, GEMM_CONV_T2, 2, 6, 6, 32, 64);
+  case_conv("conv3x3 s1 f32 1x9x7x16->24", CL_F32, GEMM_CONV_S1, 1, 9, 7, 16, 24);
+
+  if (argc > 1 && !strcmp(argv[1], "--time")) {
+    time_case("gemm bf16 4096^3", CL_BF16, GEMM_LINEAR, 4096, 4096, 4096, 0, 0, 0);
+    time_case("gemm bf16 32768x320x320 (to_q @64^2 B8)", CL_BF16, GEMM_LINEAR, 32768, 320, 320, 0, 0, 0);
+    time_case("gemm bf16 32768x320x320+r128 (LoRA)", CL_BF16, GEMM_LINEAR, 32768, 320, 320, 0, 0, 0, 128);
+    time_case("gemm bf16 32768x2560x320 (GEGLU proj)", CL_BF16, GEMM_LINEAR, 32768, 2560, 320, 0, 0, 0);
+    time_case("gemm bf16 8192x1280x1280 (@16^2... )", CL_BF16, GEMM_LINEAR, 2048, 1280, 1280, 0, 0, 0);
+    time_case("conv bf16 320->320 @64^2 B8", CL_BF16, GEMM_CONV_S1, 8 * 64 * 64, 320, 320, 8, 64, 64);
+    time_case("conv bf16 640->640 @32^2 B8", CL_BF16, GEMM_CONV_S1, 8 * 32 * 32, 640, 640, 8, 32, 32);
+    time_case("conv bf16 1280->1280 @16^2 B8", CL_BF16, GEMM_CONV_S1, 8 * 16 * 16, 1280, 1280, 8, 16, 16);
+    time_case("conv bf16 1280->1280 @8^2 B8", CL_BF16, GEMM_CONV_S1, 8 * 8 * 8, 1280, 1280, 8, 8, 8);
+    time_case("conv bf16 2560->1280 @16^2 B8", CL_BF16, GEMM_CONV_S1, 8 * 16 * 16, 1280, 2560, 8, 16, 16);
+    time_case("gemm f32 4096x1280x1280", CL_F32, GEMM_LINEAR, 4096, 1280, 1280, 0, 0, 0);
+  }
+  printf("probe_gemm: %s (%d failures)\n", g_fail ? "FAILED" : "ALL PASS", g_fail);
+  return g_fail ? 1 : 0;
+}
