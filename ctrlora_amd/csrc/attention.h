@@ -1,0 +1,38 @@
+// Argument blocks of the fused attention kernels (attention_fwd.hip / attention_bwd.hip).
+#pragma once
+#include "common.h"
+
+namespace cl {
+
+// Layouts (T = bf16 or float), heads h in [0,H), head dim DH, inner = H*DH:
+//   Q  : [B*N,   ldq]  row b*N+n,   head h at columns [h*DH, (h+1)*DH)
+//   K  : [B*Nkv, ldk]
+//   V  : [B*Nkv, ldv]                       (backward only)
+//   Vt : [B][inner][nkv_pad]  transposed V, zero padded to a multiple of 64 keys (forward)
+//   O  : [B*N,   ldo]
+//   LSE: [B][H][N] fp32, log2-domain log-sum-exp of scale*log2(e)*q.k  (saved for backward)
+struct AttnFwdArgs {
+  const void* Q; long ldq;
+  const void* K; long ldk;
+  const void* Vt; int nkv_pad;
+  void* O; long ldo;
+  float* LSE;
+  int B, H, N, Nkv, DH;
+  float scale;   // d_head^-0.5 (ldm/modules/attention.py:151)
+};
+
+struct AttnBwdArgs {
+  const void* Q; long ldq; const void* K; long ldk; const void* V; long ldv;
+  const void* O; long ldo; const void* dO; long lddo;
+  const void* Qt; const void* dOt; int n_pad;     // [B][inner][n_pad]   transposes over queries
+  const void* Kt; int nkv_pad;                    // [B][inner][nkv_pad] transpose over keys
+  const float* LSE; float* Delta;                 // [B][H][N]
+  void* dQ; long lddq; void* dK; long lddk; void* dV; long lddv;  // dK/dV may be null (frozen context)
+  int B, H, N, Nkv, DH;
+  float scale;
+};
+
+int attn_fwd(const AttnFwdArgs& a, int dtype, hipStream_t st);
+int attn_bwd(const AttnBwdArgs& a, int dtype, hipStream_t st);
+
+}  // namespace cl

@@ -1,0 +1,372 @@
+// HBM-bound elementwise / layout kernels of the CtrLoRA hot path (gfx950).
+// All activations are token-major [rows, C] with an explicit row stride so they
+// can address column slices of wider buffers (decoder concat, fused QKV).
+#include "elementwise.h"
+
+namespace cl {
+
+static inline int ew_grid(long nvec, int threads = 256) {
+  long g = (nvec + threads - 1) / threads;
+  if (g < 1) g = 1;
+  return (int)(g < 4096 ? g : 4096);
+}
+
+// ---------------------------------------------------------------- GEGLU (attention.py:49-56)
+template <typename T>
+__global__ void geglu_fwd_kernel(const T* __restrict__ h, long ldh, T* __restrict__ out, long ldo, long M, int F) {
+  const int F8 = F / 8;
+  const long n = M * F8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / F8; const int v = (int)(i - r * F8);
+    float a[8], g[8];
+    load8(h + r * ldh + v * 8, a);
+    load8(h + r * ldh + F + v * 8, g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] *= gelu_f(g[e]);
+    store8(out + r * ldo + v * 8, a);
+  }
+}
+template <typename T>
+__global__ void geglu_bwd_kernel(const T* __restrict__ h, long ldh, const T* __restrict__ dout, long lddo,
+                                 T* __restrict__ dh, long lddh, long M, int F) {
+  const int F8 = F / 8;
+  const long n = M * F8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / F8; const int v = (int)(i - r * F8);
+    float a[8], g[8], d[8], da[8], dg[8];
+    load8(h + r * ldh + v * 8, a);
+    load8(h + r * ldh + F + v * 8, g);
+    load8(dout + r * lddo + v * 8, d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { da[e] = d[e] * gelu_f(g[e]); dg[e] = d[e] * a[e] * dgelu_f(g[e]); }
+    store8(dh + r * lddh + v * 8, da);
+    store8(dh + r * lddh + F + v * 8, dg);
+  }
+}
+
+// ---------------------------------------------------------------- SiLU on small [rows, C] (emb path)
+template <typename T>
+__global__ void silu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long n8) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float f[8]; load8(x + i * 8, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e]);
+    store8(y + i * 8, f);
+  }
+}
+template <typename T>
+__global__ void silu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, long n8) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float f[8], d[8]; load8(x + i * 8, f); load8(dy + i * 8, d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d[e] *= dsilu_f(f[e]);
+    store8(dx + i * 8, d);
+  }
+}
+
+// ---------------------------------------------------------------- y = a*x + b*y over [rows, C] with strides
+template <typename T>
+__global__ void axpby_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy, long M, int C,
+                             float a, float b) {
+  const int C8 = C / 8;
+  const long n = M * C8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C8; const int v = (int)(i - r * C8);
+    float f[8], g[8];
+    load8(x + r * ldx + v * 8, f);
+    if (b != 0.f) {
+      load8(y + r * ldy + v * 8, g);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = a * f[e] + b * g[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = a * f[e];
+    }
+    store8(y + r * ldy + v * 8, f);
+  }
+}
+
+// ---------------------------------------------------------------- batched transpose with zero padding
+// in [Bt][R][C] (row stride ldi, batch stride bsi) -> out [Bt][C][Rpad] (row stride ldo >= Rpad, batch stride bso)
+template <typename U, typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const U* __restrict__ in, long ldi, long bsi,
+                                                        T* __restrict__ out, long ldo, long bso, int R, int C,
+                                                        int Rpad) {
+  __shared__ float tile[64][65];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const U* ib = in + (long)blockIdx.z * bsi;
+  T* ob = out + (long)blockIdx.z * bso;
+#pragma unroll 4
+  for (int k = 0; k < 16; ++k) {
+    const int r = r0 + ty + 4 * k, c = c0 + tx;
+    tile[ty + 4 * k][tx] = (r < R && c < C) ? to_f<U>(ib[(long)r * ldi + c]) : 0.f;
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int k = 0; k < 16; ++k) {
+    const int c = c0 + ty + 4 * k, r = r0 + tx;
+    if (c < C && r < Rpad) ob[(long)c * ldo + r] = from_f<T>(tile[tx][ty + 4 * k]);
+  }
+}
+
+// ---------------------------------------------------------------- NCHW fp32 <-> token-major T
+// in [B, Cin, HW] fp32 -> out [B*HW, ldo] T, channels [Cin, Cpad) zero filled
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_tok_kernel(const float* __restrict__ in, T* __restrict__ out,
+                                                          long ldo, int Cin, int Cpad, int HW) {
+  __shared__ float tile[64][65];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
+#pragma unroll 4
+  for (int k = 0; k < 16; ++k) {
+    const int c = c0 + ty + 4 * k, p = p0 + tx;
+    tile[ty + 4 * k][tx] = (c < Cin && p < HW) ? in[((long)b * Cin + c) * HW + p] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int k = 0; k < 16; ++k) {
+    const int p = p0 + ty + 4 * k, c = c0 + tx;
+    if (p < HW && c < Cpad) out[((long)b * HW + p) * ldo + c] = from_f<T>(tile[tx][ty + 4 * k]);
+  }
+}
+// in [B*HW, ldi] T -> out [B, C, HW] fp32  (out = alpha*in + beta*out)
+template <typename T>
+__global__ __launch_bounds__(256) void tok_to_nchw_kernel(const T* __restrict__ in, long ldi,
+                                                          float* __restrict__ out, int C, int HW, float alpha,
+                                                          float beta) {
+  __shared__ float tile[64][65];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
+#pragma unroll 4
+  for (int k = 0; k < 16; ++k) {
+    const int p = p0 + ty + 4 * k, c = c0 + tx;
+    tile[ty + 4 * k][tx] = (p < HW && c < C) ? to_f<T>(in[((long)b * HW + p) * ldi + c]) : 0.f;
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int k = 0; k < 16; ++k) {
+    const int c = c0 + ty + 4 * k, p = p0 + tx;
+    if (c < C && p < HW) {
+      float* o = out + ((long)b * C + c) * HW + p;
+      const float v = alpha * tile[tx][ty + 4 * k];
+      *o = beta != 0.f ? v + beta * *o : v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- timestep embedding (util.py:154-174)
+// out[b, i] = cos(t_b * f_i), out[b, half + i] = sin(t_b * f_i); freqs is the fp32 table the host
+// builds exactly as the reference does (exp(-ln(1e4) * arange(half) / half)).
+template <typename T>
+__global__ void timestep_embed_kernel(const long* __restrict__ t, const float* __restrict__ freqs,
+                                      T* __restrict__ out, long ldo, int B, int half) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * half) return;
+  const int b = i / half, k = i - b * half;
+  const float arg = (float)t[b] * freqs[k];
+  out[(long)b * ldo + k] = from_f<T>(cosf(arg));
+  out[(long)b * ldo + half + k] = from_f<T>(sinf(arg));
+}
+
+// ---------------------------------------------------------------- q_sample + MSE (ddpm.py:356-359,902)
+// x_noisy = sqrt_ac[t_b] * z + sqrt_1mac[t_b] * noise       (fp32, any layout; per = elems per sample)
+__global__ void qsample_kernel(const float* __restrict__ z, const float* __restrict__ noise,
+                               const long* __restrict__ t, const float* __restrict__ sqrt_ac,
+                               const float* __restrict__ sqrt_1mac, float* __restrict__ out, long per, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long tb = t[i / per];
+    out[i] = sqrt_ac[tb] * z[i] + sqrt_1mac[tb] * noise[i];
+  }
+}
+// loss += sum((eps - target)^2) / n ; d_eps = 2 (eps - target) / n * gscale
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ eps, const float* __restrict__ target,
+                                                  float* __restrict__ d_eps, float* __restrict__ loss, long n,
+                                                  float gscale) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const float inv = 1.0f / (float)n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float d = eps[i] - target[i];
+    acc += d * d;
+    if (d_eps) d_eps[i] = 2.0f * d * inv * gscale;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv);
+}
+
+// ---------------------------------------------------------------- DDIM update (ddim_hacked.py:192,203-231)
+// coef = device table [S][4] = {a_t, a_prev, sigma_t, sqrt(1 - a_t)} (fp32), row `index` is used.
+__global__ void ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ e_c,
+                                 const float* __restrict__ e_u, const float* __restrict__ noise,
+                                 const float* __restrict__ coef, int index, float scale,
+                                 float* __restrict__ x_prev, float* __restrict__ pred_x0, long n) {
+  const float a_t = coef[index * 4 + 0], a_prev = coef[index * 4 + 1];
+  const float sigma = coef[index * 4 + 2], s1m = coef[index * 4 + 3];
+  const float sqrt_at = sqrtf(a_t), sqrt_ap = sqrtf(a_prev), dir = sqrtf(1.0f - a_prev - sigma * sigma);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float e = e_c[i];
+    if (e_u) { const float u = e_u[i]; e = u + scale * (e - u); }
+    const float p0 = (x[i] - s1m * e) / sqrt_at;
+    float xp = sqrt_ap * p0 + dir * e;
+    if (noise) xp += sigma * noise[i];
+    x_prev[i] = xp;
+    if (pred_x0) pred_x0[i] = p0;
+  }
+}
+
+// ---------------------------------------------------------------- fused AdamW over one flat fp32 buffer
+// torch.optim.AdamW defaults (cldm_ctrlora_finetune.py:105): decoupled decay, bias correction.
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, long n, float lr, float beta1, float beta2, float eps,
+                             float wd, float bc1, float bc2_sqrt, float gscale) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gscale;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= (lr / bc1) * mi / denom;
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+
+// ---------------------------------------------------------------- 2x2 sum pool (data-gradient of nearest x2)
+// in [B, 2H, 2W, C] (ldi) -> out [B, H, W, C] (ldo), out (+)= sum of the 2x2 block
+template <typename T>
+__global__ void pool2x2_kernel(const T* __restrict__ in, long ldi, T* __restrict__ out, long ldo, int B, int H,
+                               int W, int C, int accumulate) {
+  const int C8 = C / 8;
+  const long n = (long)B * H * W * C8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % C8); long r = i / C8;
+    const int x = (int)(r % W); r /= W; const int y = (int)(r % H); const int b = (int)(r / H);
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    const long orow = ((long)b * H + y) * W + x;
+    if (accumulate) load8(out + orow * ldo + v * 8, s);
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        float f[8];
+        load8(in + (((long)b * 2 * H + 2 * y + dy) * 2 * W + 2 * x + dx) * ldi + v * 8, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += f[e];
+      }
+    store8(out + orow * ldo + v * 8, s);
+  }
+}
+
+// ---------------------------------------------------------------- strided 2-D convert fp32 -> T
+template <typename T>
+__global__ void pack_kernel(const float* __restrict__ in, long ldi, T* __restrict__ out, long ldo, long R, int C,
+                            int Cpad) {
+  const long n = R * Cpad;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / Cpad; const int c = (int)(i - r * Cpad);
+    out[r * ldo + c] = from_f<T>(c < C ? in[r * ldi + c] : 0.f);
+  }
+}
+
+// ================================================================= host launchers
+int geglu_fwd(int dtype, const void* h, long ldh, void* out, long ldo, long M, int F, hipStream_t st) {
+  if (F % 8 || ldh % 8 || ldo % 8) return CL_EINVAL;
+  if (dtype == CL_BF16) hipLaunchKernelGGL((geglu_fwd_kernel<bf16_t>), dim3(ew_grid(M * (F / 8))), dim3(256), 0, st, (const bf16_t*)h, ldh, (bf16_t*)out, ldo, M, F);
+  else hipLaunchKernelGGL((geglu_fwd_kernel<float>), dim3(ew_grid(M * (F / 8))), dim3(256), 0, st, (const float*)h, ldh, (float*)out, ldo, M, F);
+  CL_CHECK_LAUNCH(); return CL_OK;
+}
+int geglu_bwd(int dtype, const void* h, long ldh, const void* dout, long lddo, void* dh, long lddh, long M, int F, hipStream_t st) {
+  if (F % 8 || ldh % 8 || lddo % 8 || lddh % 8) return CL_EINVAL;
+  if (dtype == CL_BF16) hipLaunchKernelGGL((geglu_bwd_kernel<bf16_t>), dim3(ew_grid(M * (F / 8))), dim3(256), 0, st, (const bf16_t*)h, ldh, (const bf16_t*)dout, lddo, (bf16_t*)dh, lddh, M, F);
+  else hipLaunchKernelGGL((geglu_bwd_kernel<float>), dim3(ew_grid(M * (F / 8))), dim3(256), 0, st, (const float*)h, ldh, (const float*)dout, lddo, (float*)dh, lddh, M, F);
+  CL_CHECK_LAUNCH(); return CL_OK;
+}
+int silu_fwd(int dtype, const void* x, void* y, long n, hipStream_t st) {
+  if (n % 8) return CL_EINVAL;
+  if (dtype == CL_BF16) hipLaunchKernelGGL((silu_fwd_kernel<bf16_t>), dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, n / 8);
+  else hipLaunchKernelGGL((silu_fwd_kernel<float>), dim3(ew_grid(n / 8)), dim3(256), 0, st, (const float*)x, (float*)y, n / 8);
+  CL_CHECK_LAUNCH(); return CL_OK;
+}
+int silu_bwd(int dtype, const void* x, const void* dy, void* dx, long n, hipStream_t st) {
+  if (n % 8) return CL_EINVAL;
+  if (dtype == CL_BF16) hipLaunchKernelGGL((silu_bwd_kernel<bf16_t>), dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n / 8);
+  else hipLaunchKernelGGL((silu_bwd_kernel<float>), dim3(ew_grid(n / 8)), dim3(256), 0, st, (const float*)x, (const float*)dy, (float*)dx, n / 8);
+  CL_CHECK_LAUNCH(); return CL_OK;
+}
+int axpby(int dtype, const void* x, long ldx, void* y, long ldy, long M, int C, float a, float b, hipStream_t st) {
+  if (C % 8 || ldx % 8 || ldy % 8) return CL_EINVAL;
+  if (dtype == CL_BF16) hipLaunchKernelGGL((axpby_kernel<bf16_t>), dim3(ew_grid(M * (C / 8))), dim3(256), 0, st, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, M, C, a, b);
+  else hipLaunchKernelGGL((axpby_kernel<float>), dim3(ew_grid(M * (C / 8))), dim3(256), 0, st, (const float*)x, ldx, (float*)y, ldy, M, C, a, b);
+  CL_CHECK_LAUNCH(); return CL_OK;
+}
+int transpose(int in_dtype, int out_dtype, const void* in, long ldi, long bsi, void* out, long ldo, long bso,
+              int Bt, int R, int C, int Rpad, hipStream_t st) {
+  if (Rpad < R || ldo < Rpad) return CL_EINVAL;
+  dim3 grid((Rpad + 63) / 64, (C + 63) / 64, Bt);
+  if (in_dtype == CL_F32 && out_dtype == CL_BF16) hipLaunchKernelGGL((transpose_kernel<float, bf16_t>), grid, dim3(256), 0, st, (const float*)in, ldi, bsi, (bf16_t*)out, ldo, bso, R, C, Rpad);
+  else if (in_dtype == CL_F32 && out_dtype == CL_F32) hipLaunchKernelGGL((transpose_kernel<float, float>), grid, dim3(256), 0, st, (const float*)in, ldi, bsi, (float*)out, ldo, bso, R, C, Rpad);
+  else if (in_dtype == CL_BF16 && out_dtype == CL_BF16) hipLaunchKernelGGL((transpose_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)in, ldi, bsi, (bf16_t*)out, ldo, bso, R, C, Rpad);
+  else return CL_EINVAL;
+  CL_CHECK_LAUNCH(); return CL_OK;
+}
+int nchw_to_tok(int dtype, const float* in, void* out, long ldo, int B, int Cin, int Cpad, int HW, hipStream_t st) {
+  if (Cpad < Cin || ldo < Cpad) return CL_EINVAL;
+  dim3 grid((HW + 63) / 64, (Cpad + 63) / 64, B);
+  if (dtype == CL_BF16) hipLaunchKernelGGL((nchw_to_tok_kernel<bf16_t>), grid, dim3(256), 0, st, in, (bf16_t*)out, ldo, Cin, Cpad, HW);
+  else hipLaunchKernelGGL((nchw_to_tok_kernel<float>), grid, dim3(256), 0, st, in, (float*)out, ldo, Cin, Cpad, HW);
+  CL_CHECK_LAUNCH(); return CL_OK;
+}
+int tok_to_nchw(int dtype, const void* in, long ldi, float* out, int B, int C, int HW, float alpha, float beta, hipStream_t st) {
+  dim3 grid((HW + 63) / 64, (C + 63) / 64, B);
+  if (dtype == CL_BF16) hipLaunchKernelGGL((tok_to_nchw_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)in, ldi, out, C, HW, alpha, beta);
+  else hipLaunchKernelGGL((tok_to_nchw_kernel<float>), grid, dim3(256), 0, st, (const float*)in, ldi, out, C, HW, alpha, beta);
+  CL_CHECK_LAUNCH(); return CL_OK;
+}
+int timestep_embed(int dtype, const long* t, const float* freqs, void* out, long ldo, int B, int half, hipStream_t st) {
+  const int n = B * half;
+  if (dtype == CL_BF16) hipLaunchKernelGGL((timestep_embed_kernel<bf16_t>), dim3((n + 255) / 256), dim3(256), 0, st, t, freqs, (bf16_t*)out, ldo, B, half);
+  else hipLaunchKernelGGL((timestep_embed_kernel<float>), dim3((n + 255) / 256), dim3(256), 0, st, t, freqs, (float*)out, ldo, B, half);
+  CL_CHECK_LAUNCH(); return CL_OK;
+}
+int qsample(const float* z, const float* noise, const long* t, const float* sqrt_ac, const float* sqrt_1mac,
+            float* out, int B, long per, hipStream_t st) {
+  hipLaunchKernelGGL(qsample_kernel, dim3(ew_grid(B * per)), dim3(256), 0, st, z, noise, t, sqrt_ac, sqrt_1mac, out, per, (long)B * per);
+  CL_CHECK_LAUNCH(); return CL_OK;
+}
+int mse_loss(const float* eps, const float* target, float* d_eps, float* loss, long n, float gscale, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
+  if (e != hipSuccess) return CL_ELAUNCH;
+  hipLaunchKernelGGL(mse_kernel, dim3(ew_grid(n) < 256 ? ew_grid(n) : 256), dim3(256), 0, st, eps, target, d_eps, loss, n, gscale);
+  CL_CHECK_LAUNCH(); return CL_OK;
+}
+int ddim_step(const float* x, const float* e_c, const float* e_u, const float* noise, const float* coef, int index,
+              float scale, float* x_prev, float* pred_x0, long n, hipStream_t st) {
+  hipLaunchKernelGGL(ddim_step_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, e_c, e_u, noise, coef, index, scale, x_prev, pred_x0, n);
+  CL_CHECK_LAUNCH(); return CL_OK;
+}
+int adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+          float wd, int step, float gscale, hipStream_t st) {
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n)), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, wd, bc1, sqrtf(bc2), gscale);
+  CL_CHECK_LAUNCH(); return CL_OK;
+}
+int pool2x2(int dtype, const void* in, long ldi, void* out, long ldo, int B, int H, int W, int C, int accumulate, hipStream_t st) {
+  if (C % 8 || ldi % 8 || ldo % 8) return CL_EINVAL;
+  const long n = (long)B * H * W * (C / 8);
+  if (dtype == CL_BF16) hipLaunchKernelGGL((pool2x2_kernel<bf16_t>), dim3(ew_grid(n)), dim3(256), 0, st, (const bf16_t*)in, ldi, (bf16_t*)out, ldo, B, H, W, C, accumulate);
+  else hipLaunchKernelGGL((pool2x2_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, st, (const float*)in, ldi, (float*)out, ldo, B, H, W, C, accumulate);
+  CL_CHECK_LAUNCH(); return CL_OK;
+}
+int pack2d(int dtype, const float* in, long ldi, void* out, long ldo, long R, int C, int Cpad, hipStream_t st) {
+  if (Cpad < C || ldo < Cpad) return CL_EINVAL;
+  if (dtype == CL_BF16) hipLaunchKernelGGL((pack_kernel<bf16_t>), dim3(ew_grid(R * Cpad)), dim3(256), 0, st, in, ldi, (bf16_t*)out, ldo, R, C, Cpad);
+  else hipLaunchKernelGGL((pack_kernel<float>), dim3(ew_grid(R * Cpad)), dim3(256), 0, st, in, ldi, (float*)out, ldo, R, C, Cpad);
+  CL_CHECK_LAUNCH(); return CL_OK;
+}
+
+}  // namespace cl

@@ -23,28 +23,9 @@
 // The accumulator tile is staged through LDS so the epilogue reads residuals
 // and writes outputs as whole 16-byte vectors.
 #include "gemm.h"
+#include "mma.h"
 
 namespace cl {
-
-template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
-  // frag = 8 bf16 (one 16-byte LDS chunk) : k = 8*(lane>>4) + [0,8)
-  static __device__ __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
-    bf16x8_t av = __builtin_bit_cast(bf16x8_t, a);
-    bf16x8_t bv = __builtin_bit_cast(bf16x8_t, b);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, c, 0, 0, 0);
-  }
-};
-template <> struct Mma<float> {
-  // frag = 4 floats; MFMA step s contracts k = 4*(lane>>4) + s over the four
-  // lane groups (any consistent k partition is valid).
-  static __device__ __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
-  }
-};
 
 template <typename T, int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {

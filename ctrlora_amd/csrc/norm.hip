@@ -1,0 +1,479 @@
+// GroupNorm(32)+SiLU and LayerNorm, forward and backward, for NHWC / token-major
+// activations on gfx950.  HBM-bound kernels: 16-byte vector loads, fp32
+// statistics (GroupNorm32 computes in fp32, ldm/modules/diffusionmodules/util.py:217-219),
+// wave64 shuffle reductions, SiLU fused into the normalisation pass.
+//
+//   GroupNorm fwd : gn_partial (per-channel sum / sumsq per pixel chunk)
+//                   -> gn_finalize (per-(b,group) mean/rstd, per-(b,channel) scale/shift)
+//                   -> gn_apply   (y = silu?(x*scale + shift))
+//   GroupNorm bwd : gn_bwd_partial -> gn_bwd_finalize (+ dgamma/dbeta) -> gn_bwd_apply
+//   LayerNorm     : one wave per row, row kept in registers (D <= 2048)
+//
+// Reference ops replaced: ResBlock in_layers[0:2]/out_layers[0:2]
+// (openaimodel.py:201-202,225-226; eps 1e-5), SpatialTransformer.norm
+// (attention.py:88-89,295; eps 1e-6, no SiLU), BasicTransformerBlock.norm1-3
+// (attention.py:263-265; eps 1e-5), UNetModel.out[0:2] (openaimodel.py:726-728).
+#include "norm.h"
+
+namespace cl {
+
+static constexpr int GN_MAX_THREADS = 512;
+
+struct GnGeom { int VX, PY, threads, nchunk, ppc; };
+
+static GnGeom gn_geom(int B, int HW, int C) {
+  GnGeom g;
+  const int C8 = C / 8;
+  g.VX = C8 < 320 ? C8 : 320;
+  if (g.VX > GN_MAX_THREADS) g.VX = GN_MAX_THREADS;
+  g.PY = 256 / g.VX; if (g.PY < 1) g.PY = 1;
+  g.threads = g.VX * g.PY;
+  // enough blocks to fill 256 CUs a few times over, at least 4 pixels per py lane
+  int want = (1024 + B - 1) / B;
+  int maxc = HW / (g.PY * 4); if (maxc < 1) maxc = 1;
+  g.nchunk = want < maxc ? want : maxc;
+  if (g.nchunk > 256) g.nchunk = 256;
+  g.ppc = (HW + g.nchunk - 1) / g.nchunk;
+  g.nchunk = (HW + g.ppc - 1) / g.ppc;
+  return g;
+}
+
+long gn_ws_floats(int B, int HW, int C) {
+  GnGeom g = gn_geom(B, HW, C);
+  return (long)B * g.nchunk * C * 2 + (long)B * C * 4;
+}
+
+// ------------------------------------------------------------------ forward
+
+template <typename T>
+__global__ void gn_partial_kernel(const T* __restrict__ x, long ldx, int HW, int C, int VX, int PY,
+                                  int ppc, int nchunk, float* __restrict__ partial) {
+  extern __shared__ float red[];  // [PY][VX][16]
+  const int C8 = C / 8;
+  const int vx = threadIdx.x % VX, py = threadIdx.x / VX;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int p0 = chunk * ppc, p1 = min(HW, p0 + ppc);
+  for (int v = vx; v < C8; v += VX) {
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    for (int p = p0 + py; p < p1; p += PY) {
+      float f[8];
+      load8(x + ((long)b * HW + p) * ldx + v * 8, f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+    }
+    float* r = red + (py * VX + vx) * 16;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { r[e] = s[e]; r[8 + e] = q[e]; }
+    __syncthreads();
+    if (py == 0) {
+      for (int k = 1; k < PY; ++k) {
+        const float* o = red + (k * VX + vx) * 16;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] += o[e]; q[e] += o[8 + e]; }
+      }
+      float* dst = partial + (((long)b * nchunk + chunk) * C + v * 8) * 2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { dst[2 * e] = s[e]; dst[2 * e + 1] = q[e]; }
+    }
+    __syncthreads();
+  }
+}
+
+// one block per batch sample: per-(b,group) mean/rstd and per-(b,channel) scale/shift
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nchunk, int HW, int C, int G,
+                                   float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ stats /*[B][G][2]*/, float* __restrict__ coef /*[B][C][2]*/) {
+  extern __shared__ double sm[];  // [C][2] then [G][2]
+  double* cs = sm; double* gs = sm + 2 * C;
+  const int b = blockIdx.x, cg = C / G;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double s = 0, q = 0;
+    for (int k = 0; k < nchunk; ++k) {
+      const float* p = partial + (((long)b * nchunk + k) * C + c) * 2;
+      s += p[0]; q += p[1];
+    }
+    cs[2 * c] = s; cs[2 * c + 1] = q;
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    double s = 0, q = 0;
+    for (int c = g * cg; c < (g + 1) * cg; ++c) { s += cs[2 * c]; q += cs[2 * c + 1]; }
+    const double n = (double)HW * cg;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0) var = 0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    gs[2 * g] = mean; gs[2 * g + 1] = rstd;
+    stats[((long)b * G + g) * 2] = (float)mean;
+    stats[((long)b * G + g) * 2 + 1] = (float)rstd;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int g = c / cg;
+    const double sc = gs[2 * g + 1] * (double)gamma[c];
+    coef[((long)b * C + c) * 2] = (float)sc;
+    coef[((long)b * C + c) * 2 + 1] = (float)((double)beta[c] - gs[2 * g] * sc);
+  }
+}
+
+template <typename T, bool SILU>
+__global__ void gn_apply_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy, int HW, int C,
+                                int VX, int PY, int ppc, const float* __restrict__ coef) {
+  const int C8 = C / 8;
+  const int vx = threadIdx.x % VX, py = threadIdx.x / VX;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int p0 = chunk * ppc, p1 = min(HW, p0 + ppc);
+  for (int v = vx; v < C8; v += VX) {
+    float sc[8], sh[8];
+    const float* cf = coef + ((long)b * C + v * 8) * 2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = cf[2 * e]; sh[e] = cf[2 * e + 1]; }
+    for (int p = p0 + py; p < p1; p += PY) {
+      float f[8];
+      const long row = (long)b * HW + p;
+      load8(x + row * ldx + v * 8, f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float z = f[e] * sc[e] + sh[e];
+        f[e] = SILU ? silu_f(z) : z;
+      }
+      store8(y + row * ldy + v * 8, f);
+    }
+  }
+}
+
+template <typename T>
+static int gn_fwd_t(const GnArgs& a, hipStream_t st) {
+  const GnGeom g = gn_geom(a.B, a.HW, a.C);
+  float* partial = a.ws;
+  float* coef = a.ws + (long)a.B * g.nchunk * a.C * 2;
+  dim3 grid(g.nchunk, a.B);
+  hipLaunchKernelGGL((gn_partial_kernel<T>), grid, dim3(g.threads), g.threads * 64, st,
+                     (const T*)a.x, a.ldx, a.HW, a.C, g.VX, g.PY, g.ppc, g.nchunk, partial);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.B), dim3(256), (2 * a.C + 2 * a.G) * sizeof(double), st,
+                     partial, g.nchunk, a.HW, a.C, a.G, a.eps, a.gamma, a.beta, a.stats, coef);
+  if (a.silu)
+    hipLaunchKernelGGL((gn_apply_kernel<T, true>), grid, dim3(g.threads), 0, st,
+                       (const T*)a.x, a.ldx, (T*)a.y, a.ldy, a.HW, a.C, g.VX, g.PY, g.ppc, coef);
+  else
+    hipLaunchKernelGGL((gn_apply_kernel<T, false>), grid, dim3(g.threads), 0, st,
+                       (const T*)a.x, a.ldx, (T*)a.y, a.ldy, a.HW, a.C, g.VX, g.PY, g.ppc, coef);
+  CL_CHECK_LAUNCH();
+  return CL_OK;
+}
+
+int gn_fwd(const GnArgs& a, int dtype, hipStream_t st) {
+  if (a.C % 8 || a.C % a.G || a.ldx % 8 || a.ldy % 8 || a.C > 8192) return CL_EINVAL;
+  if (a.C / 8 > 320 && (a.C / 8) % 320) return CL_EINVAL;  // uniform trip count across the block
+  return dtype == CL_BF16 ? gn_fwd_t<bf16_t>(a, st) : gn_fwd_t<float>(a, st);
+}
+
+// ------------------------------------------------------------------ backward
+
+template <typename T, bool SILU>
+__global__ void gn_bwd_partial_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy, long lddy,
+                                      int HW, int C, int G, int VX, int PY, int ppc, int nchunk,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ stats, float* __restrict__ partial) {
+  extern __shared__ float red[];
+  const int C8 = C / 8, cg = C / G;
+  const int vx = threadIdx.x % VX, py = threadIdx.x / VX;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int p0 = chunk * ppc, p1 = min(HW, p0 + ppc);
+  for (int v = vx; v < C8; v += VX) {
+    float ga[8], be[8], mu[8], rs[8], s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = v * 8 + e, g = c / cg;
+      ga[e] = gamma[c]; be[e] = beta[c];
+      mu[e] = stats[((long)b * G + g) * 2]; rs[e] = stats[((long)b * G + g) * 2 + 1];
+      s[e] = 0.f; q[e] = 0.f;
+    }
+    for (int p = p0 + py; p < p1; p += PY) {
+      float f[8], d[8];
+      const long row = (long)b * HW + p;
+      load8(x + row * ldx + v * 8, f);
+      load8(dy + row * lddy + v * 8, d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (f[e] - mu[e]) * rs[e];
+        float dz = d[e];
+        if (SILU) dz *= dsilu_f(xh * ga[e] + be[e]);
+        s[e] += dz; q[e] += dz * xh;
+      }
+    }
+    float* r = red + (py * VX + vx) * 16;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { r[e] = s[e]; r[8 + e] = q[e]; }
+    __syncthreads();
+    if (py == 0) {
+      for (int k = 1; k < PY; ++k) {
+        const float* o = red + (k * VX + vx) * 16;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] += o[e]; q[e] += o[8 + e]; }
+      }
+      float* dst = partial + (((long)b * nchunk + chunk) * C + v * 8) * 2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { dst[2 * e] = s[e]; dst[2 * e + 1] = q[e]; }
+    }
+    __syncthreads();
+  }
+}
+
+// per (b): channel sums -> group sums -> apply coefficients; optional dgamma/dbeta accumulation
+__global__ void gn_bwd_finalize_kernel(const float* __restrict__ partial, int nchunk, int HW, int C, int G,
+                                       const float* __restrict__ gamma, const float* __restrict__ stats,
+                                       float* __restrict__ bcoef /*[B][C][4]: k1,k2,k3,_*/,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  extern __shared__ double sm[];
+  double* cs = sm; double* gs = sm + 2 * C;
+  const int b = blockIdx.x, cg = C / G;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double s = 0, q = 0;
+    for (int k = 0; k < nchunk; ++k) {
+      const float* p = partial + (((long)b * nchunk + k) * C + c) * 2;
+      s += p[0]; q += p[1];
+    }
+    cs[2 * c] = s; cs[2 * c + 1] = q;
+    if (dgamma) { atomicAdd(dgamma + c, (float)q); atomicAdd(dbeta + c, (float)s); }
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    double s1 = 0, s2 = 0;
+    for (int c = g * cg; c < (g + 1) * cg; ++c) { s1 += gamma[c] * cs[2 * c]; s2 += gamma[c] * cs[2 * c + 1]; }
+    const double n = (double)HW * cg;
+    gs[2 * g] = s1 / n; gs[2 * g + 1] = s2 / n;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int g = c / cg;
+    const double rstd = stats[((long)b * G + g) * 2 + 1];
+    float* o = bcoef + ((long)b * C + c) * 4;
+    o[0] = (float)(rstd * gamma[c]); o[1] = (float)(rstd * gs[2 * g]); o[2] = (float)(rstd * gs[2 * g + 1]); o[3] = 0.f;
+  }
+}
+
+template <typename T, bool SILU>
+__global__ void gn_bwd_apply_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy, long lddy,
+                                    const T* __restrict__ accum, long ldacc, T* __restrict__ dx, long lddx,
+                                    int HW, int C, int G, int VX, int PY, int ppc,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ stats, const float* __restrict__ bcoef) {
+  const int C8 = C / 8, cg = C / G;
+  const int vx = threadIdx.x % VX, py = threadIdx.x / VX;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int p0 = chunk * ppc, p1 = min(HW, p0 + ppc);
+  for (int v = vx; v < C8; v += VX) {
+    float ga[8], be[8], mu[8], rs[8], k1[8], k2[8], k3[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = v * 8 + e, g = c / cg;
+      ga[e] = gamma[c]; be[e] = beta[c];
+      mu[e] = stats[((long)b * G + g) * 2]; rs[e] = stats[((long)b * G + g) * 2 + 1];
+      const float* o = bcoef + ((long)b * C + c) * 4;
+      k1[e] = o[0]; k2[e] = o[1]; k3[e] = o[2];
+    }
+    for (int p = p0 + py; p < p1; p += PY) {
+      float f[8], d[8], ac[8];
+      const long row = (long)b * HW + p;
+      load8(x + row * ldx + v * 8, f);
+      load8(dy + row * lddy + v * 8, d);
+      if (accum) load8(accum + row * ldacc + v * 8, ac);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (f[e] - mu[e]) * rs[e];
+        float dz = d[e];
+        if (SILU) dz *= dsilu_f(xh * ga[e] + be[e]);
+        float r = dz * k1[e] - k2[e] - xh * k3[e];
+        if (accum) r += ac[e];
+        f[e] = r;
+      }
+      store8(dx + row * lddx + v * 8, f);
+    }
+  }
+}
+
+template <typename T>
+static int gn_bwd_t(const GnBwdArgs& a, hipStream_t st) {
+  const GnGeom g = gn_geom(a.B, a.HW, a.C);
+  float* partial = a.ws;
+  float* bcoef = a.ws + (long)a.B * g.nchunk * a.C * 2;
+  dim3 grid(g.nchunk, a.B);
+#define GN_BWD_LAUNCH(S)                                                                                       \
+  hipLaunchKernelGGL((gn_bwd_partial_kernel<T, S>), grid, dim3(g.threads), g.threads * 64, st, (const T*)a.x,   \
+                     a.ldx, (const T*)a.dy, a.lddy, a.HW, a.C, a.G, g.VX, g.PY, g.ppc, g.nchunk, a.gamma,       \
+                     a.beta, a.stats, partial);                                                                \
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(a.B), dim3(256), (2 * a.C + 2 * a.G) * sizeof(double), st,    \
+                     partial, g.nchunk, a.HW, a.C, a.G, a.gamma, a.stats, bcoef, a.dgamma, a.dbeta);            \
+  hipLaunchKernelGGL((gn_bwd_apply_kernel<T, S>), grid, dim3(g.threads), 0, st, (const T*)a.x, a.ldx,           \
+                     (const T*)a.dy, a.lddy, (const T*)a.accum, a.ldacc, (T*)a.dx, a.lddx, a.HW, a.C, a.G,      \
+                     g.VX, g.PY, g.ppc, a.gamma, a.beta, a.stats, bcoef);
+  if (a.silu) { GN_BWD_LAUNCH(true) } else { GN_BWD_LAUNCH(false) }
+#undef GN_BWD_LAUNCH
+  CL_CHECK_LAUNCH();
+  return CL_OK;
+}
+
+int gn_bwd(const GnBwdArgs& a, int dtype, hipStream_t st) {
+  if (a.C % 8 || a.C % a.G || a.ldx % 8 || a.lddy % 8 || a.lddx % 8 || a.C > 8192) return CL_EINVAL;
+  if (a.C / 8 > 320 && (a.C / 8) % 320) return CL_EINVAL;
+  if (a.accum && a.ldacc % 8) return CL_EINVAL;
+  if ((a.dgamma == nullptr) != (a.dbeta == nullptr)) return CL_EINVAL;
+  return dtype == CL_BF16 ? gn_bwd_t<bf16_t>(a, st) : gn_bwd_t<float>(a, st);
+}
+
+// ------------------------------------------------------------------ LayerNorm
+
+static constexpr int LN_MAXV = 4;  // vectors of 8 per lane -> D <= 2048
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y,
+                                                     long ldy, int M, int D, float eps,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta,
+                                                     float* __restrict__ stats /*[M][2]*/) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D8 = D / 8;
+  for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
+    float f[LN_MAXV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+      const int v = lane + 64 * k;
+      if (v < D8) {
+        load8(x + row * ldx + v * 8, f[k]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += f[k][e];
+      }
+    }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+      const int v = lane + 64 * k;
+      if (v < D8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = f[k][e] - mean; q += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+    if (lane == 0 && stats) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+      const int v = lane + 64 * k;
+      if (v < D8) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f[k][e] - mean) * rstd * gamma[v * 8 + e] + beta[v * 8 + e];
+        store8(y + row * ldy + v * 8, o);
+      }
+    }
+  }
+}
+
+// dx = rstd * (dyh - mean(dyh) - xh * mean(dyh * xh)),  dyh = dy * gamma ; optional (+ accum)
+// dgamma += sum_rows dy * xh ; dbeta += sum_rows dy   (fp32 atomics, one per column per block)
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy,
+                                                     long lddy, const T* __restrict__ accum, long ldacc,
+                                                     T* __restrict__ dx, long lddx, int M, int D,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ stats,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D8 = D / 8;
+  float gsum[LN_MAXV][8], bsum[LN_MAXV][8];
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gsum[k][e] = 0.f; bsum[k][e] = 0.f; }
+  for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
+    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    float xh[LN_MAXV][8], dh[LN_MAXV][8];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+      const int v = lane + 64 * k;
+      if (v < D8) {
+        float f[8], d[8];
+        load8(x + row * ldx + v * 8, f);
+        load8(dy + row * lddy + v * 8, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[k][e] = (f[e] - mean) * rstd;
+          gsum[k][e] += d[e] * xh[k][e];
+          bsum[k][e] += d[e];
+          dh[k][e] = d[e] * gamma[v * 8 + e];
+          c1 += dh[k][e]; c2 += dh[k][e] * xh[k][e];
+        }
+      }
+    }
+    c1 = wave_sum(c1) / D; c2 = wave_sum(c2) / D;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+      const int v = lane + 64 * k;
+      if (v < D8) {
+        float o[8];
+        if (accum) load8(accum + row * ldacc + v * 8, o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float r = rstd * (dh[k][e] - c1 - xh[k][e] * c2);
+          o[e] = accum ? o[e] + r : r;
+        }
+        store8(dx + row * lddx + v * 8, o);
+      }
+    }
+  }
+  if (dgamma) {
+    // one atomic per column per wave (grid is capped, so this stays cheap)
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+      const int v = lane + 64 * k;
+      if (v < D8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          atomicAdd(dgamma + v * 8 + e, gsum[k][e]);
+          atomicAdd(dbeta + v * 8 + e, bsum[k][e]);
+        }
+      }
+    }
+  }
+}
+
+static int ln_grid(int M) {
+  int g = (M + 3) / 4;
+  return g < 1024 ? g : 1024;
+}
+
+int ln_fwd(const LnArgs& a, int dtype, hipStream_t st) {
+  if (a.D % 8 || a.D > 64 * LN_MAXV * 8 || a.ldx % 8 || a.ldy % 8) return CL_EINVAL;
+  if (dtype == CL_BF16)
+    hipLaunchKernelGGL((ln_fwd_kernel<bf16_t>), dim3(ln_grid(a.M)), dim3(256), 0, st, (const bf16_t*)a.x, a.ldx,
+                       (bf16_t*)a.y, a.ldy, a.M, a.D, a.eps, a.gamma, a.beta, a.stats);
+  else
+    hipLaunchKernelGGL((ln_fwd_kernel<float>), dim3(ln_grid(a.M)), dim3(256), 0, st, (const float*)a.x, a.ldx,
+                       (float*)a.y, a.ldy, a.M, a.D, a.eps, a.gamma, a.beta, a.stats);
+  CL_CHECK_LAUNCH();
+  return CL_OK;
+}
+
+int ln_bwd(const LnBwdArgs& a, int dtype, hipStream_t st) {
+  if (a.D % 8 || a.D > 64 * LN_MAXV * 8 || a.ldx % 8 || a.lddy % 8 || a.lddx % 8) return CL_EINVAL;
+  if ((a.dgamma == nullptr) != (a.dbeta == nullptr)) return CL_EINVAL;
+  int grid = ln_grid(a.M);
+  if (a.dgamma && grid > 256) grid = 256;  // fewer, longer blocks: fewer dgamma atomics
+  if (dtype == CL_BF16)
+    hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)a.x, a.ldx,
+                       (const bf16_t*)a.dy, a.lddy, (const bf16_t*)a.accum, a.ldacc, (bf16_t*)a.dx, a.lddx, a.M,
+                       a.D, a.gamma, a.stats, a.dgamma, a.dbeta);
+  else
+    hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)a.x, a.ldx,
+                       (const float*)a.dy, a.lddy, (const float*)a.accum, a.ldacc, (float*)a.dx, a.lddx, a.M, a.D,
+                       a.gamma, a.stats, a.dgamma, a.dbeta);
+  CL_CHECK_LAUNCH();
+  return CL_OK;
+}
+
+}  // namespace cl

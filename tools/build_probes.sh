@@ -3,10 +3,12 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p build
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value"
+C=ctrlora_amd/csrc
 for p in "$@"; do
   case $p in
-    gemm) hipcc $FLAGS tools/probe_gemm.hip ctrlora_amd/csrc/gemm.hip -o build/probe_gemm ;;
+    gemm) hipcc $FLAGS tools/probe_gemm.hip $C/gemm.hip -o build/probe_gemm ;;
+    attn) hipcc $FLAGS tools/probe_attn.hip $C/attention_fwd.hip $C/elementwise.hip -o build/probe_attn ;;
     *) echo "unknown probe $p"; exit 1 ;;
   esac
 done
