@@ -10,13 +10,14 @@ namespace cl {
 //   V  : [B*Nkv, ldv]                       (backward only)
 //   Vt : [B][inner][nkv_pad]  transposed V, zero padded to a multiple of 64 keys (forward)
 //   O  : [B*N,   ldo]
-//   LSE: [B][H][N] fp32, log2-domain log-sum-exp of scale*log2(e)*q.k  (saved for backward)
+//   LSE: [B][H][lse_stride] fp32, log2-domain log-sum-exp of scale*log2(e)*q.k (saved for
+//        backward); lse_stride = N rounded up to a multiple of 64
 struct AttnFwdArgs {
   const void* Q; long ldq;
   const void* K; long ldk;
   const void* Vt; int nkv_pad;
   void* O; long ldo;
-  float* LSE;
+  float* LSE; int lse_stride;
   int B, H, N, Nkv, DH;
   float scale;   // d_head^-0.5 (ldm/modules/attention.py:151)
 };
@@ -26,7 +27,7 @@ struct AttnBwdArgs {
   const void* O; long ldo; const void* dO; long lddo;
   const void* Qt; const void* dOt; int n_pad;     // [B][inner][n_pad]   transposes over queries
   const void* Kt; int nkv_pad;                    // [B][inner][nkv_pad] transpose over keys
-  const float* LSE; float* Delta;                 // [B][H][N]
+  const float* LSE; float* Delta; int lse_stride; // [B][H][lse_stride]
   void* dQ; long lddq; void* dK; long lddk; void* dV; long lddv;  // dK/dV may be null (frozen context)
   int B, H, N, Nkv, DH;
   float scale;

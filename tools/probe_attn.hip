@@ -45,7 +45,7 @@ static void run_case(const char* name, int dtype, int B, int H, int N, int Nkv, 
   int rc = transpose(dtype == CL_BF16 ? CL_BF16 : CL_F32, dtype, V.d, ldv, (long)Nkv * ldv, Vt.d, pad, (long)inner * pad, B, Nkv, inner, pad, 0);
   if (dtype == CL_F32 && rc == 0) {}  // f32->f32 path
   AttnFwdArgs a{}; a.Q = Q.d; a.ldq = ldq; a.K = K.d; a.ldk = ldk; a.Vt = Vt.d; a.nkv_pad = pad; a.O = O.d; a.ldo = inner;
-  a.LSE = dlse; a.B = B; a.H = H; a.N = N; a.Nkv = Nkv; a.DH = DH; a.scale = 1.0f / std::sqrt((float)DH);
+  a.LSE = dlse; a.lse_stride = N; a.B = B; a.H = H; a.N = N; a.Nkv = Nkv; a.DH = DH; a.scale = 1.0f / std::sqrt((float)DH);
   if (!rc) rc = attn_fwd(a, dtype, 0);
   HIPCHK(hipDeviceSynchronize());
   if (rc) { printf("[FAIL] %s rc=%d\n", name, rc); g_fail++; return; }
