@@ -1,0 +1,197 @@
+// extern "C" surface of libctrlora_hip.so (see include/ctrlora_hip.h for the contract).
+#define CTRLORA_HIP_INTERNAL
+#include "../../include/ctrlora_hip.h"
+#include "attention.h"
+#include "elementwise.h"
+#include "gemm.h"
+#include "norm.h"
+
+using namespace cl;
+
+static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+static GemmParams base_params() {
+  GemmParams g{};
+  g.alpha = 1.f; g.beta = 0.f; g.splitk = 1; g.mode = GEMM_LINEAR;
+  return g;
+}
+
+extern "C" {
+
+int cl_abi_version(void) { return 1; }
+
+int cl_gemm(const cl_gemm_params* p, int dtype, void* stream) {
+  if (!p) return CL_EINVAL;
+  GemmParams g{};
+  g.A1 = p->A1; g.lda1 = p->lda1; g.K1 = p->K1; g.W1 = p->W1; g.ldw1 = p->ldw1;
+  g.A2 = p->A2; g.lda2 = p->lda2; g.K2 = p->K2; g.W2 = p->W2; g.ldw2 = p->ldw2;
+  g.M = p->M; g.N = p->N; g.mode = p->mode;
+  g.B = p->B; g.Hin = p->Hin; g.Win = p->Win; g.Hout = p->Hout; g.Wout = p->Wout;
+  g.zero_page = p->zero_page; g.bias = p->bias;
+  g.rowbias = p->rowbias; g.ldrb = p->ldrb; g.rows_per_batch = p->rows_per_batch;
+  g.residual = p->residual; g.ldr = p->ldr; g.alpha = p->alpha; g.beta = p->beta; g.act = p->act;
+  g.C = p->C; g.ldc = p->ldc; g.out_f32 = p->out_f32; g.atomic = p->atomic; g.splitk = p->splitk < 1 ? 1 : p->splitk;
+  return launch_gemm(g, dtype, S(stream));
+}
+
+int cl_lora_down(int dtype, const void* x, long ldx, const void* A, int r, void* t, long ldt, int M, int K,
+                 void* stream) {
+  GemmParams g = base_params();
+  g.A1 = x; g.lda1 = ldx; g.K1 = K; g.W1 = A; g.ldw1 = K; g.M = M; g.N = r; g.C = t; g.ldc = ldt;
+  return launch_gemm(g, dtype, S(stream));
+}
+
+int cl_lora_linear_fwd(int dtype, const void* x, long ldx, const void* W, const float* bias, const void* t,
+                       long ldt, const void* Bup, int r, const void* residual, long ldr, int act, void* y,
+                       long ldy, int M, int N, int K, void* stream) {
+  GemmParams g = base_params();
+  g.A1 = x; g.lda1 = ldx; g.K1 = K; g.W1 = W; g.ldw1 = K;
+  if (r > 0) { g.A2 = t; g.lda2 = ldt; g.K2 = r; g.W2 = Bup; g.ldw2 = r; }
+  g.M = M; g.N = N; g.bias = bias; g.act = act;
+  if (residual) { g.residual = residual; g.ldr = ldr; g.beta = 1.f; }
+  g.C = y; g.ldc = ldy;
+  return launch_gemm(g, dtype, S(stream));
+}
+
+int cl_lora_linear_bwd_data(int dtype, const void* dy, long lddy, const void* Wt, const void* At, const void* Bt,
+                            int r, void* u, long ldu, const void* accum, long ldacc, void* dx, long lddx, int M,
+                            int N, int K, void* stream) {
+  if (r > 0) {  // u = dy . B   ([M,N] x [N,r]) as an NT product against B^T [r,N]
+    GemmParams g = base_params();
+    g.A1 = dy; g.lda1 = lddy; g.K1 = N; g.W1 = Bt; g.ldw1 = N; g.M = M; g.N = r; g.C = u; g.ldc = ldu;
+    const int rc = launch_gemm(g, dtype, S(stream));
+    if (rc) return rc;
+  }
+  GemmParams g = base_params();
+  g.A1 = dy; g.lda1 = lddy; g.K1 = N; g.W1 = Wt; g.ldw1 = N;
+  if (r > 0) { g.A2 = u; g.lda2 = ldu; g.K2 = r; g.W2 = At; g.ldw2 = r; }
+  g.M = M; g.N = K;
+  if (accum) { g.residual = accum; g.ldr = ldacc; g.beta = 1.f; }
+  g.C = dx; g.ldc = lddx;
+  return launch_gemm(g, dtype, S(stream));
+}
+
+int cl_weight_grad(int dtype, const void* dyT, long lddyt, const void* xT, long ldxt, float* dW, long lddw, int N,
+                   int K, int Mp, float scale, void* stream) {
+  GemmParams g = base_params();
+  g.A1 = dyT; g.lda1 = lddyt; g.K1 = Mp; g.W1 = xT; g.ldw1 = ldxt; g.M = N; g.N = K;
+  g.alpha = scale; g.C = dW; g.ldc = lddw; g.out_f32 = 1; g.atomic = 1;
+  // deep-K, small-MN product: split K so that a few hundred workgroups are in flight
+  const int kpb = dtype == CL_BF16 ? 32 : 16;
+  const long tiles = (long)((N + 63) / 64) * ((K + 63) / 64);
+  int sk = (int)(512 / (tiles > 0 ? tiles : 1));
+  const int ksteps = Mp / kpb;
+  if (sk > ksteps / 4) sk = ksteps / 4;
+  if (sk < 1) sk = 1;
+  if (sk > 64) sk = 64;
+  g.splitk = sk;
+  return launch_gemm(g, dtype, S(stream));
+}
+
+int cl_conv3x3_fwd(int dtype, int mode, const void* x, long ldx, const void* Wp, const float* bias, const void* emb,
+                   long ldemb, const void* residual, long ldr, void* y, long ldy, int B, int Hin, int Win, int Cin,
+                   int Cout, const void* zero_page, void* stream) {
+  GemmParams g = base_params();
+  int Hout = Hin, Wout = Win;
+  if (mode == GEMM_CONV_S2) { Hout = Hin / 2; Wout = Win / 2; }
+  else if (mode == GEMM_CONV_UP2 || mode == GEMM_CONV_T2) { Hout = 2 * Hin; Wout = 2 * Win; }
+  else if (mode != GEMM_CONV_S1) return CL_EINVAL;
+  g.mode = mode; g.A1 = x; g.lda1 = ldx; g.K1 = Cin; g.W1 = Wp; g.ldw1 = 9L * Cin;
+  g.M = B * Hout * Wout; g.N = Cout; g.B = B; g.Hin = Hin; g.Win = Win; g.Hout = Hout; g.Wout = Wout;
+  g.zero_page = zero_page; g.bias = bias;
+  if (emb) { g.rowbias = emb; g.ldrb = ldemb; g.rows_per_batch = Hout * Wout; }
+  if (residual) { g.residual = residual; g.ldr = ldr; g.beta = 1.f; }
+  g.C = y; g.ldc = ldy;
+  return launch_gemm(g, dtype, S(stream));
+}
+
+int cl_conv3x3_bwd_data(int dtype, int mode, const void* dy, long lddy, const void* Wd, const void* accum,
+                        long ldacc, void* dx, long lddx, int B, int Hdy, int Wdy, int Cout, int Cin,
+                        const void* zero_page, void* stream) {
+  return cl_conv3x3_fwd(dtype, mode, dy, lddy, Wd, nullptr, nullptr, 0, accum, ldacc, dx, lddx, B, Hdy, Wdy, Cout,
+                        Cin, zero_page, stream);
+}
+
+int cl_conv1x1_fwd(int dtype, const void* x, long ldx, const void* W, const float* bias, float scale,
+                   const void* residual, long ldr, float beta, void* y, long ldy, int M, int Cin, int Cout,
+                   void* stream) {
+  GemmParams g = base_params();
+  g.A1 = x; g.lda1 = ldx; g.K1 = Cin; g.W1 = W; g.ldw1 = Cin; g.M = M; g.N = Cout; g.bias = bias; g.alpha = scale;
+  if (residual) { g.residual = residual; g.ldr = ldr; g.beta = beta; }
+  g.C = y; g.ldc = ldy;
+  return launch_gemm(g, dtype, S(stream));
+}
+
+long cl_groupnorm_ws_floats(int B, int HW, int C) { return gn_ws_floats(B, HW, C); }
+
+int cl_groupnorm_silu_fwd(int dtype, const void* x, long ldx, void* y, long ldy, const float* gamma,
+                          const float* beta, int B, int HW, int C, int groups, float eps, int silu, float* stats,
+                          float* ws, void* stream) {
+  GnArgs a{}; a.x = x; a.ldx = ldx; a.y = y; a.ldy = ldy; a.gamma = gamma; a.beta = beta; a.B = B; a.HW = HW; a.C = C;
+  a.G = groups; a.eps = eps; a.silu = silu; a.stats = stats; a.ws = ws;
+  return gn_fwd(a, dtype, S(stream));
+}
+
+int cl_groupnorm_silu_bwd(int dtype, const void* x, long ldx, const void* dy, long lddy, const void* accum,
+                          long ldacc, void* dx, long lddx, const float* gamma, const float* beta, const float* stats,
+                          int B, int HW, int C, int groups, int silu, float* dgamma, float* dbeta, float* ws,
+                          void* stream) {
+  GnBwdArgs a{}; a.x = x; a.ldx = ldx; a.dy = dy; a.lddy = lddy; a.accum = accum; a.ldacc = ldacc; a.dx = dx; a.lddx = lddx;
+  a.gamma = gamma; a.beta = beta; a.stats = stats; a.B = B; a.HW = HW; a.C = C; a.G = groups; a.silu = silu;
+  a.dgamma = dgamma; a.dbeta = dbeta; a.ws = ws;
+  return gn_bwd(a, dtype, S(stream));
+}
+
+int cl_layernorm_fwd(int dtype, const void* x, long ldx, void* y, long ldy, const float* gamma, const float* beta,
+                     int M, int D, float eps, float* stats, void* stream) {
+  LnArgs a{}; a.x = x; a.ldx = ldx; a.y = y; a.ldy = ldy; a.gamma = gamma; a.beta = beta; a.M = M; a.D = D; a.eps = eps;
+  a.stats = stats;
+  return ln_fwd(a, dtype, S(stream));
+}
+
+int cl_layernorm_bwd(int dtype, const void* x, long ldx, const void* dy, long lddy, const void* accum, long ldacc,
+                     void* dx, long lddx, const float* gamma, const float* stats, int M, int D, float* dgamma,
+                     float* dbeta, void* stream) {
+  LnBwdArgs a{}; a.x = x; a.ldx = ldx; a.dy = dy; a.lddy = lddy; a.accum = accum; a.ldacc = ldacc; a.dx = dx; a.lddx = lddx;
+  a.gamma = gamma; a.stats = stats; a.M = M; a.D = D; a.dgamma = dgamma; a.dbeta = dbeta;
+  return ln_bwd(a, dtype, S(stream));
+}
+
+int cl_attention_fwd(int dtype, const void* Q, long ldq, const void* K, long ldk, const void* Vt, int nkv_pad,
+                     void* O, long ldo, float* LSE, int lse_stride, int B, int H, int N, int Nkv, int dh, float scale,
+                     void* stream) {
+  AttnFwdArgs a{}; a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.Vt = Vt; a.nkv_pad = nkv_pad; a.O = O; a.ldo = ldo;
+  a.LSE = LSE; a.lse_stride = lse_stride; a.B = B; a.H = H; a.N = N; a.Nkv = Nkv; a.DH = dh; a.scale = scale;
+  return attn_fwd(a, dtype, S(stream));
+}
+
+int cl_attention_bwd(int dtype, const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv,
+                     const void* O, long ldo, const void* dO, long lddo, const void* Qt, const void* dOt, int n_pad,
+                     const void* Kt, int nkv_pad, const float* LSE, float* Delta, int lse_stride, void* dQ, long lddq,
+                     void* dK, long lddk, void* dV, long lddv, int B, int H, int N, int Nkv, int dh, float scale,
+                     void* stream) {
+  AttnBwdArgs a{}; a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo;
+  a.dO = dO; a.lddo = lddo; a.Qt = Qt; a.dOt = dOt; a.n_pad = n_pad; a.Kt = Kt; a.nkv_pad = nkv_pad; a.LSE = LSE;
+  a.Delta = Delta; a.lse_stride = lse_stride; a.dQ = dQ; a.lddq = lddq; a.dK = dK; a.lddk = lddk; a.dV = dV; a.lddv = lddv;
+  a.B = B; a.H = H; a.N = N; a.Nkv = Nkv; a.DH = dh; a.scale = scale;
+  return attn_bwd(a, dtype, S(stream));
+}
+
+int cl_geglu_fwd(int dtype, const void* h, long ldh, void* out, long ldo, long M, int F, void* stream) { return geglu_fwd(dtype, h, ldh, out, ldo, M, F, S(stream)); }
+int cl_geglu_bwd(int dtype, const void* h, long ldh, const void* dout, long lddo, void* dh, long lddh, long M, int F, void* stream) { return geglu_bwd(dtype, h, ldh, dout, lddo, dh, lddh, M, F, S(stream)); }
+int cl_silu_fwd(int dtype, const void* x, void* y, long n, void* stream) { return silu_fwd(dtype, x, y, n, S(stream)); }
+int cl_silu_bwd(int dtype, const void* x, const void* dy, void* dx, long n, void* stream) { return silu_bwd(dtype, x, dy, dx, n, S(stream)); }
+int cl_axpby(int dtype, const void* x, long ldx, void* y, long ldy, long M, int C, float a, float b, void* stream) { return axpby(dtype, x, ldx, y, ldy, M, C, a, b, S(stream)); }
+int cl_transpose(int in_dtype, int out_dtype, const void* in, long ldi, long bsi, void* out, long ldo, long bso, int Bt, int R, int C, int Rpad, void* stream) { return transpose(in_dtype, out_dtype, in, ldi, bsi, out, ldo, bso, Bt, R, C, Rpad, S(stream)); }
+int cl_nchw_to_tok(int dtype, const float* in, void* out, long ldo, int B, int Cin, int Cpad, int HW, void* stream) { return nchw_to_tok(dtype, in, out, ldo, B, Cin, Cpad, HW, S(stream)); }
+int cl_tok_to_nchw(int dtype, const void* in, long ldi, float* out, int B, int C, int HW, float alpha, float beta, void* stream) { return tok_to_nchw(dtype, in, ldi, out, B, C, HW, alpha, beta, S(stream)); }
+int cl_colsum(int dtype, const void* in, long ldi, float* out, long ldo, int B, int HW, int C, float scale, void* stream) { return colsum(dtype, in, ldi, out, ldo, B, HW, C, scale, S(stream)); }
+int cl_pool2x2(int dtype, const void* in, long ldi, void* out, long ldo, int B, int H, int W, int C, int accumulate, void* stream) { return pool2x2(dtype, in, ldi, out, ldo, B, H, W, C, accumulate, S(stream)); }
+int cl_pack2d(int dtype, const float* in, long ldi, void* out, long ldo, long R, int C, int Cpad, void* stream) { return pack2d(dtype, in, ldi, out, ldo, R, C, Cpad, S(stream)); }
+int cl_timestep_embedding(int dtype, const long* t, const float* freqs, void* out, long ldo, int B, int half, void* stream) { return timestep_embed(dtype, t, freqs, out, ldo, B, half, S(stream)); }
+int cl_qsample(const float* z, const float* noise, const long* t, const float* sqrt_ac, const float* sqrt_1mac, float* out, int B, long per_sample, void* stream) { return qsample(z, noise, t, sqrt_ac, sqrt_1mac, out, B, per_sample, S(stream)); }
+int cl_mse_loss(const float* eps, const float* target, float* d_eps, float* loss, long n, float gscale, void* stream) { return mse_loss(eps, target, d_eps, loss, n, gscale, S(stream)); }
+int cl_ddim_step(const float* x, const float* e_c, const float* e_u, const float* noise, const float* coef, int index, float scale, float* x_prev, float* pred_x0, long n, void* stream) { return ddim_step(x, e_c, e_u, noise, coef, index, scale, x_prev, pred_x0, n, S(stream)); }
+int cl_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) { return adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, S(stream)); }
+
+}  // extern "C"

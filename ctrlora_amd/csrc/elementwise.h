@@ -22,6 +22,7 @@ int ddim_step(const float* x, const float* e_c, const float* e_u, const float* n
 int adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
           float wd, int step, float gscale, hipStream_t st);
 int pool2x2(int dtype, const void* in, long ldi, void* out, long ldo, int B, int H, int W, int C, int accumulate, hipStream_t st);
+int colsum(int dtype, const void* in, long ldi, float* out, long ldo, int B, int HW, int C, float scale, hipStream_t st);
 int pack2d(int dtype, const float* in, long ldi, void* out, long ldo, long R, int C, int Cpad, hipStream_t st);
 
 }  // namespace cl

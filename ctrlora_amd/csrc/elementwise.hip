@@ -261,6 +261,33 @@ __global__ void pool2x2_kernel(const T* __restrict__ in, long ldi, T* __restrict
   }
 }
 
+// ---------------------------------------------------------------- per-sample column sums
+// out[b, c] += sum_p in[b*HW + p, c]   (fp32 atomics; data-gradient of the `h + emb_out[:, :, None, None]`
+// broadcast, openaimodel.py:272, and bias gradients of the zero convs)
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ in, long ldi, float* __restrict__ out, long ldo, int HW, int C,
+                              int ppc, float scale) {
+  const int C8 = C / 8;
+  const int b = blockIdx.y, p0 = blockIdx.x * ppc, p1 = min(HW, p0 + ppc);
+  const int VX = blockDim.x < C8 ? blockDim.x : C8;
+  const int PY = blockDim.x / VX;
+  const int vx = threadIdx.x % VX, py = threadIdx.x / VX;
+  if (py >= PY) return;
+  for (int v = vx; v < C8; v += VX) {
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    for (int p = p0 + py; p < p1; p += PY) {
+      float f[8];
+      load8(in + ((long)b * HW + p) * ldi + v * 8, f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += f[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(out + (long)b * ldo + v * 8 + e, s[e] * scale);
+  }
+}
+
 // ---------------------------------------------------------------- strided 2-D convert fp32 -> T
 template <typename T>
 __global__ void pack_kernel(const float* __restrict__ in, long ldi, T* __restrict__ out, long ldo, long R, int C,
@@ -360,6 +387,18 @@ int pool2x2(int dtype, const void* in, long ldi, void* out, long ldo, int B, int
   const long n = (long)B * H * W * (C / 8);
   if (dtype == CL_BF16) hipLaunchKernelGGL((pool2x2_kernel<bf16_t>), dim3(ew_grid(n)), dim3(256), 0, st, (const bf16_t*)in, ldi, (bf16_t*)out, ldo, B, H, W, C, accumulate);
   else hipLaunchKernelGGL((pool2x2_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, st, (const float*)in, ldi, (float*)out, ldo, B, H, W, C, accumulate);
+  CL_CHECK_LAUNCH(); return CL_OK;
+}
+int colsum(int dtype, const void* in, long ldi, float* out, long ldo, int B, int HW, int C, float scale, hipStream_t st) {
+  if (C % 8 || ldi % 8) return CL_EINVAL;
+  int nchunk = (HW + 63) / 64;
+  int want = (512 + B - 1) / B;
+  if (nchunk > want) nchunk = want;
+  const int ppc = (HW + nchunk - 1) / nchunk;
+  nchunk = (HW + ppc - 1) / ppc;
+  dim3 grid(nchunk, B);
+  if (dtype == CL_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)in, ldi, out, ldo, HW, C, ppc, scale);
+  else hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, st, (const float*)in, ldi, out, ldo, HW, C, ppc, scale);
   CL_CHECK_LAUNCH(); return CL_OK;
 }
 int pack2d(int dtype, const float* in, long ldi, void* out, long ldo, long R, int C, int Cpad, hipStream_t st) {

@@ -1,0 +1,341 @@
+"""ctypes binding of libctrlora_hip.so (include/ctrlora_hip.h) for torch tensors.
+
+PyTorch is plumbing here: device memory, the current HIP stream, torch.distributed.
+Every function enqueues hand-written gfx950 kernels on `torch.cuda.current_stream()`.
+There is NO fallback: if the library is missing or a kernel rejects its arguments the
+call raises -- a product path that silently ran ATen / CPU code would void every
+parity claim.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libctrlora_hip.so")
+
+BF16, F32 = 0, 1
+LINEAR, CONV_S1, CONV_S2, CONV_UP2, CONV_T2 = 0, 1, 2, 3, 4
+ACT_NONE, ACT_SILU = 0, 1
+
+
+class HipError(RuntimeError):
+    pass
+
+
+class GemmParams(C.Structure):
+    _fields_ = [
+        ("A1", C.c_void_p), ("lda1", C.c_long), ("K1", C.c_int),
+        ("W1", C.c_void_p), ("ldw1", C.c_long),
+        ("A2", C.c_void_p), ("lda2", C.c_long), ("K2", C.c_int),
+        ("W2", C.c_void_p), ("ldw2", C.c_long),
+        ("M", C.c_int), ("N", C.c_int), ("mode", C.c_int),
+        ("B", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("Hout", C.c_int), ("Wout", C.c_int),
+        ("zero_page", C.c_void_p), ("bias", C.c_void_p),
+        ("rowbias", C.c_void_p), ("ldrb", C.c_long), ("rows_per_batch", C.c_int),
+        ("residual", C.c_void_p), ("ldr", C.c_long),
+        ("alpha", C.c_float), ("beta", C.c_float), ("act", C.c_int),
+        ("C", C.c_void_p), ("ldc", C.c_long),
+        ("out_f32", C.c_int), ("atomic", C.c_int), ("splitk", C.c_int),
+    ]
+
+
+_lib = None
+
+# name -> argtypes (restype is int except where noted); mirrors include/ctrlora_hip.h
+_P, _L, _I, _F = C.c_void_p, C.c_long, C.c_int, C.c_float
+_SIGS = {
+    "cl_abi_version": [],
+    "cl_gemm": [C.POINTER(GemmParams), _I, _P],
+    "cl_lora_down": [_I, _P, _L, _P, _I, _P, _L, _I, _I, _P],
+    "cl_lora_linear_fwd": [_I, _P, _L, _P, _P, _P, _L, _P, _I, _P, _L, _I, _P, _L, _I, _I, _I, _P],
+    "cl_lora_linear_bwd_data": [_I, _P, _L, _P, _P, _P, _I, _P, _L, _P, _L, _P, _L, _I, _I, _I, _P],
+    "cl_weight_grad": [_I, _P, _L, _P, _L, _P, _L, _I, _I, _I, _F, _P],
+    "cl_conv3x3_fwd": [_I, _I, _P, _L, _P, _P, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P, _P],
+    "cl_conv3x3_bwd_data": [_I, _I, _P, _L, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P, _P],
+    "cl_conv1x1_fwd": [_I, _P, _L, _P, _P, _F, _P, _L, _F, _P, _L, _I, _I, _I, _P],
+    "cl_groupnorm_ws_floats": [_I, _I, _I],
+    "cl_groupnorm_silu_fwd": [_I, _P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P, _P],
+    "cl_groupnorm_silu_bwd": [_I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "cl_layernorm_fwd": [_I, _P, _L, _P, _L, _P, _P, _I, _I, _F, _P, _P],
+    "cl_layernorm_bwd": [_I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _I, _I, _P, _P, _P],
+    "cl_attention_fwd": [_I, _P, _L, _P, _L, _P, _I, _P, _L, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+    "cl_attention_bwd": [_I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _I, _P, _I, _P, _P, _I, _P, _L, _P, _L,
+                         _P, _L, _I, _I, _I, _I, _I, _F, _P],
+    "cl_geglu_fwd": [_I, _P, _L, _P, _L, _L, _I, _P],
+    "cl_geglu_bwd": [_I, _P, _L, _P, _L, _P, _L, _L, _I, _P],
+    "cl_silu_fwd": [_I, _P, _P, _L, _P],
+    "cl_silu_bwd": [_I, _P, _P, _P, _L, _P],
+    "cl_axpby": [_I, _P, _L, _P, _L, _L, _I, _F, _F, _P],
+    "cl_transpose": [_I, _I, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _P],
+    "cl_nchw_to_tok": [_I, _P, _P, _L, _I, _I, _I, _I, _P],
+    "cl_tok_to_nchw": [_I, _P, _L, _P, _I, _I, _I, _F, _F, _P],
+    "cl_colsum": [_I, _P, _L, _P, _L, _I, _I, _I, _F, _P],
+    "cl_pool2x2": [_I, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P],
+    "cl_pack2d": [_I, _P, _L, _P, _L, _L, _I, _I, _P],
+    "cl_timestep_embedding": [_I, _P, _P, _P, _L, _I, _I, _P],
+    "cl_qsample": [_P, _P, _P, _P, _P, _P, _I, _L, _P],
+    "cl_mse_loss": [_P, _P, _P, _P, _L, _F, _P],
+    "cl_ddim_step": [_P, _P, _P, _P, _P, _I, _F, _P, _P, _L, _P],
+    "cl_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
+}
+EXPORTED = tuple(_SIGS.keys())
+
+
+def lib():
+    """Load the shared library once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipError(f"{LIB_PATH} not found -- run `python -m ctrlora_amd.build` "
+                           "(the CtrLoRA engine has no non-HIP fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, args in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = C.c_long if name == "cl_groupnorm_ws_floats" else C.c_int
+        _lib = L
+    return _lib
+
+
+def _chk(rc: int, what: str):
+    if rc != 0:
+        raise HipError(f"{what} failed with code {rc} "
+                       f"({'unsupported shape/alignment' if rc == 1 else 'HIP launch error'})")
+
+
+def dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise HipError(f"unsupported dtype {t.dtype}")
+
+
+def dt_of(dtype: torch.dtype) -> int:
+    return BF16 if dtype == torch.bfloat16 else F32
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def ld(t: Optional[torch.Tensor]) -> int:
+    """Row stride (elements) of a 2-D view whose last dim is contiguous."""
+    if t is None:
+        return 0
+    assert t.dim() == 2 and t.stride(1) == 1, (t.shape, t.stride())
+    return t.stride(0)
+
+
+_zero_pages = {}
+
+
+def zero_page(device) -> torch.Tensor:
+    k = str(device)
+    if k not in _zero_pages:
+        _zero_pages[k] = torch.zeros(1024, dtype=torch.uint8, device=device)
+    return _zero_pages[k]
+
+
+# ------------------------------------------------------------------ dense contractions
+
+def gemm(a1, w1, out, *, a2=None, w2=None, bias=None, rowbias=None, rows_per_batch=0, residual=None,
+         alpha=1.0, beta=0.0, act=ACT_NONE, mode=LINEAR, conv=None, k1=None, out_f32=False, atomic=False,
+         splitk=1, M=None, N=None, dtype=None):
+    """out[M,N] = act(a1.w1^T + a2.w2^T + bias + rowbias[m // rows_per_batch]) * alpha + beta * residual.
+
+    a1: [M,K1] (LINEAR) or the NHWC activation [B*Hin*Win, C] (conv modes, conv=(B,Hin,Win,Hout,Wout)).
+    """
+    p = GemmParams()
+    dty = dt(a1) if dtype is None else dtype
+    p.A1 = a1.data_ptr(); p.lda1 = ld(a1); p.K1 = a1.shape[1] if k1 is None else k1
+    p.W1 = w1.data_ptr(); p.ldw1 = ld(w1)
+    if a2 is not None:
+        p.A2 = a2.data_ptr(); p.lda2 = ld(a2); p.K2 = a2.shape[1]; p.W2 = w2.data_ptr(); p.ldw2 = ld(w2)
+    p.M = out.shape[0] if M is None else M
+    p.N = out.shape[1] if N is None else N
+    p.mode = mode
+    if conv is not None:
+        p.B, p.Hin, p.Win, p.Hout, p.Wout = conv
+        p.zero_page = zero_page(a1.device).data_ptr()
+    p.bias = ptr(bias)
+    if rowbias is not None:
+        p.rowbias = rowbias.data_ptr(); p.ldrb = ld(rowbias); p.rows_per_batch = rows_per_batch
+    if residual is not None:
+        p.residual = residual.data_ptr(); p.ldr = ld(residual)
+    p.alpha = alpha; p.beta = beta; p.act = act
+    p.C = out.data_ptr(); p.ldc = ld(out)
+    p.out_f32 = int(out_f32); p.atomic = int(atomic); p.splitk = splitk
+    _chk(lib().cl_gemm(C.byref(p), dty, stream()), "cl_gemm")
+    return out
+
+
+def weight_grad(dyT, xT, dW, scale=1.0):
+    """dW[N,K] (fp32) += scale * dyT[N,Mp] . xT[K,Mp]^T  (split-K, fp32 atomics)."""
+    _chk(lib().cl_weight_grad(dt(dyT), dyT.data_ptr(), ld(dyT), xT.data_ptr(), ld(xT), dW.data_ptr(), ld(dW),
+                              dyT.shape[0], xT.shape[0], dyT.shape[1], scale, stream()), "cl_weight_grad")
+
+
+# ------------------------------------------------------------------ normalisation
+
+def groupnorm_ws(B, HW, C_) -> int:
+    return int(lib().cl_groupnorm_ws_floats(B, HW, C_))
+
+
+def groupnorm_fwd(x, y, gamma, beta, B, HW, eps, silu, stats, ws, groups=32):
+    _chk(lib().cl_groupnorm_silu_fwd(dt(x), x.data_ptr(), ld(x), y.data_ptr(), ld(y), gamma.data_ptr(),
+                                     beta.data_ptr(), B, HW, x.shape[1], groups, eps, int(silu), stats.data_ptr(),
+                                     ws.data_ptr(), stream()), "cl_groupnorm_silu_fwd")
+    return y
+
+
+def groupnorm_bwd(x, dy, dx, gamma, beta, stats, B, HW, silu, ws, accum=None, dgamma=None, dbeta=None, groups=32):
+    _chk(lib().cl_groupnorm_silu_bwd(dt(x), x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), ptr(accum), ld(accum),
+                                     dx.data_ptr(), ld(dx), gamma.data_ptr(), beta.data_ptr(), stats.data_ptr(), B, HW,
+                                     x.shape[1], groups, int(silu), ptr(dgamma), ptr(dbeta), ws.data_ptr(), stream()),
+         "cl_groupnorm_silu_bwd")
+    return dx
+
+
+def layernorm_fwd(x, y, gamma, beta, eps=1e-5, stats=None):
+    _chk(lib().cl_layernorm_fwd(dt(x), x.data_ptr(), ld(x), y.data_ptr(), ld(y), gamma.data_ptr(), beta.data_ptr(),
+                                x.shape[0], x.shape[1], eps, ptr(stats), stream()), "cl_layernorm_fwd")
+    return y
+
+
+def layernorm_bwd(x, dy, dx, gamma, stats, accum=None, dgamma=None, dbeta=None):
+    _chk(lib().cl_layernorm_bwd(dt(x), x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), ptr(accum), ld(accum),
+                                dx.data_ptr(), ld(dx), gamma.data_ptr(), stats.data_ptr(), x.shape[0], x.shape[1],
+                                ptr(dgamma), ptr(dbeta), stream()), "cl_layernorm_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------ attention
+
+def attention_fwd(q, k, vt, o, lse, B, H, N, Nkv, dh, scale):
+    """q [B*N, >=H*dh], k [B*Nkv, ..], vt [B, H*dh, nkv_pad], o [B*N, H*dh], lse [B,H,lse_stride] or None."""
+    _chk(lib().cl_attention_fwd(dt(q), q.data_ptr(), ld(q), k.data_ptr(), ld(k), vt.data_ptr(), vt.shape[-1],
+                                o.data_ptr(), ld(o), ptr(lse), 0 if lse is None else lse.shape[-1], B, H, N, Nkv, dh,
+                                scale, stream()), "cl_attention_fwd")
+    return o
+
+
+def attention_bwd(q, k, v, o, do, qt, dot, kt, lse, delta, dq, dk, dv, B, H, N, Nkv, dh, scale):
+    _chk(lib().cl_attention_bwd(dt(q), q.data_ptr(), ld(q), k.data_ptr(), ld(k), v.data_ptr(), ld(v), o.data_ptr(),
+                                ld(o), do.data_ptr(), ld(do), qt.data_ptr(), dot.data_ptr(), qt.shape[-1],
+                                kt.data_ptr(), kt.shape[-1], lse.data_ptr(), delta.data_ptr(), lse.shape[-1],
+                                dq.data_ptr(), ld(dq), ptr(dk), ld(dk), ptr(dv), ld(dv), B, H, N, Nkv, dh, scale,
+                                stream()), "cl_attention_bwd")
+
+
+# ------------------------------------------------------------------ elementwise / layout
+
+def geglu_fwd(h, out):
+    _chk(lib().cl_geglu_fwd(dt(h), h.data_ptr(), ld(h), out.data_ptr(), ld(out), h.shape[0], out.shape[1], stream()),
+         "cl_geglu_fwd")
+    return out
+
+
+def geglu_bwd(h, dout, dh):
+    _chk(lib().cl_geglu_bwd(dt(h), h.data_ptr(), ld(h), dout.data_ptr(), ld(dout), dh.data_ptr(), ld(dh), h.shape[0],
+                            dout.shape[1], stream()), "cl_geglu_bwd")
+    return dh
+
+
+def silu_fwd(x, y):
+    _chk(lib().cl_silu_fwd(dt(x), x.data_ptr(), y.data_ptr(), x.numel(), stream()), "cl_silu_fwd")
+    return y
+
+
+def silu_bwd(x, dy, dx):
+    _chk(lib().cl_silu_bwd(dt(x), x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), stream()), "cl_silu_bwd")
+    return dx
+
+
+def axpby(x, y, a=1.0, b=1.0):
+    """y = a*x + b*y over 2-D strided views."""
+    _chk(lib().cl_axpby(dt(x), x.data_ptr(), ld(x), y.data_ptr(), ld(y), x.shape[0], x.shape[1], a, b, stream()),
+         "cl_axpby")
+    return y
+
+
+def transpose(src, dst, Bt, R, C_, Rpad, ldi=None, bsi=None):
+    """src [Bt][R][C] (row stride ldi, batch stride bsi) -> dst [Bt][C][Rpad] (zero padded)."""
+    ldi = src.stride(-2) if ldi is None else ldi
+    bsi = R * ldi if bsi is None else bsi
+    _chk(lib().cl_transpose(dt(src), dt(dst), src.data_ptr(), ldi, bsi, dst.data_ptr(), Rpad, C_ * Rpad, Bt, R, C_,
+                            Rpad, stream()), "cl_transpose")
+    return dst
+
+
+def nchw_to_tok(x_nchw, out, Cpad=None):
+    B, Cin, H, W = x_nchw.shape
+    x_nchw = x_nchw.contiguous()
+    _chk(lib().cl_nchw_to_tok(dt(out), x_nchw.data_ptr(), out.data_ptr(), ld(out), B, Cin,
+                              out.shape[1] if Cpad is None else Cpad, H * W, stream()), "cl_nchw_to_tok")
+    return out
+
+
+def tok_to_nchw(tok, out_nchw, alpha=1.0, beta=0.0):
+    B, C_, H, W = out_nchw.shape
+    _chk(lib().cl_tok_to_nchw(dt(tok), tok.data_ptr(), ld(tok), out_nchw.data_ptr(), B, C_, H * W, alpha, beta,
+                              stream()), "cl_tok_to_nchw")
+    return out_nchw
+
+
+def colsum(x, out_f32, B, HW, scale=1.0):
+    _chk(lib().cl_colsum(dt(x), x.data_ptr(), ld(x), out_f32.data_ptr(), ld(out_f32), B, HW, x.shape[1], scale,
+                         stream()), "cl_colsum")
+    return out_f32
+
+
+def pool2x2(src, dst, B, H, W, accumulate=False):
+    _chk(lib().cl_pool2x2(dt(src), src.data_ptr(), ld(src), dst.data_ptr(), ld(dst), B, H, W, dst.shape[1],
+                          int(accumulate), stream()), "cl_pool2x2")
+    return dst
+
+
+def pack2d(src_f32, dst, Cpad=None):
+    """fp32 [R, C] (strided) -> dst dtype [R, Cpad] with zero-filled pad columns."""
+    R, C_ = src_f32.shape
+    _chk(lib().cl_pack2d(dt(dst), src_f32.data_ptr(), ld(src_f32), dst.data_ptr(), ld(dst), R, C_,
+                         dst.shape[1] if Cpad is None else Cpad, stream()), "cl_pack2d")
+    return dst
+
+
+def timestep_embedding(t_long, freqs, out):
+    _chk(lib().cl_timestep_embedding(dt(out), t_long.data_ptr(), freqs.data_ptr(), out.data_ptr(), ld(out),
+                                     t_long.shape[0], freqs.shape[0], stream()), "cl_timestep_embedding")
+    return out
+
+
+def qsample(z, noise, t, sqrt_ac, sqrt_1mac, out):
+    B = z.shape[0]
+    _chk(lib().cl_qsample(z.data_ptr(), noise.data_ptr(), t.data_ptr(), sqrt_ac.data_ptr(), sqrt_1mac.data_ptr(),
+                          out.data_ptr(), B, z.numel() // B, stream()), "cl_qsample")
+    return out
+
+
+def mse_loss(eps, target, d_eps, loss, gscale=1.0):
+    _chk(lib().cl_mse_loss(eps.data_ptr(), target.data_ptr(), ptr(d_eps), loss.data_ptr(), eps.numel(), gscale,
+                           stream()), "cl_mse_loss")
+    return loss
+
+
+def ddim_step(x, e_c, e_u, noise, coef, index, scale, x_prev, pred_x0=None):
+    _chk(lib().cl_ddim_step(x.data_ptr(), e_c.data_ptr(), ptr(e_u), ptr(noise), coef.data_ptr(), index, scale,
+                            x_prev.data_ptr(), ptr(pred_x0), x.numel(), stream()), "cl_ddim_step")
+    return x_prev
+
+
+def adamw(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
+    _chk(lib().cl_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
+                        weight_decay, step, grad_scale, stream()), "cl_adamw")

@@ -1,0 +1,177 @@
+/* ctrlora_hip.h -- C ABI of libctrlora_hip.so: the MI355X (gfx950) kernels behind the
+ * CtrLoRA hot path (SD1.5 UNet + ControlNet + condition-LoRA forward/backward, DDIM step).
+ *
+ * The reference (xyfJASON/ctrlora) has no FFI: the hot path sits behind Python class
+ * contracts (cldm.*), and every operator below replaces the ATen kernel(s) that the cited
+ * reference lines issue.  The Python host side (ctrlora_amd/, cldm/, ldm/) binds these
+ * entry points with ctypes; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every function returns 0 on success, CL_EINVAL (1) for an unsupported shape /
+ *     alignment, CL_ELAUNCH (2) for a HIP launch failure.  Nothing is allocated, nothing
+ *     synchronises; all work is enqueued on `stream` (a hipStream_t) and is hipGraph-capture safe.
+ *   - dtype: 0 = bf16 storage (fp32 accumulate, fp32 statistics/softmax),
+ *            1 = fp32 storage ("parity mode": f32-input MFMA, exact fmaf chains).
+ *   - activations are token-major ("NHWC"): a [rows, C] matrix with an explicit row stride
+ *     (ld, in elements) so that operators can read/write column slices of wider buffers
+ *     (decoder concat buffers, fused QKV).  rows = b*H*W + y*W + x.
+ *   - channel counts / K dimensions must be multiples of 32 (bf16) or 16 (fp32); N and all
+ *     ld's multiples of 8.  Base pointers 16-byte aligned.
+ */
+#ifndef CTRLORA_HIP_H
+#define CTRLORA_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef CTRLORA_HIP_INTERNAL  /* the library's own sources carry these as C++ enums */
+#define CL_OK 0
+#define CL_EINVAL 1
+#define CL_ELAUNCH 2
+#define CL_BF16 0
+#define CL_F32 1
+#endif
+
+int cl_abi_version(void);
+
+/* ---- dense contractions -------------------------------------------------------------
+ * One MFMA kernel family (csrc/gemm.hip) behind all of them:
+ *   out[M,N] = act( A1.W1^T + A2.W2^T + bias[n] + rowbias[m / rows_per_batch, n] ) * alpha
+ *              + beta * residual[m, n]
+ */
+enum cl_gemm_mode {
+  CL_GEMM_LINEAR = 0,   /* A1 row-major [M,K1]                                              */
+  CL_GEMM_CONV_S1 = 1,  /* A1 = NHWC [B,Hin,Win,K1]; 3x3 stride 1 pad 1                      */
+  CL_GEMM_CONV_S2 = 2,  /* 3x3 stride 2 pad 1                                                */
+  CL_GEMM_CONV_UP2 = 3, /* 3x3 over nearest-x2 upsampled input                               */
+  CL_GEMM_CONV_T2 = 4   /* 3x3 over zero-stuffed x2 grid: data-gradient of CL_GEMM_CONV_S2   */
+};
+
+typedef struct cl_gemm_params {
+  const void* A1; long lda1; int K1;
+  const void* W1; long ldw1;          /* [N, taps*K1], K contiguous (taps = 9 in conv modes: ky,kx,c) */
+  const void* A2; long lda2; int K2;  /* optional second K segment                           */
+  const void* W2; long ldw2;
+  int M, N;
+  int mode;
+  int B, Hin, Win, Hout, Wout;        /* conv geometry                                       */
+  const void* zero_page;              /* >= 64 zero bytes on the device (conv halo)          */
+  const float* bias;                  /* fp32 [N] or NULL                                    */
+  const void* rowbias; long ldrb; int rows_per_batch;
+  const void* residual; long ldr;
+  float alpha, beta;
+  int act;                            /* 0 none, 1 SiLU                                      */
+  void* C; long ldc;
+  int out_f32;                        /* store fp32 regardless of dtype                      */
+  int atomic;                         /* fp32 atomicAdd into C (required when splitk > 1)    */
+  int splitk;
+} cl_gemm_params;
+
+/* Generic entry; the named operators below are thin fillers of cl_gemm_params. */
+int cl_gemm(const cl_gemm_params* p, int dtype, void* stream);
+
+/* LoRACompatibleLinear.forward (cldm/lora.py:285-291): y = x W^T + b + (x A^T) B^T (+ residual).
+ * t = x A^T (LoRALinearLayer.down, cldm/lora.py:74) is produced by cl_lora_down and kept for
+ * the backward pass; the up-projection is folded into the main MFMA chain as a second K segment.
+ * W [N,K], A [r,K], Bup [N,r] row-major in `dtype`; pass t = NULL / r = 0 for a plain nn.Linear. */
+int cl_lora_down(int dtype, const void* x, long ldx, const void* A, int r, void* t, long ldt,
+                 int M, int K, void* stream);
+int cl_lora_linear_fwd(int dtype, const void* x, long ldx, const void* W, const float* bias,
+                       const void* t, long ldt, const void* Bup, int r,
+                       const void* residual, long ldr, int act, void* y, long ldy,
+                       int M, int N, int K, void* stream);
+/* data gradient: dx = dy W + (dy B) A (+ accum).  Wt = W^T [K,N], At = A^T [K,r], Bt = B^T [r,N];
+ * u = dy B [M,r] is written to `u` (needed again for dA).  No dW is ever formed for frozen W. */
+int cl_lora_linear_bwd_data(int dtype, const void* dy, long lddy, const void* Wt, const void* At,
+                            const void* Bt, int r, void* u, long ldu, const void* accum, long ldacc,
+                            void* dx, long lddx, int M, int N, int K, void* stream);
+/* weight gradient of a (LoRA / zero-conv) matrix: dW[N,K] += dyT[N,Mp] . xT[K,Mp]^T, fp32 atomics.
+ * dyT / xT are the zero-padded transposes produced by cl_transpose (Mp multiple of 32). */
+int cl_weight_grad(int dtype, const void* dyT, long lddyt, const void* xT, long ldxt, float* dW,
+                   long lddw, int N, int K, int Mp, float scale, void* stream);
+
+/* 3x3 convolutions of ResBlock / Downsample / Upsample / input conv / out conv
+ * (ldm/modules/diffusionmodules/openaimodel.py:108-118,150,203,229,729; cldm/cldm.py:141):
+ * out = conv(x) + bias + emb[b, :] (openaimodel.py:272) + residual (openaimodel.py:274).
+ * Wp = [Cout][ky][kx][Cin] in `dtype`.  mode is one of CL_GEMM_CONV_*. */
+int cl_conv3x3_fwd(int dtype, int mode, const void* x, long ldx, const void* Wp, const float* bias,
+                   const void* emb, long ldemb, const void* residual, long ldr, void* y, long ldy,
+                   int B, int Hin, int Win, int Cin, int Cout, const void* zero_page, void* stream);
+/* data gradient: same kernel on the tap-flipped, in/out-swapped weights Wd = [Cin][2-ky][2-kx][Cout]
+ * (mode CL_GEMM_CONV_S1 for stride-1 convs, CL_GEMM_CONV_T2 for the stride-2 Downsample). */
+int cl_conv3x3_bwd_data(int dtype, int mode, const void* dy, long lddy, const void* Wd,
+                        const void* accum, long ldacc, void* dx, long lddx,
+                        int B, int Hdy, int Wdy, int Cout, int Cin, const void* zero_page, void* stream);
+
+/* 1x1 convs (SpatialTransformer.proj_in/out, ResBlock.skip_connection, ControlNet zero convs,
+ * cldm/cldm.py:281-282) with the ControlNet residual injection fused in
+ * (cldm_ctrlora_finetune.py:79, cldm/cldm.py:35,41):  y = (x W^T + b) * scale + beta * residual. */
+int cl_conv1x1_fwd(int dtype, const void* x, long ldx, const void* W, const float* bias, float scale,
+                   const void* residual, long ldr, float beta, void* y, long ldy,
+                   int M, int Cin, int Cout, void* stream);
+
+/* ---- normalisation ------------------------------------------------------------------- */
+/* GroupNorm32(32, C) [+ SiLU] in fp32 statistics (util.py:217-219; openaimodel.py:201-202). */
+long cl_groupnorm_ws_floats(int B, int HW, int C);
+int cl_groupnorm_silu_fwd(int dtype, const void* x, long ldx, void* y, long ldy, const float* gamma,
+                          const float* beta, int B, int HW, int C, int groups, float eps, int silu,
+                          float* stats, float* ws, void* stream);
+int cl_groupnorm_silu_bwd(int dtype, const void* x, long ldx, const void* dy, long lddy,
+                          const void* accum, long ldacc, void* dx, long lddx, const float* gamma,
+                          const float* beta, const float* stats, int B, int HW, int C, int groups,
+                          int silu, float* dgamma, float* dbeta, float* ws, void* stream);
+/* nn.LayerNorm over the last dim (attention.py:263-265) */
+int cl_layernorm_fwd(int dtype, const void* x, long ldx, void* y, long ldy, const float* gamma,
+                     const float* beta, int M, int D, float eps, float* stats, void* stream);
+int cl_layernorm_bwd(int dtype, const void* x, long ldx, const void* dy, long lddy, const void* accum,
+                     long ldacc, void* dx, long lddx, const float* gamma, const float* stats, int M,
+                     int D, float* dgamma, float* dbeta, void* stream);
+
+/* ---- attention ----------------------------------------------------------------------- */
+/* CrossAttention.forward core (attention.py:171-192): softmax(q k^T d^-1/2) v per head, fp32
+ * scores/softmax, never materialising the score matrix.  Vt / Qt / dOt / Kt are the
+ * [B][H*dh][pad64] transposes made with cl_transpose. */
+int cl_attention_fwd(int dtype, const void* Q, long ldq, const void* K, long ldk, const void* Vt,
+                     int nkv_pad, void* O, long ldo, float* LSE, int lse_stride, int B, int H, int N,
+                     int Nkv, int dh, float scale, void* stream);
+int cl_attention_bwd(int dtype, const void* Q, long ldq, const void* K, long ldk, const void* V,
+                     long ldv, const void* O, long ldo, const void* dO, long lddo, const void* Qt,
+                     const void* dOt, int n_pad, const void* Kt, int nkv_pad, const float* LSE,
+                     float* Delta, int lse_stride, void* dQ, long lddq, void* dK, long lddk, void* dV,
+                     long lddv, int B, int H, int N, int Nkv, int dh, float scale, void* stream);
+
+/* ---- elementwise / layout ------------------------------------------------------------ */
+int cl_geglu_fwd(int dtype, const void* h, long ldh, void* out, long ldo, long M, int F, void* stream); /* attention.py:55-56 */
+int cl_geglu_bwd(int dtype, const void* h, long ldh, const void* dout, long lddo, void* dh, long lddh, long M, int F, void* stream);
+int cl_silu_fwd(int dtype, const void* x, void* y, long n, void* stream);
+int cl_silu_bwd(int dtype, const void* x, const void* dy, void* dx, long n, void* stream);
+int cl_axpby(int dtype, const void* x, long ldx, void* y, long ldy, long M, int C, float a, float b, void* stream);
+int cl_transpose(int in_dtype, int out_dtype, const void* in, long ldi, long bsi, void* out, long ldo,
+                 long bso, int Bt, int R, int C, int Rpad, void* stream);
+int cl_nchw_to_tok(int dtype, const float* in, void* out, long ldo, int B, int Cin, int Cpad, int HW, void* stream);
+int cl_tok_to_nchw(int dtype, const void* in, long ldi, float* out, int B, int C, int HW, float alpha, float beta, void* stream);
+int cl_colsum(int dtype, const void* in, long ldi, float* out, long ldo, int B, int HW, int C, float scale, void* stream);
+int cl_pool2x2(int dtype, const void* in, long ldi, void* out, long ldo, int B, int H, int W, int C, int accumulate, void* stream);
+int cl_pack2d(int dtype, const float* in, long ldi, void* out, long ldo, long R, int C, int Cpad, void* stream);
+/* timestep_embedding (util.py:154-174); freqs = the fp32 table exp(-ln(1e4) * arange(half)/half) */
+int cl_timestep_embedding(int dtype, const long* t, const float* freqs, void* out, long ldo, int B, int half, void* stream);
+
+/* ---- diffusion bookkeeping ------------------------------------------------------------ */
+/* DDPM.q_sample (ddpm.py:356-359): out = sqrt_ac[t_b] * z + sqrt_1mac[t_b] * noise */
+int cl_qsample(const float* z, const float* noise, const long* t, const float* sqrt_ac, const float* sqrt_1mac,
+               float* out, int B, long per_sample, void* stream);
+/* p_losses MSE (ddpm.py:902-918): *loss = mean((eps - target)^2); d_eps = 2 (eps - target) / n * gscale */
+int cl_mse_loss(const float* eps, const float* target, float* d_eps, float* loss, long n, float gscale, void* stream);
+/* DDIMSampler.p_sample_ddim update (cldm/ddim_hacked.py:192,203-231); coef = device [S][4] fp32 table
+ * {a_t, a_prev, sigma_t, sqrt(1-a_t)}; e_u = NULL disables classifier-free guidance. */
+int cl_ddim_step(const float* x, const float* e_c, const float* e_u, const float* noise, const float* coef,
+                 int index, float scale, float* x_prev, float* pred_x0, long n, void* stream);
+/* torch.optim.AdamW step over one flat fp32 buffer (cldm_ctrlora_finetune.py:105) */
+int cl_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+             float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTRLORA_HIP_H */

@@ -1,0 +1,70 @@
+"""The C-ABI library builds, loads and exports every symbol include/ctrlora_hip.h declares, and the
+ctypes signatures agree with the header (argument counts and pointer/int/float classes).
+No kernel is launched here (no GPU needed)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from tests.util import ROOT
+
+
+def _header_decls():
+    src = open(os.path.join(ROOT, "include", "ctrlora_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\b(int|long)\s+(cl_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        args = [a.strip() for a in m.group(3).split(",")]
+        if args == ["void"] or args == [""]:
+            args = []
+        decls[m.group(2)] = (m.group(1), args)
+    return decls
+
+
+def _cls(arg: str) -> str:
+    if "*" in arg:
+        return "ptr"
+    base = arg.split()[:-1]
+    if "float" in base:
+        return "float"
+    if "long" in base:
+        return "long"
+    return "int"
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from ctrlora_amd import build
+    return build.build(verbose=False)
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    decls = _header_decls()
+    assert len(decls) >= 30
+    L = ctypes.CDLL(built_lib)
+    for name in decls:
+        assert hasattr(L, name), f"{name} declared in ctrlora_hip.h but not exported"
+    assert L.cl_abi_version() == 1
+
+
+def test_ctypes_signatures_match_header(built_lib):
+    from ctrlora_amd import hip
+    decls = _header_decls()
+    assert set(hip.EXPORTED) == set(decls), set(hip.EXPORTED) ^ set(decls)
+    cmap = {ctypes.c_void_p: "ptr", ctypes.c_long: "long", ctypes.c_int: "int", ctypes.c_float: "float"}
+    for name, (ret, args) in decls.items():
+        sig = hip._SIGS[name]
+        assert len(sig) == len(args), (name, len(sig), len(args))
+        for a, s in zip(args, sig):
+            want = _cls(a)
+            got = cmap.get(s, "ptr")
+            assert want == got, (name, a, s)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from ctrlora_amd import hip
+    monkeypatch.setattr(hip, "_lib", None)
+    monkeypatch.setattr(hip, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(hip.HipError):
+        hip.lib()
