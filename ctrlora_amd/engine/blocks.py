@@ -1,0 +1,404 @@
+"""Forward / backward of the CtrLoRA building blocks on the HIP kernels.
+
+Activations are token-major ("NHWC") 2-D tensors [B*H*W, C] in the engine dtype.  Every
+block has an explicit `fwd` (optionally recording what its `bwd` needs) and a hand-written
+`bwd` that produces data gradients and accumulates gradients of the *trainable* tensors only
+(LoRA A/B, zero convs, `norm` layers) -- no dW is ever formed for a frozen weight and nothing
+is recomputed (the algorithmic minimum, vs. the reference's
+checkpoint()-recompute + dead weight-gradients).
+
+Reference modules restated (behaviour, not code):
+  ResBlock._forward                ldm/modules/diffusionmodules/openaimodel.py:254-274
+  Downsample / Upsample            openaimodel.py:108-118,157-159
+  SpatialTransformer.forward       ldm/modules/attention.py:321-340
+  BasicTransformerBlock._forward   attention.py:271-275
+  CrossAttention.forward           attention.py:163-194
+  GEGLU / FeedForward              attention.py:49-76
+  LoRACompatibleLinear.forward     cldm/lora.py:285-291
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from .. import hip
+from .packing import Conv3W, LinearW, NormW, rup
+
+
+class Ctx:
+    """Per-call execution context: dtype, device, whether to record for backward, scratch."""
+
+    def __init__(self, dtype: torch.dtype, device, record: bool):
+        self.dtype = dtype
+        self.device = device
+        self.record = record
+        self._gn_ws: Optional[torch.Tensor] = None
+        self._tcache: Dict[Tuple[int, int, int, int], torch.Tensor] = {}
+
+    def new(self, rows: int, cols: int, dtype=None) -> torch.Tensor:
+        return torch.empty((rows, cols), dtype=dtype or self.dtype, device=self.device)
+
+    def zeros(self, rows: int, cols: int, dtype=None) -> torch.Tensor:
+        return torch.zeros((rows, cols), dtype=dtype or self.dtype, device=self.device)
+
+    def gn_ws(self, B: int, HW: int, C: int) -> torch.Tensor:
+        n = hip.groupnorm_ws(B, HW, C)
+        if self._gn_ws is None or self._gn_ws.numel() < n:
+            self._gn_ws = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=self.device)
+        return self._gn_ws
+
+    # transposed, zero-padded copy [C, Mp] of a [M, C] activation (weight-gradient operand);
+    # cached for the lifetime of one block backward because q/k/v share their input.
+    def transposed(self, x: torch.Tensor) -> torch.Tensor:
+        key = (x.data_ptr(), x.shape[0], x.shape[1], x.stride(0))
+        hit = self._tcache.get(key)
+        if hit is None:
+            M, Cc = x.shape
+            Mp = rup(M, 32)
+            t = torch.empty((Cc, Mp), dtype=x.dtype, device=x.device)
+            hip.transpose(x, t, 1, M, Cc, Mp)
+            hit = (x, t)     # keep the source alive so its address cannot be recycled while cached
+            self._tcache[key] = hit
+        return hit[1]
+
+    def drop_transposes(self):
+        self._tcache.clear()
+
+
+# --------------------------------------------------------------------------- linear
+
+def linear_fwd(ctx: Ctx, L: LinearW, x, out=None, residual=None, act=hip.ACT_NONE, alpha=1.0, beta=1.0,
+               out_f32=False):
+    """y = (x W^T + b [+ (x A^T) B^T]) * alpha + beta * residual.  Returns (y, t = x A^T or None)."""
+    M = x.shape[0]
+    t = None
+    if L.r:
+        t = ctx.new(M, L.r)
+        hip.gemm(x, L.A, t)
+    if out is None:
+        out = ctx.new(M, L.N, torch.float32 if out_f32 else None)
+    hip.gemm(x, L.W, out, a2=t, w2=L.B if L.r else None, bias=L.bias, residual=residual,
+             alpha=alpha, beta=beta if residual is not None else 0.0, act=act, out_f32=out_f32)
+    return out, t
+
+
+def linear_bwd_data(ctx: Ctx, L: LinearW, dy, out=None, accum=None):
+    """dx = dy W + (dy B) A (+ accum).  Returns (dx, u = dy B or None)."""
+    M = dy.shape[0]
+    u = None
+    if L.r:
+        u = ctx.new(M, L.r)
+        hip.gemm(dy, L.Bt, u)
+    if out is None:
+        out = ctx.new(M, L.K)
+    hip.gemm(dy, L.Wt, out, a2=u, w2=L.At if L.r else None, residual=accum, beta=1.0 if accum is not None else 0.0)
+    return out, u
+
+
+def linear_bwd_lora(ctx: Ctx, L: LinearW, x, t, dy, u):
+    """dB += dy^T t ;  dA += u^T x   (fp32, split-K atomics into the flat gradient buffer)."""
+    if not L.r:
+        return
+    hip.weight_grad(ctx.transposed(dy), ctx.transposed(t), L.tB.grad)
+    hip.weight_grad(ctx.transposed(u), ctx.transposed(x), L.tA.grad)
+
+
+def dense_bwd_weight(ctx: Ctx, L: LinearW, x, dy, B: int, HW: int, scale: float = 1.0):
+    """Trainable dense 1x1 conv (zero convs): dW += scale * dy^T x ; db += scale * colsum(dy)."""
+    hip.weight_grad(ctx.transposed(dy), ctx.transposed(x), L.tW.grad.view(L.N, L.K), scale)
+    if L.tb is not None:
+        hip.colsum(dy, L.tb.grad.view(1, L.N), 1, B * HW, scale)
+
+
+# --------------------------------------------------------------------------- norms
+
+class GroupNormOp:
+    def __init__(self, w: NormW, eps: float, silu: bool):
+        self.w, self.eps, self.silu = w, eps, silu
+
+    def fwd(self, ctx: Ctx, x, B: int, HW: int, out=None):
+        C = x.shape[1]
+        if out is None:
+            out = ctx.new(x.shape[0], C)
+        stats = torch.empty((B, 32, 2), dtype=torch.float32, device=ctx.device)
+        hip.groupnorm_fwd(x, out, self.w.gamma, self.w.beta, B, HW, self.eps, self.silu, stats, ctx.gn_ws(B, HW, C))
+        return out, stats
+
+    def bwd(self, ctx: Ctx, x, dy, stats, B: int, HW: int, accum=None, out=None):
+        C = x.shape[1]
+        if out is None:
+            out = ctx.new(x.shape[0], C)
+        hip.groupnorm_bwd(x, dy, out, self.w.gamma, self.w.beta, stats, B, HW, self.silu, ctx.gn_ws(B, HW, C),
+                          accum=accum, dgamma=self.w.ggamma, dbeta=self.w.gbeta)
+        return out
+
+
+class LayerNormOp:
+    def __init__(self, w: NormW, eps: float = 1e-5):
+        self.w, self.eps = w, eps
+
+    def fwd(self, ctx: Ctx, x):
+        out = ctx.new(*x.shape)
+        stats = torch.empty((x.shape[0], 2), dtype=torch.float32, device=ctx.device) if ctx.record else None
+        hip.layernorm_fwd(x, out, self.w.gamma, self.w.beta, self.eps, stats)
+        return out, stats
+
+    def bwd(self, ctx: Ctx, x, dy, stats, accum=None):
+        out = ctx.new(*x.shape)
+        hip.layernorm_bwd(x, dy, out, self.w.gamma, stats, accum=accum, dgamma=self.w.ggamma, dbeta=self.w.gbeta)
+        return out
+
+
+# --------------------------------------------------------------------------- conv helpers
+
+def conv3_fwd(ctx: Ctx, cw: Conv3W, x, B, Hin, Win, mode=hip.CONV_S1, out=None, rowbias=None, residual=None,
+              out_f32=False):
+    if mode == hip.CONV_S2:
+        Ho, Wo = Hin // 2, Win // 2
+    elif mode == hip.CONV_UP2:
+        Ho, Wo = 2 * Hin, 2 * Win
+    else:
+        Ho, Wo = Hin, Win
+    M = B * Ho * Wo
+    if out is None:
+        out = ctx.new(M, cw.Op, torch.float32 if out_f32 else None)
+    hip.gemm(x, cw.Wp, out, bias=cw.bias, rowbias=rowbias, rows_per_batch=Ho * Wo, residual=residual,
+             beta=1.0 if residual is not None else 0.0, mode=mode, conv=(B, Hin, Win, Ho, Wo), k1=cw.Ip,
+             out_f32=out_f32, N=cw.Op)
+    return out
+
+
+def conv3_bwd_data(ctx: Ctx, cw: Conv3W, dy, B, Hdy, Wdy, fwd_mode=hip.CONV_S1, out=None, accum=None):
+    """Data gradient of a 3x3 conv given dy on the conv's OUTPUT grid (Hdy x Wdy)."""
+    if fwd_mode == hip.CONV_S1:
+        M = B * Hdy * Wdy
+        if out is None:
+            out = ctx.new(M, cw.Ip)
+        hip.gemm(dy, cw.Wd, out, residual=accum, beta=1.0 if accum is not None else 0.0, mode=hip.CONV_S1,
+                 conv=(B, Hdy, Wdy, Hdy, Wdy), k1=cw.Op, N=cw.Ip)
+        return out
+    if fwd_mode == hip.CONV_S2:      # dx lives on the 2x grid: conv over the zero-stuffed dy
+        M = B * 4 * Hdy * Wdy
+        if out is None:
+            out = ctx.new(M, cw.Ip)
+        hip.gemm(dy, cw.Wd, out, residual=accum, beta=1.0 if accum is not None else 0.0, mode=hip.CONV_T2,
+                 conv=(B, Hdy, Wdy, 2 * Hdy, 2 * Wdy), k1=cw.Op, N=cw.Ip)
+        return out
+    if fwd_mode == hip.CONV_UP2:     # dy on the upsampled grid -> stride-1 data gradient -> 2x2 sum pool
+        M = B * Hdy * Wdy
+        dup = ctx.new(M, cw.Ip)
+        hip.gemm(dy, cw.Wd, dup, mode=hip.CONV_S1, conv=(B, Hdy, Wdy, Hdy, Wdy), k1=cw.Op, N=cw.Ip)
+        if out is None:
+            out = ctx.new(M // 4, cw.Ip)
+        hip.pool2x2(dup, out, B, Hdy // 2, Wdy // 2, accumulate=False)
+        return out
+    raise ValueError(fwd_mode)
+
+
+# --------------------------------------------------------------------------- ResBlock
+
+class ResBlockE:
+    def __init__(self, gn1: NormW, conv1: Conv3W, emb: LinearW, gn2: NormW, conv2: Conv3W,
+                 skip: Optional[LinearW]):
+        self.gn1 = GroupNormOp(gn1, 1e-5, True)
+        self.gn2 = GroupNormOp(gn2, 1e-5, True)
+        self.conv1, self.conv2, self.emb, self.skip = conv1, conv2, emb, skip
+        self.cin, self.cout = conv1.I, conv1.O
+
+    def fwd(self, ctx: Ctx, x, semb, B, H, W, out=None):
+        HW = H * W
+        h1, st1 = self.gn1.fwd(ctx, x, B, HW)
+        e_out, t_e = linear_fwd(ctx, self.emb, semb)                      # [B, cout]
+        h2 = conv3_fwd(ctx, self.conv1, h1, B, H, W, rowbias=e_out)       # + bias + emb (openaimodel.py:272)
+        del h1
+        h3, st2 = self.gn2.fwd(ctx, h2, B, HW)
+        if self.skip is not None:
+            out, _ = linear_fwd(ctx, self.skip, x, out=out)
+            conv3_fwd(ctx, self.conv2, h3, B, H, W, out=out, residual=out)  # skip(x) + h  (:274)
+        else:
+            out = conv3_fwd(ctx, self.conv2, h3, B, H, W, out=out, residual=x)
+        saved = (x, st1, h2, st2, semb, t_e) if ctx.record else None
+        return out, saved
+
+    def bwd(self, ctx: Ctx, dout, saved, B, H, W, dsemb=None, need_emb_grads=False, out=None):
+        x, st1, h2, st2, semb, t_e = saved
+        HW = H * W
+        dh3 = conv3_bwd_data(ctx, self.conv2, dout, B, H, W)
+        dh2 = self.gn2.bwd(ctx, h2, dh3, st2, B, HW)
+        del dh3
+        if need_emb_grads:
+            # d emb_out[b, c] = sum_p dh2[b, p, c]; back through the LoRA'd emb linear into d silu(emb)
+            de32 = ctx.zeros(B, self.cout, torch.float32)
+            hip.colsum(dh2, de32, B, HW)
+            de = ctx.new(B, self.cout)
+            hip.pack2d(de32, de)
+            _, u = linear_bwd_data(ctx, self.emb, de, out=dsemb, accum=dsemb)
+            linear_bwd_lora(ctx, self.emb, semb, t_e, de, u)
+        dh1 = conv3_bwd_data(ctx, self.conv1, dh2, B, H, W)
+        del dh2
+        if self.skip is not None:
+            dskip, _ = linear_bwd_data(ctx, self.skip, dout)
+        else:
+            dskip = dout
+        dx = self.gn1.bwd(ctx, x, dh1, st1, B, HW, accum=dskip, out=out)
+        ctx.drop_transposes()
+        return dx
+
+
+# --------------------------------------------------------------------------- attention
+
+class AttnE:
+    """CrossAttention.  `fused` = [q|k|v] (self) or [k|v] (cross) weights concatenated along N,
+    used when there is no LoRA (frozen UNet): one GEMM instead of three."""
+
+    def __init__(self, to_q: LinearW, to_k: LinearW, to_v: LinearW, to_out: LinearW, heads: int, is_self: bool,
+                 fused_qkv: Optional[LinearW] = None, fused_kv: Optional[LinearW] = None, need_kv_grad=True):
+        self.q, self.k, self.v, self.o = to_q, to_k, to_v, to_out
+        self.heads, self.is_self = heads, is_self
+        self.fused_qkv, self.fused_kv = fused_qkv, fused_kv
+        self.need_kv_grad = need_kv_grad
+        self.inner = to_q.N
+        self.dh = self.inner // heads
+        self.scale = float(self.dh) ** -0.5
+
+    def project_context(self, ctx: Ctx, c):
+        """K / V projections of the text context (identical for every denoising step)."""
+        if self.fused_kv is not None:
+            kv, _ = linear_fwd(ctx, self.fused_kv, c)
+            return kv[:, :self.inner], kv[:, self.inner:], None, None
+        k, tk = linear_fwd(ctx, self.k, c)
+        v, tv = linear_fwd(ctx, self.v, c)
+        return k, v, tk, tv
+
+    def fwd(self, ctx: Ctx, xn, c, B, N, Nkv, residual, kv_cache=None):
+        inner, H = self.inner, self.heads
+        tq = tk = tv = None
+        if self.is_self:
+            if self.fused_qkv is not None:
+                qkv, _ = linear_fwd(ctx, self.fused_qkv, xn)
+                q, k, v = qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:]
+            else:
+                q, tq = linear_fwd(ctx, self.q, xn)
+                k, tk = linear_fwd(ctx, self.k, xn)
+                v, tv = linear_fwd(ctx, self.v, xn)
+        else:
+            q, tq = linear_fwd(ctx, self.q, xn)
+            if kv_cache is not None:
+                k, v, tk, tv = kv_cache
+            else:
+                k, v, tk, tv = self.project_context(ctx, c)
+        kpad = rup(Nkv, 64)
+        vt = torch.empty((B, inner, kpad), dtype=ctx.dtype, device=ctx.device)
+        hip.transpose(v, vt, B, Nkv, inner, kpad, ldi=v.stride(0))
+        a = ctx.new(B * N, inner)
+        lse = torch.empty((B, H, rup(N, 64)), dtype=torch.float32, device=ctx.device) if ctx.record else None
+        hip.attention_fwd(q, k, vt, a, lse, B, H, N, Nkv, self.dh, self.scale)
+        del vt
+        out, to_ = linear_fwd(ctx, self.o, a, residual=residual)
+        saved = (xn, c, q, k, v, a, lse, tq, tk, tv, to_) if ctx.record else None
+        return out, saved
+
+    def bwd(self, ctx: Ctx, dout, saved, B, N, Nkv, accum_xn=None):
+        """dout: gradient of the block output (residual path handled by the caller).
+        Returns d(xn) (+ accum_xn)."""
+        xn, c, q, k, v, a, lse, tq, tk, tv, to_ = saved
+        inner, H = self.inner, self.heads
+        da, uo = linear_bwd_data(ctx, self.o, dout)
+        linear_bwd_lora(ctx, self.o, a, to_, dout, uo)
+        npad, kpad = rup(N, 64), rup(Nkv, 64)
+        qt = torch.empty((B, inner, npad), dtype=ctx.dtype, device=ctx.device)
+        dot = torch.empty((B, inner, npad), dtype=ctx.dtype, device=ctx.device)
+        kt = torch.empty((B, inner, kpad), dtype=ctx.dtype, device=ctx.device)
+        hip.transpose(q, qt, B, N, inner, npad, ldi=q.stride(0))
+        hip.transpose(da, dot, B, N, inner, npad, ldi=da.stride(0))
+        hip.transpose(k, kt, B, Nkv, inner, kpad, ldi=k.stride(0))
+        delta = torch.empty_like(lse)
+        want_kv = self.is_self or self.need_kv_grad
+        if self.is_self and self.fused_qkv is not None:
+            dqkv = ctx.new(B * N, 3 * inner)
+            dq, dk, dv = dqkv[:, :inner], dqkv[:, inner:2 * inner], dqkv[:, 2 * inner:]
+        else:
+            dq = ctx.new(B * N, inner)
+            dk = ctx.new(B * Nkv, inner) if want_kv else None
+            dv = ctx.new(B * Nkv, inner) if want_kv else None
+        hip.attention_bwd(q, k, v, a, da, qt, dot, kt, lse, delta, dq, dk, dv, B, H, N, Nkv, self.dh, self.scale)
+        del qt, dot, kt
+        if self.is_self:
+            if self.fused_qkv is not None:
+                dxn, _ = linear_bwd_data(ctx, self.fused_qkv, dqkv, accum=accum_xn)
+                return dxn
+            dxn, uq = linear_bwd_data(ctx, self.q, dq, accum=accum_xn)
+            linear_bwd_lora(ctx, self.q, xn, tq, dq, uq)
+            _, uk = linear_bwd_data(ctx, self.k, dk, out=dxn, accum=dxn)
+            linear_bwd_lora(ctx, self.k, xn, tk, dk, uk)
+            _, uv = linear_bwd_data(ctx, self.v, dv, out=dxn, accum=dxn)
+            linear_bwd_lora(ctx, self.v, xn, tv, dv, uv)
+            return dxn
+        dxn, uq = linear_bwd_data(ctx, self.q, dq, accum=accum_xn)
+        linear_bwd_lora(ctx, self.q, xn, tq, dq, uq)
+        if want_kv and self.k.r:
+            # context is an input (no data gradient needed), only the LoRA factors of to_k / to_v train
+            uk = ctx.new(B * Nkv, self.k.r); hip.gemm(dk, self.k.Bt, uk)
+            linear_bwd_lora(ctx, self.k, c, tk, dk, uk)
+            uv = ctx.new(B * Nkv, self.v.r); hip.gemm(dv, self.v.Bt, uv)
+            linear_bwd_lora(ctx, self.v, c, tv, dv, uv)
+        return dxn
+
+
+# --------------------------------------------------------------------------- SpatialTransformer
+
+class SpatialTransformerE:
+    def __init__(self, norm: NormW, proj_in: LinearW, ln1: NormW, attn1: AttnE, ln2: NormW, attn2: AttnE,
+                 ln3: NormW, ff_proj: LinearW, ff_out: LinearW, proj_out: LinearW):
+        self.norm = GroupNormOp(norm, 1e-6, False)
+        self.proj_in, self.proj_out = proj_in, proj_out
+        self.ln1, self.ln2, self.ln3 = LayerNormOp(ln1), LayerNormOp(ln2), LayerNormOp(ln3)
+        self.attn1, self.attn2 = attn1, attn2
+        self.ff_proj, self.ff_out = ff_proj, ff_out
+        self.C = proj_in.N
+
+    def fwd(self, ctx: Ctx, x, c, B, H, W, Nkv, out=None, kv_cache=None):
+        N = H * W
+        xn, st0 = self.norm.fwd(ctx, x, B, N)
+        h0, _ = linear_fwd(ctx, self.proj_in, xn)                    # 1x1 conv == per-token linear
+        del xn
+        n1, s1 = self.ln1.fwd(ctx, h0)
+        h1, sv1 = self.attn1.fwd(ctx, n1, None, B, N, N, residual=h0)
+        n2, s2 = self.ln2.fwd(ctx, h1)
+        h2, sv2 = self.attn2.fwd(ctx, n2, c, B, N, Nkv, residual=h1, kv_cache=kv_cache)
+        n3, s3 = self.ln3.fwd(ctx, h2)
+        p, tp = linear_fwd(ctx, self.ff_proj, n3)                    # [M, 8C]
+        gg = ctx.new(B * N, 4 * self.C)
+        hip.geglu_fwd(p, gg)
+        h3, tf = linear_fwd(ctx, self.ff_out, gg, residual=h2)
+        out, _ = linear_fwd(ctx, self.proj_out, h3, out=out, residual=x)
+        saved = (x, st0, h0, s1, sv1, h1, s2, sv2, h2, s3, n3, p, tp, gg, tf, h3) if ctx.record else None
+        return out, saved
+
+    def bwd(self, ctx: Ctx, dout, saved, B, H, W, Nkv, out=None):
+        x, st0, h0, s1, sv1, h1, s2, sv2, h2, s3, n3, p, tp, gg, tf, h3 = saved
+        N = H * W
+        dh, _ = linear_bwd_data(ctx, self.proj_out, dout)           # d h3 ; (x_in residual: + dout at the end)
+        # feed-forward
+        dgg, uf = linear_bwd_data(ctx, self.ff_out, dh)
+        linear_bwd_lora(ctx, self.ff_out, gg, tf, dh, uf)
+        dp = ctx.new(B * N, 8 * self.C)
+        hip.geglu_bwd(p, dgg, dp)
+        del dgg
+        dn3, up = linear_bwd_data(ctx, self.ff_proj, dp)
+        linear_bwd_lora(ctx, self.ff_proj, n3, tp, dp, up)
+        del dp
+        dh = self.ln3.bwd(ctx, h2, dn3, s3, accum=dh)                # d h2
+        ctx.drop_transposes()
+        # cross attention
+        dn2 = self.attn2.bwd(ctx, dh, sv2, B, N, Nkv)
+        dh = self.ln2.bwd(ctx, h1, dn2, s2, accum=dh)                # d h1
+        ctx.drop_transposes()
+        # self attention
+        dn1 = self.attn1.bwd(ctx, dh, sv1, B, N, N)
+        dh = self.ln1.bwd(ctx, h0, dn1, s1, accum=dh)                # d h0
+        ctx.drop_transposes()
+        dxn, _ = linear_bwd_data(ctx, self.proj_in, dh)
+        dx = self.norm.bwd(ctx, x, dxn, st0, B, N, accum=dout, out=out)
+        return dx

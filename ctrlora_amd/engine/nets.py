@@ -1,0 +1,464 @@
+"""ControlNet (CtrLoRA variant) and ControlledUnetModel executors on the HIP kernels.
+
+Built from a state dict with the reference's parameter names, so the same files load:
+  ControlNetFinetune   cldm/cldm_ctrlora_finetune.py:10-54  (over ControlNet.__init__, cldm/cldm.py:48-282)
+  ControlledUnetModel  cldm/cldm.py:22-45                   (over UNetModel.__init__, openaimodel.py:412-736)
+
+Dataflow differences from the reference that do not change the arithmetic:
+  * activations are NHWC / token-major, so SpatialTransformer's two rearranges vanish and
+    every 1x1 conv is a plain GEMM;
+  * the UNet decoder's torch.cat([h, hs.pop() + control.pop()]) is never materialised by a
+    copy: each zero conv writes  (conv(h)+b)*scale + skip  straight into the right half of the
+    decoder block's input buffer, and the previous decoder block writes its output into the
+    left half (row-stride addressing in every kernel);
+  * the backward pass is hand-written: data gradients everywhere they are needed, weight
+    gradients only for the optimizer's subset, nothing recomputed.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from .. import hip
+from .blocks import (AttnE, Ctx, ResBlockE, SpatialTransformerE, conv3_bwd_data, conv3_fwd, dense_bwd_weight,
+                     linear_bwd_data, linear_bwd_lora, linear_fwd)
+from .packing import Conv3W, LinearW, NormW, TrainableSet, rup
+
+
+@dataclass(frozen=True)
+class NetCfg:
+    """The architecture knobs of configs/*.yaml (control_stage_config / unet_config params)."""
+    in_channels: int = 4
+    out_channels: int = 4
+    model_channels: int = 320
+    channel_mult: Tuple[int, ...] = (1, 2, 4, 4)
+    num_res_blocks: int = 2
+    attention_resolutions: Tuple[int, ...] = (4, 2, 1)
+    num_heads: int = 8
+    context_dim: int = 768
+
+    @property
+    def time_embed_dim(self) -> int:
+        return 4 * self.model_channels
+
+    @staticmethod
+    def from_params(p: dict) -> "NetCfg":
+        return NetCfg(in_channels=p.get("in_channels", 4), out_channels=p.get("out_channels", 4),
+                      model_channels=p["model_channels"], channel_mult=tuple(p["channel_mult"]),
+                      num_res_blocks=p["num_res_blocks"], attention_resolutions=tuple(p["attention_resolutions"]),
+                      num_heads=p["num_heads"], context_dim=p["context_dim"])
+
+
+def is_trainable_name(n: str) -> bool:
+    """Name filter of ControlFinetuneLDM.configure_optimizers (cldm_ctrlora_finetune.py:92-101)."""
+    return ("lora_layer" in n) or ("zero_convs" in n) or ("middle_block_out" in n) or ("norm" in n)
+
+
+class _Builder:
+    def __init__(self, sd: Dict[str, torch.Tensor], prefix: str, dtype, device, need_bwd: bool,
+                 trainables: Optional[TrainableSet]):
+        self.sd, self.prefix, self.dtype, self.device = sd, prefix, dtype, device
+        self.need_bwd, self.tr = need_bwd, trainables
+        self.linears: List[LinearW] = []
+        self.norms: List[NormW] = []
+
+    def _g(self, name):
+        return self.sd[self.prefix + name]
+
+    def _has(self, name):
+        return (self.prefix + name) in self.sd
+
+    def linear(self, name: str) -> LinearW:
+        L = LinearW(self._g(name + ".weight"), self._g(name + ".bias") if self._has(name + ".bias") else None,
+                    self.dtype, self.device, self.need_bwd)
+        dn = name + ".lora_layer.down.weight"
+        if self._has(dn):
+            tA = self.tr.declare(self.prefix + dn, self._g(dn).shape)
+            un = name + ".lora_layer.up.weight"
+            tB = self.tr.declare(self.prefix + un, self._g(un).shape)
+            L.attach_lora(tA, tB, self.device)
+        self.linears.append(L)
+        return L
+
+    def fused(self, names: Sequence[str]) -> LinearW:
+        W = torch.cat([self._g(n + ".weight") for n in names], dim=0)
+        L = LinearW(W, None, self.dtype, self.device, self.need_bwd)
+        return L
+
+    def zero_conv(self, name: str) -> LinearW:
+        L = LinearW(self._g(name + ".weight"), self._g(name + ".bias"), self.dtype, self.device, self.need_bwd)
+        if self.tr is not None:
+            tW = self.tr.declare(self.prefix + name + ".weight", self._g(name + ".weight").shape)
+            tb = self.tr.declare(self.prefix + name + ".bias", self._g(name + ".bias").shape)
+            L.attach_trainable_weight(tW, tb)
+        self.linears.append(L)
+        return L
+
+    def conv3(self, name: str) -> Conv3W:
+        return Conv3W(self._g(name + ".weight"), self._g(name + ".bias"), self.dtype, self.device, self.need_bwd)
+
+    def norm(self, name: str) -> NormW:
+        w = NormW(self._g(name + ".weight"), self._g(name + ".bias"), self.device)
+        if self.tr is not None and is_trainable_name(name):
+            w.attach(self.tr.declare(self.prefix + name + ".weight", self._g(name + ".weight").shape),
+                     self.tr.declare(self.prefix + name + ".bias", self._g(name + ".bias").shape))
+        self.norms.append(w)
+        return w
+
+    def res(self, p: str, cin: int, cout: int) -> ResBlockE:
+        skip = self.linear(p + ".skip_connection") if cin != cout else None
+        return ResBlockE(self.norm(p + ".in_layers.0"), self.conv3(p + ".in_layers.2"),
+                         self.linear(p + ".emb_layers.1"), self.norm(p + ".out_layers.0"),
+                         self.conv3(p + ".out_layers.3"), skip)
+
+    def st(self, p: str, ch: int, heads: int, lora: bool) -> SpatialTransformerE:
+        tb = p + ".transformer_blocks.0"
+        norm = self.norm(p + ".norm")
+        proj_in = self.linear(p + ".proj_in")
+        ln1 = self.norm(tb + ".norm1")
+        a1 = [self.linear(f"{tb}.attn1.{n}") for n in ("to_q", "to_k", "to_v", "to_out.0")]
+        ln2 = self.norm(tb + ".norm2")
+        a2 = [self.linear(f"{tb}.attn2.{n}") for n in ("to_q", "to_k", "to_v", "to_out.0")]
+        ln3 = self.norm(tb + ".norm3")
+        ff_proj = self.linear(tb + ".ff.net.0.proj")
+        ff_out = self.linear(tb + ".ff.net.2")
+        proj_out = self.linear(p + ".proj_out")
+        fq = fkv = None
+        if not lora:   # frozen UNet: one GEMM for q|k|v and for the context's k|v
+            fq = self.fused([f"{tb}.attn1.to_q", f"{tb}.attn1.to_k", f"{tb}.attn1.to_v"])
+            fkv = self.fused([f"{tb}.attn2.to_k", f"{tb}.attn2.to_v"])
+        attn1 = AttnE(a1[0], a1[1], a1[2], a1[3], heads, True, fused_qkv=fq)
+        attn2 = AttnE(a2[0], a2[1], a2[2], a2[3], heads, False, fused_kv=fkv, need_kv_grad=lora)
+        return SpatialTransformerE(norm, proj_in, ln1, attn1, ln2, attn2, ln3, ff_proj, ff_out, proj_out)
+
+
+# ------------------------------------------------------------------------------ layer wrappers
+
+class _Env:
+    """Mutable per-pass state threaded through the layers."""
+    __slots__ = ("B", "H", "W", "semb", "c", "Nkv", "dsemb", "emb_grads", "kv")
+
+    def __init__(self, B, H, W, semb, c, Nkv):
+        self.B, self.H, self.W, self.semb, self.c, self.Nkv = B, H, W, semb, c, Nkv
+        self.dsemb = None
+        self.emb_grads = False
+        self.kv = None
+
+
+class _Res:
+    def __init__(self, blk: ResBlockE):
+        self.blk = blk
+        self.cout = blk.cout
+
+    def fwd(self, ctx, x, env, out=None):
+        return self.blk.fwd(ctx, x, env.semb, env.B, env.H, env.W, out=out)
+
+    def bwd(self, ctx, dy, saved, env, out=None):
+        return self.blk.bwd(ctx, dy, saved, env.B, env.H, env.W, dsemb=env.dsemb, need_emb_grads=env.emb_grads,
+                            out=out)
+
+
+class _ST:
+    def __init__(self, blk: SpatialTransformerE, key: str):
+        self.blk, self.key = blk, key
+        self.cout = blk.C
+
+    def fwd(self, ctx, x, env, out=None):
+        cache = None
+        if env.kv is not None:
+            cache = env.kv.get(self.key)
+            if cache is None:
+                cache = self.blk.attn2.project_context(ctx, env.c)
+                env.kv[self.key] = cache
+        return self.blk.fwd(ctx, x, env.c, env.B, env.H, env.W, env.Nkv, out=out, kv_cache=cache)
+
+    def bwd(self, ctx, dy, saved, env, out=None):
+        return self.blk.bwd(ctx, dy, saved, env.B, env.H, env.W, env.Nkv, out=out)
+
+
+class _Conv:
+    """Plain 3x3 conv layer: input conv, Downsample.op (stride 2), Upsample.conv (nearest x2 fused)."""
+
+    def __init__(self, cw: Conv3W, mode: int):
+        self.cw, self.mode = cw, mode
+        self.cout = cw.O
+
+    def fwd(self, ctx, x, env, out=None):
+        y = conv3_fwd(ctx, self.cw, x, env.B, env.H, env.W, mode=self.mode, out=out)
+        if self.mode == hip.CONV_S2:
+            env.H //= 2; env.W //= 2
+        elif self.mode == hip.CONV_UP2:
+            env.H *= 2; env.W *= 2
+        return y, ()
+
+    def bwd(self, ctx, dy, saved, env, out=None):
+        # env.H/W are the spatial dims of dy (the conv's output grid)
+        dx = conv3_bwd_data(ctx, self.cw, dy, env.B, env.H, env.W, fwd_mode=self.mode, out=out)
+        if self.mode == hip.CONV_S2:
+            env.H *= 2; env.W *= 2
+        elif self.mode == hip.CONV_UP2:
+            env.H //= 2; env.W //= 2
+        return dx
+
+
+def _run_fwd(ctx, layers, x, env, out=None):
+    saved = []
+    for i, l in enumerate(layers):
+        x, s = l.fwd(ctx, x, env, out=out if i == len(layers) - 1 else None)
+        saved.append(s)
+    return x, saved
+
+
+def _run_bwd(ctx, layers, dy, saved, env, out=None):
+    for i in range(len(layers) - 1, -1, -1):
+        dy = layers[i].bwd(ctx, dy, saved[i], env, out=out if i == 0 else None)
+    return dy
+
+
+class _TimeEmbed:
+    """timestep_embedding -> Linear -> SiLU -> Linear (-> SiLU for the ResBlocks' emb_layers[0])."""
+
+    def __init__(self, b: _Builder, cfg: NetCfg):
+        self.l0, self.l2 = b.linear("time_embed.0"), b.linear("time_embed.2")
+        half = cfg.model_channels // 2
+        # exactly the reference's fp32 table (util.py:165-167), built on the host once
+        freqs = torch.exp(-math.log(10000.0) * torch.arange(0, half, dtype=torch.float32) / half)
+        self.freqs = freqs.to(b.device)
+        self.mc, self.ted = cfg.model_channels, cfg.time_embed_dim
+
+    def fwd(self, ctx: Ctx, t: torch.Tensor):
+        B = t.shape[0]
+        temb = ctx.new(B, self.mc)
+        hip.timestep_embedding(t, self.freqs, temb)
+        te0, t0 = linear_fwd(ctx, self.l0, temb)
+        h = ctx.new(B, self.ted); hip.silu_fwd(te0, h)
+        emb, t2 = linear_fwd(ctx, self.l2, h)
+        semb = ctx.new(B, self.ted); hip.silu_fwd(emb, semb)
+        return semb, (temb, te0, t0, h, emb, t2)
+
+    def bwd(self, ctx: Ctx, dsemb, saved):
+        temb, te0, t0, h, emb, t2 = saved
+        demb = ctx.new(*emb.shape); hip.silu_bwd(emb, dsemb, demb)
+        dh, u2 = linear_bwd_data(ctx, self.l2, demb)
+        linear_bwd_lora(ctx, self.l2, h, t2, demb, u2)
+        dte0 = ctx.new(*te0.shape); hip.silu_bwd(te0, dh, dte0)
+        if self.l0.r:
+            u0 = ctx.new(dte0.shape[0], self.l0.r); hip.gemm(dte0, self.l0.Bt, u0)
+            linear_bwd_lora(ctx, self.l0, temb, t0, dte0, u0)
+        ctx.drop_transposes()
+
+
+def _encoder_layers(b: _Builder, cfg: NetCfg, lora: bool):
+    """input_blocks (openaimodel.py:542-605 / cldm.py:139-237): list of layer lists + channel list."""
+    mc = cfg.model_channels
+    blocks = [[_Conv(b.conv3("input_blocks.0.0"), hip.CONV_S1)]]
+    chans = [mc]
+    ch, ds, idx = mc, 1, 1
+    for level, mult in enumerate(cfg.channel_mult):
+        for _ in range(cfg.num_res_blocks):
+            layers = [_Res(b.res(f"input_blocks.{idx}.0", ch, mult * mc))]
+            ch = mult * mc
+            if ds in cfg.attention_resolutions:
+                layers.append(_ST(b.st(f"input_blocks.{idx}.1", ch, cfg.num_heads, lora), f"in{idx}"))
+            blocks.append(layers)
+            chans.append(ch)
+            idx += 1
+        if level != len(cfg.channel_mult) - 1:
+            blocks.append([_Conv(b.conv3(f"input_blocks.{idx}.0.op"), hip.CONV_S2)])
+            chans.append(ch)
+            ds *= 2
+            idx += 1
+    mid = [_Res(b.res("middle_block.0", ch, ch)), _ST(b.st("middle_block.1", ch, cfg.num_heads, lora), "mid"),
+           _Res(b.res("middle_block.2", ch, ch))]
+    return blocks, chans, mid, ds
+
+
+# ------------------------------------------------------------------------------ ControlNet
+
+class ControlNetE:
+    def __init__(self, sd, cfg: NetCfg, dtype, device, prefix: str = "", need_bwd: bool = True,
+                 trainables: Optional[TrainableSet] = None):
+        self.cfg, self.dtype, self.device = cfg, dtype, device
+        self.tr = trainables if trainables is not None else TrainableSet()
+        b = _Builder(sd, prefix, dtype, device, need_bwd, self.tr)
+        self.lora = (prefix + "time_embed.0.lora_layer.down.weight") in sd
+        self.time = _TimeEmbed(b, cfg)
+        self.blocks, self.chans, self.mid, _ = _encoder_layers(b, cfg, lora=True)
+        self.zero = [b.zero_conv(f"zero_convs.{k}.0") for k in range(len(self.chans))]
+        self.zero.append(b.zero_conv("middle_block_out.0"))
+        # flat buffer in backward-completion order: middle first, time_embed last
+        self.tr.items.reverse()
+        self.tr.materialize({k: v for k, v in sd.items()}, device)
+        self._b = b
+        self.repack()
+
+    def repack(self):
+        for L in self._b.linears:
+            L.repack()
+        for n in self._b.norms:
+            n.repack()
+
+    def fwd(self, ctx: Ctx, hint_tok, t, c, B, H, W, sinks, scales, weight=1.0, kv=None):
+        """sinks[k] = (out_view, residual_view or None); out = (zero_conv_k(h_k)) * scale_k * weight + residual."""
+        semb, tsv = self.time.fwd(ctx, t)
+        env = _Env(B, H, W, semb, c, c.shape[0] // B)
+        env.kv = kv
+        h = hint_tok
+        saved, hs, dims = [], [], []
+        for k, layers in enumerate(self.blocks):
+            h, sv = _run_fwd(ctx, layers, h, env)
+            saved.append(sv); dims.append((env.H, env.W))
+            self._zero_fwd(k, h, sinks[k], scales[k] * weight)
+            hs.append(h if ctx.record else None)
+        h, sv = _run_fwd(ctx, self.mid, h, env)
+        saved.append(sv); dims.append((env.H, env.W))
+        self._zero_fwd(len(self.blocks), h, sinks[-1], scales[-1] * weight)
+        hs.append(h if ctx.record else None)
+        return (tsv, semb, saved, hs, dims, c) if ctx.record else None
+
+    def _zero_fwd(self, k, h, sink, alpha):
+        out, res = sink
+        z = self.zero[k]
+        hip.gemm(h, z.W, out, bias=z.bias, alpha=alpha, residual=res, beta=1.0 if res is not None else 0.0)
+
+    def bwd(self, ctx: Ctx, record, dsinks, scales, weight, B):
+        tsv, semb, saved, hs, dims, c = record
+        env = _Env(B, 0, 0, semb, c, c.shape[0] // B)
+        env.emb_grads = True
+        env.dsemb = ctx.zeros(B, self.cfg.time_embed_dim)
+        nb = len(self.blocks)
+        # middle_block_out + middle block
+        env.H, env.W = dims[nb]
+        dh = self._zero_bwd(ctx, nb, hs[nb], dsinks[nb], scales[nb] * weight, None, B, env.H * env.W)
+        dh = _run_bwd(ctx, self.mid, dh, saved[nb], env)
+        for k in range(nb - 1, -1, -1):
+            env.H, env.W = dims[k]
+            dh = self._zero_bwd(ctx, k, hs[k], dsinks[k], scales[k] * weight, dh, B, env.H * env.W)
+            if k == 0:
+                break   # input conv is frozen and the hint needs no gradient
+            dh = _run_bwd(ctx, self.blocks[k], dh, saved[k], env)
+        self.time.bwd(ctx, env.dsemb, tsv)
+
+    def _zero_bwd(self, ctx, k, h, dz, alpha, dh_in, B, HW):
+        z = self.zero[k]
+        dense_bwd_weight(ctx, z, h, dz, B, HW, alpha)
+        ctx.drop_transposes()
+        out = ctx.new(h.shape[0], z.K)
+        hip.gemm(dz, z.Wt, out, alpha=alpha, residual=dh_in, beta=1.0 if dh_in is not None else 0.0)
+        return out
+
+
+# ------------------------------------------------------------------------------ UNet
+
+class UNetE:
+    def __init__(self, sd, cfg: NetCfg, dtype, device, prefix: str = "", need_bwd: bool = True):
+        self.cfg, self.dtype, self.device = cfg, dtype, device
+        b = _Builder(sd, prefix, dtype, device, need_bwd, None)
+        self.time = _TimeEmbed(b, cfg)
+        self.blocks, self.chans, self.mid, ds = _encoder_layers(b, cfg, lora=False)
+        mc = cfg.model_channels
+        chans = list(self.chans)
+        ch = mc * cfg.channel_mult[-1]
+        self.dec: List[list] = []
+        self.dec_c1: List[int] = []
+        self.dec_c2: List[int] = []
+        idx = 0
+        for level, mult in list(enumerate(cfg.channel_mult))[::-1]:
+            for i in range(cfg.num_res_blocks + 1):
+                ich = chans.pop()
+                self.dec_c1.append(ch); self.dec_c2.append(ich)
+                layers = [_Res(b.res(f"output_blocks.{idx}.0", ch + ich, mc * mult))]
+                ch = mc * mult
+                if ds in cfg.attention_resolutions:
+                    layers.append(_ST(b.st(f"output_blocks.{idx}.{len(layers)}", ch, cfg.num_heads, False), f"out{idx}"))
+                if level and i == cfg.num_res_blocks:
+                    layers.append(_Conv(b.conv3(f"output_blocks.{idx}.{len(layers)}.conv"), hip.CONV_UP2))
+                    ds //= 2
+                self.dec.append(layers)
+                idx += 1
+        self.out_norm = b.norm("out.0")
+        self.out_conv = b.conv3("out.2")
+        from .blocks import GroupNormOp
+        self.out_gn = GroupNormOp(self.out_norm, 1e-5, True)
+
+    # -- encoder + middle (never needs gradients: cldm/cldm.py:25-32 runs it under no_grad)
+    def encode(self, ctx: Ctx, x_tok, t, c, B, H, W, kv=None):
+        rec = ctx.record
+        ctx.record = False
+        semb, _ = self.time.fwd(ctx, t)
+        env = _Env(B, H, W, semb, c, c.shape[0] // B)
+        env.kv = kv
+        hs, dims = [], []
+        h = x_tok
+        for layers in self.blocks:
+            h, _ = _run_fwd(ctx, layers, h, env)
+            hs.append(h); dims.append((env.H, env.W))
+        h, _ = _run_fwd(ctx, self.mid, h, env)
+        ctx.record = rec
+        return semb, hs, dims, h
+
+    def alloc_decoder_inputs(self, ctx: Ctx, B, dims):
+        """One buffer per decoder block = its concatenated input [h | skip + control]."""
+        bufs = []
+        nd = len(self.dec)
+        for i in range(nd):
+            Hh, Ww = dims[nd - 1 - i]
+            bufs.append(ctx.new(B * Hh * Ww, self.dec_c1[i] + self.dec_c2[i]))
+        return bufs
+
+    def control_sinks(self, bufs, hs, h_mid):
+        """Where ControlNet zero-conv k must write, and what it must add (UNet skip / middle output)."""
+        nd = len(self.dec)
+        sinks = []
+        for k in range(nd):
+            i = nd - 1 - k
+            sinks.append((bufs[i][:, self.dec_c1[i]:], hs[k]))
+        sinks.append((bufs[0][:, :self.dec_c1[0]], h_mid))
+        return sinks
+
+    def fill_without_control(self, ctx, bufs, hs, h_mid, only_mid: Optional[torch.Tensor] = None):
+        nd = len(self.dec)
+        for k in range(nd):
+            i = nd - 1 - k
+            hip.axpby(hs[k], bufs[i][:, self.dec_c1[i]:], 1.0, 0.0)
+        hip.axpby(h_mid, bufs[0][:, :self.dec_c1[0]], 1.0, 0.0)
+
+    def decode(self, ctx: Ctx, bufs, semb, c, B, dims_mid):
+        env = _Env(B, dims_mid[0], dims_mid[1], semb, c, c.shape[0] // B)
+        saved = []
+        nd = len(self.dec)
+        h = None
+        for i, layers in enumerate(self.dec):
+            out = bufs[i + 1][:, :self.dec_c1[i + 1]] if i + 1 < nd else None
+            h, sv = _run_fwd(ctx, layers, bufs[i], env, out=out)
+            saved.append((sv, (env.H, env.W)))
+        M = h.shape[0]
+        hn, st = self.out_gn.fwd(ctx, h, B, env.H * env.W)
+        eps_tok = conv3_fwd(ctx, self.out_conv, hn, B, env.H, env.W, out_f32=True)      # [M, 32] fp32, 4 real
+        rec = (saved, h, st, semb, c, (env.H, env.W)) if ctx.record else None
+        return eps_tok, rec
+
+    def decode_bwd(self, ctx: Ctx, d_eps_tok, rec, B):
+        """d_eps_tok [M, 32] (engine dtype, channels >= out_channels zero).  Returns per-decoder-block
+        gradients of the concatenated inputs (left half: previous block / middle, right half: skip+control)."""
+        saved, h_last, st, semb, c, (H, W) = rec
+        dhn = conv3_bwd_data(ctx, self.out_conv, d_eps_tok, B, H, W)
+        dh = self.out_gn.bwd(ctx, h_last, dhn, st, B, H * W)
+        nd = len(self.dec)
+        dbufs = [None] * nd
+        env = _Env(B, H, W, semb, c, c.shape[0] // B)
+        for i in range(nd - 1, -1, -1):
+            sv, (Ho, Wo) = saved[i]
+            env.H, env.W = Ho, Wo
+            dbufs[i] = _run_bwd(ctx, self.dec[i], dh, sv, env)
+            dh = dbufs[i][:, :self.dec_c1[i]]
+        return dbufs
+
+    def control_grad_sinks(self, dbufs):
+        nd = len(self.dec)
+        ds = [dbufs[nd - 1 - k][:, self.dec_c1[nd - 1 - k]:] for k in range(nd)]
+        ds.append(dbufs[0][:, :self.dec_c1[0]])
+        return ds

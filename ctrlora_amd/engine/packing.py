@@ -1,0 +1,160 @@
+"""Weight packing for the HIP engine.
+
+The nn.Module mirror (cldm/, ldm/) owns fp32 parameters under the reference's state-dict
+names.  The engine consumes *packed* copies in its storage dtype, laid out for the kernels:
+
+  linear  W [N,K]            -> W (NT operand), Wt = W^T [K,N] (data-gradient operand)
+  LoRA    down A [r,K], up B [N,r]  -> A, At = A^T [K,r], B, Bt = B^T [r,N]
+  conv3x3 W [O,I,3,3]        -> Wp [O][ky][kx][I]  and  Wd [I][2-ky][2-kx][O] (data gradient)
+  conv1x1 W [O,I,1,1]        -> as linear
+
+Frozen weights are packed once.  Trainables (LoRA A/B, zero convs, the `norm` layers --
+cldm/cldm_ctrlora_finetune.py:84-108) live in ONE flat fp32 master buffer with ONE flat fp32
+gradient buffer (ordered by backward completion so that the DP all-reduce can be bucketed and
+overlapped); their packed copies are refreshed after every optimizer step by the pack /
+transpose kernels.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from .. import hip
+
+
+def rup(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class Trainable:
+    name: str
+    shape: Tuple[int, ...]
+    offset: int = 0
+    master: Optional[torch.Tensor] = None   # fp32 view into the flat master buffer
+    grad: Optional[torch.Tensor] = None     # fp32 view into the flat grad buffer
+
+
+class TrainableSet:
+    """Flat fp32 master + gradient storage for the optimizer's parameter subset."""
+
+    def __init__(self):
+        self.items: List[Trainable] = []
+        self.by_name: Dict[str, Trainable] = {}
+        self.flat: Optional[torch.Tensor] = None
+        self.flat_grad: Optional[torch.Tensor] = None
+        self.numel = 0
+
+    def declare(self, name: str, shape) -> Trainable:
+        t = Trainable(name, tuple(shape))
+        self.items.append(t)
+        self.by_name[name] = t
+        return t
+
+    def materialize(self, sd: Dict[str, torch.Tensor], device):
+        off = 0
+        for t in self.items:
+            t.offset = off
+            n = 1
+            for s in t.shape:
+                n *= s
+            off += rup(n, 64)            # keep every tensor 256-byte aligned
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+        self.flat_grad = torch.zeros(off, dtype=torch.float32, device=device)
+        for t in self.items:
+            n = 1
+            for s in t.shape:
+                n *= s
+            t.master = self.flat[t.offset:t.offset + n].view(t.shape)
+            t.grad = self.flat_grad[t.offset:t.offset + n].view(t.shape)
+            t.master.copy_(sd[t.name].to(device=device, dtype=torch.float32).reshape(t.shape))
+
+
+class LinearW:
+    """nn.Linear / 1x1 conv / LoRACompatibleLinear in packed form."""
+
+    def __init__(self, W: torch.Tensor, bias: Optional[torch.Tensor], dtype, device, need_bwd: bool):
+        W = W.reshape(W.shape[0], -1).to(device=device, dtype=torch.float32)
+        self.N, self.K = W.shape
+        self.W = W.to(dtype).contiguous()
+        self.Wt = W.t().to(dtype).contiguous() if need_bwd else None
+        self.bias = None if bias is None else bias.to(device=device, dtype=torch.float32).contiguous()
+        self.r = 0
+        # LoRA (trainable) pieces
+        self.tA: Optional[Trainable] = None
+        self.tB: Optional[Trainable] = None
+        self.A = self.At = self.B = self.Bt = None
+        # trainable dense weight (zero convs)
+        self.tW: Optional[Trainable] = None
+        self.tb: Optional[Trainable] = None
+        self.dtype = dtype
+
+    def attach_lora(self, tA: Trainable, tB: Trainable, device):
+        self.tA, self.tB = tA, tB
+        self.r = tA.shape[0]
+        self.A = torch.empty(self.r, self.K, dtype=self.dtype, device=device)
+        self.At = torch.empty(self.K, self.r, dtype=self.dtype, device=device)
+        self.B = torch.empty(self.N, self.r, dtype=self.dtype, device=device)
+        self.Bt = torch.empty(self.r, self.N, dtype=self.dtype, device=device)
+
+    def attach_trainable_weight(self, tW: Trainable, tb: Optional[Trainable]):
+        self.tW, self.tb = tW, tb
+
+    def repack(self):
+        """Refresh packed copies from the fp32 masters (pack / transpose kernels)."""
+        if self.tA is not None:
+            hip.pack2d(self.tA.master, self.A)
+            hip.transpose(self.tA.master, self.At, 1, self.r, self.K, self.r)
+            hip.pack2d(self.tB.master, self.B)
+            hip.transpose(self.tB.master, self.Bt, 1, self.N, self.r, self.N)
+        if self.tW is not None:
+            w2 = self.tW.master.view(self.N, self.K)
+            hip.pack2d(w2, self.W)
+            if self.Wt is not None:
+                hip.transpose(w2, self.Wt, 1, self.N, self.K, self.N)
+            if self.tb is not None:
+                self.bias = self.tb.master
+
+
+class Conv3W:
+    """3x3 conv in implicit-GEMM form; channels padded to multiples of 32 where needed."""
+
+    def __init__(self, W: torch.Tensor, bias: torch.Tensor, dtype, device, need_bwd: bool):
+        W = W.to(device=device, dtype=torch.float32)
+        O, I = W.shape[0], W.shape[1]
+        self.O, self.I = O, I
+        self.Op, self.Ip = rup(O, 32), rup(I, 32)
+        Wpad = torch.zeros(self.Op, self.Ip, 3, 3, dtype=torch.float32, device=device)
+        Wpad[:O, :I] = W
+        self.Wp = Wpad.permute(0, 2, 3, 1).reshape(self.Op, 9 * self.Ip).to(dtype).contiguous()
+        self.Wd = (Wpad.flip(2, 3).permute(1, 2, 3, 0).reshape(self.Ip, 9 * self.Op).to(dtype).contiguous()
+                   if need_bwd else None)
+        b = torch.zeros(self.Op, dtype=torch.float32, device=device)
+        b[:O] = bias.to(device=device, dtype=torch.float32)
+        self.bias = b
+
+
+class NormW:
+    def __init__(self, gamma, beta, device):
+        self.gamma = gamma.to(device=device, dtype=torch.float32).contiguous()
+        self.beta = beta.to(device=device, dtype=torch.float32).contiguous()
+        self.tg: Optional[Trainable] = None
+        self.tb: Optional[Trainable] = None
+
+    def attach(self, tg: Trainable, tb: Trainable):
+        self.tg, self.tb = tg, tb
+
+    def repack(self):
+        if self.tg is not None:
+            self.gamma, self.beta = self.tg.master, self.tb.master
+
+    @property
+    def ggamma(self):
+        return None if self.tg is None else self.tg.grad
+
+    @property
+    def gbeta(self):
+        return None if self.tb is None else self.tb.grad
