@@ -251,11 +251,16 @@ class _TimeEmbed:
         ctx.drop_transposes()
 
 
-def _encoder_layers(b: _Builder, cfg: NetCfg, lora: bool):
-    """input_blocks (openaimodel.py:542-605 / cldm.py:139-237): list of layer lists + channel list."""
+def _encoder_layers(b: _Builder, cfg: NetCfg, lora: bool, after_block=None):
+    """input_blocks (openaimodel.py:542-605 / cldm.py:139-237): list of layer lists + channel list.
+    `after_block(k)` is called once block k (and finally the middle block, k = n) has been built, so
+    the ControlNet can declare zero conv k right behind it (keeps every backward stage's trainables
+    contiguous in the flat gradient buffer)."""
     mc = cfg.model_channels
+    done = (lambda k: None) if after_block is None else after_block
     blocks = [[_Conv(b.conv3("input_blocks.0.0"), hip.CONV_S1)]]
     chans = [mc]
+    done(0)
     ch, ds, idx = mc, 1, 1
     for level, mult in enumerate(cfg.channel_mult):
         for _ in range(cfg.num_res_blocks):
@@ -265,14 +270,17 @@ def _encoder_layers(b: _Builder, cfg: NetCfg, lora: bool):
                 layers.append(_ST(b.st(f"input_blocks.{idx}.1", ch, cfg.num_heads, lora), f"in{idx}"))
             blocks.append(layers)
             chans.append(ch)
+            done(idx)
             idx += 1
         if level != len(cfg.channel_mult) - 1:
             blocks.append([_Conv(b.conv3(f"input_blocks.{idx}.0.op"), hip.CONV_S2)])
             chans.append(ch)
+            done(idx)
             ds *= 2
             idx += 1
     mid = [_Res(b.res("middle_block.0", ch, ch)), _ST(b.st("middle_block.1", ch, cfg.num_heads, lora), "mid"),
            _Res(b.res("middle_block.2", ch, ch))]
+    done(idx)
     return blocks, chans, mid, ds
 
 
@@ -286,12 +294,31 @@ class ControlNetE:
         b = _Builder(sd, prefix, dtype, device, need_bwd, self.tr)
         self.lora = (prefix + "time_embed.0.lora_layer.down.weight") in sd
         self.time = _TimeEmbed(b, cfg)
-        self.blocks, self.chans, self.mid, _ = _encoder_layers(b, cfg, lora=True)
-        self.zero = [b.zero_conv(f"zero_convs.{k}.0") for k in range(len(self.chans))]
-        self.zero.append(b.zero_conv("middle_block_out.0"))
-        # flat buffer in backward-completion order: middle first, time_embed last
+        marks = [len(self.tr.items)]          # stage boundaries in declaration (= forward) order
+        self.zero: List[LinearW] = []
+
+        def after_block(k):
+            name = f"zero_convs.{k}.0" if (prefix + f"zero_convs.{k}.0.weight") in sd else "middle_block_out.0"
+            self.zero.append(b.zero_conv(name))
+            marks.append(len(self.tr.items))
+
+        self.blocks, self.chans, self.mid, _ = _encoder_layers(b, cfg, lora=True, after_block=after_block)
+        stage_items = [self.tr.items[marks[i]:marks[i + 1]] for i in range(len(marks) - 1)]
+        time_items = self.tr.items[:marks[0]]
+        # flat buffer in backward-completion order: middle stage first, time_embed last
         self.tr.items.reverse()
         self.tr.materialize({k: v for k, v in sd.items()}, device)
+
+        def span(items):
+            if not items:
+                return (0, 0)
+            lo = min(t.offset for t in items)
+            hi = max(t.offset + rup(t.master.numel(), 64) for t in items)
+            return (lo, hi)
+
+        self.stage_spans = [span(it) for it in stage_items]   # index k = encoder stage k (last = middle)
+        self.time_span = span(time_items)
+        self.on_stage_done = None    # callable(start, end): that slice of flat_grad is final (DP overlap hook)
         self._b = b
         self.repack()
 
@@ -334,18 +361,28 @@ class ControlNetE:
         env.H, env.W = dims[nb]
         dh = self._zero_bwd(ctx, nb, hs[nb], dsinks[nb], scales[nb] * weight, None, B, env.H * env.W)
         dh = _run_bwd(ctx, self.mid, dh, saved[nb], env)
+        self._done(self.stage_spans[nb])
         for k in range(nb - 1, -1, -1):
             env.H, env.W = dims[k]
-            dh = self._zero_bwd(ctx, k, hs[k], dsinks[k], scales[k] * weight, dh, B, env.H * env.W)
-            if k == 0:
-                break   # input conv is frozen and the hint needs no gradient
-            dh = _run_bwd(ctx, self.blocks[k], dh, saved[k], env)
+            # stage 0: the input conv is frozen and the hint needs no gradient -> weight grads only
+            dh = self._zero_bwd(ctx, k, hs[k], dsinks[k], scales[k] * weight, dh, B, env.H * env.W,
+                                need_dx=k > 0)
+            if k > 0:
+                dh = _run_bwd(ctx, self.blocks[k], dh, saved[k], env)
+            self._done(self.stage_spans[k])
         self.time.bwd(ctx, env.dsemb, tsv)
+        self._done(self.time_span)
 
-    def _zero_bwd(self, ctx, k, h, dz, alpha, dh_in, B, HW):
+    def _done(self, span):
+        if self.on_stage_done is not None and span[1] > span[0]:
+            self.on_stage_done(span[0], span[1])
+
+    def _zero_bwd(self, ctx, k, h, dz, alpha, dh_in, B, HW, need_dx=True):
         z = self.zero[k]
         dense_bwd_weight(ctx, z, h, dz, B, HW, alpha)
         ctx.drop_transposes()
+        if not need_dx:
+            return None
         out = ctx.new(h.shape[0], z.K)
         hip.gemm(dz, z.Wt, out, alpha=alpha, residual=dh_in, beta=1.0 if dh_in is not None else 0.0)
         return out
