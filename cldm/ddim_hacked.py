@@ -1,0 +1,174 @@
+"""DDIM sampler (API of the reference's cldm/ddim_hacked.py: make_schedule :23-52, sample :55-120,
+ddim_sampling :123-178, p_sample_ddim :181-231).
+
+What changes underneath, not in the results:
+  * the per-step coefficients live in ONE device table; the CFG combine + x0 / direction / noise update is a
+    single fused HIP kernel (the reference issues ~5 elementwise launches and 4 host syncs per step);
+  * classifier-free guidance evaluates the conditional and unconditional passes as one batch of 2B through the
+    engine when both conditionings have the same structure (samples are independent, so the results are
+    those of the reference's two sequential apply_model calls);
+  * schedule tables are computed exactly as the reference does (fp64 numpy / fp32 torch on the host) --
+    index and timestep bookkeeping is bit-exact.
+"""
+import numpy as np
+import torch
+
+from ldm.modules.diffusionmodules.util import make_ddim_sampling_parameters, make_ddim_timesteps, noise_like
+
+
+def _cat_conds(c, u):
+    """Batch two conditioning dicts (or lists of dicts) along dim 0; None if their structure differs."""
+    if isinstance(c, dict) and isinstance(u, dict) and c.keys() == u.keys():
+        out = {}
+        for k in c:
+            a, b = c[k], u[k]
+            if isinstance(a, list) and isinstance(b, list) and len(a) == len(b) and all(
+                    torch.is_tensor(x) and torch.is_tensor(y) and x.shape == y.shape for x, y in zip(a, b)):
+                out[k] = [torch.cat([x, y], 0) for x, y in zip(a, b)]
+            elif a is None and b is None:
+                out[k] = None
+            elif isinstance(a, str) and a == b:
+                out[k] = a
+            else:
+                return None
+        return out
+    if isinstance(c, (list, tuple)) and isinstance(u, (list, tuple)) and len(c) == len(u):
+        parts = [_cat_conds(a, b) for a, b in zip(c, u)]
+        return None if any(p is None for p in parts) else parts
+    return None
+
+
+class DDIMSampler(object):
+    def __init__(self, model, schedule="linear", **kwargs):
+        super().__init__()
+        self.model = model
+        self.ddpm_num_timesteps = model.num_timesteps
+        self.schedule = schedule
+        self.batch_cfg = True
+
+    def register_buffer(self, name, attr):
+        if isinstance(attr, torch.Tensor) and attr.device != self.model.device:
+            attr = attr.to(self.model.device)
+        setattr(self, name, attr)
+
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True):
+        self.ddim_timesteps = make_ddim_timesteps(ddim_discr_method=ddim_discretize, num_ddim_timesteps=ddim_num_steps,
+                                                  num_ddpm_timesteps=self.ddpm_num_timesteps, verbose=verbose)
+        alphas_cumprod = self.model.alphas_cumprod
+        assert alphas_cumprod.shape[0] == self.ddpm_num_timesteps, "alphas have to be defined for each timestep"
+        to_torch = lambda x: x.clone().detach().to(torch.float32).to(self.model.device)
+        self.register_buffer("betas", to_torch(self.model.betas))
+        self.register_buffer("alphas_cumprod", to_torch(alphas_cumprod))
+        self.register_buffer("alphas_cumprod_prev", to_torch(self.model.alphas_cumprod_prev))
+        ac = alphas_cumprod.cpu()
+        self.register_buffer("sqrt_alphas_cumprod", to_torch(np.sqrt(ac)))
+        self.register_buffer("sqrt_one_minus_alphas_cumprod", to_torch(np.sqrt(1. - ac)))
+        ddim_sigmas, ddim_alphas, ddim_alphas_prev = make_ddim_sampling_parameters(
+            alphacums=ac, ddim_timesteps=self.ddim_timesteps, eta=ddim_eta, verbose=verbose)
+        self.register_buffer("ddim_sigmas", ddim_sigmas)
+        self.register_buffer("ddim_alphas", ddim_alphas)
+        self.register_buffer("ddim_alphas_prev", ddim_alphas_prev)
+        self.register_buffer("ddim_sqrt_one_minus_alphas", np.sqrt(1. - ddim_alphas))
+        # device table for the fused update kernel: rows = ddim index, cols = {a_t, a_prev, sigma_t, sqrt(1-a_t)};
+        # each entry is the fp32 value torch.full(..., table[index]) produces in the reference (:203-211)
+        cols = [torch.as_tensor(np.asarray(v, dtype=np.float64) if not torch.is_tensor(v) else v.double().cpu().numpy())
+                for v in (ddim_alphas, ddim_alphas_prev, ddim_sigmas, np.sqrt(1. - ddim_alphas))]
+        self.coef_table = torch.stack([c.to(torch.float32) for c in cols], dim=1).contiguous().to(self.model.device)
+
+    @torch.no_grad()
+    def sample(self, S, batch_size, shape, conditioning=None, callback=None, normals_sequence=None, img_callback=None,
+               quantize_x0=False, eta=0., mask=None, x0=None, temperature=1., noise_dropout=0., score_corrector=None,
+               corrector_kwargs=None, verbose=True, x_T=None, log_every_t=100, unconditional_guidance_scale=1.,
+               unconditional_conditioning=None, dynamic_threshold=None, ucg_schedule=None, **kwargs):
+        self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
+        C, H, W = shape
+        size = (batch_size, C, H, W)
+        if verbose:
+            print(f"Data shape for DDIM sampling is {size}, eta {eta}")
+        return self.ddim_sampling(conditioning, size, callback=callback, img_callback=img_callback,
+                                  quantize_denoised=quantize_x0, mask=mask, x0=x0, ddim_use_original_steps=False,
+                                  noise_dropout=noise_dropout, temperature=temperature,
+                                  score_corrector=score_corrector, corrector_kwargs=corrector_kwargs, x_T=x_T,
+                                  log_every_t=log_every_t, unconditional_guidance_scale=unconditional_guidance_scale,
+                                  unconditional_conditioning=unconditional_conditioning,
+                                  dynamic_threshold=dynamic_threshold, ucg_schedule=ucg_schedule)
+
+    @torch.no_grad()
+    def ddim_sampling(self, cond, shape, x_T=None, ddim_use_original_steps=False, callback=None, timesteps=None,
+                      quantize_denoised=False, mask=None, x0=None, img_callback=None, log_every_t=100, temperature=1.,
+                      noise_dropout=0., score_corrector=None, corrector_kwargs=None, unconditional_guidance_scale=1.,
+                      unconditional_conditioning=None, dynamic_threshold=None, ucg_schedule=None):
+        if ddim_use_original_steps or quantize_denoised or score_corrector is not None or dynamic_threshold is not None:
+            raise NotImplementedError("option not used by the CtrLoRA sampling scripts")
+        device = self.model.betas.device
+        b = shape[0]
+        img = torch.randn(shape, device=device) if x_T is None else x_T.to(device).float()
+        if timesteps is None:
+            timesteps = self.ddim_timesteps
+        else:
+            subset_end = int(min(timesteps / self.ddim_timesteps.shape[0], 1) * self.ddim_timesteps.shape[0]) - 1
+            timesteps = self.ddim_timesteps[:subset_end]
+        intermediates = {"x_inter": [img], "pred_x0": [img]}
+        time_range = np.flip(timesteps)
+        total_steps = timesteps.shape[0]
+        eng = getattr(self.model, "engine", None)
+        if callable(eng):
+            # text context is constant over the loop: project K/V of every cross-attention once
+            self.model.engine().cache_context_kv = True
+            self.model.engine().reset_context_cache()
+        try:
+            for i, step in enumerate(time_range):
+                index = total_steps - i - 1
+                ts = torch.full((b,), int(step), device=device, dtype=torch.long)
+                if mask is not None:
+                    assert x0 is not None
+                    img = self.model.q_sample(x0, ts) * mask + (1. - mask) * img
+                if ucg_schedule is not None:
+                    assert len(ucg_schedule) == len(time_range)
+                    unconditional_guidance_scale = ucg_schedule[i]
+                img, pred_x0 = self.p_sample_ddim(img, cond, ts, index=index, temperature=temperature,
+                                                  noise_dropout=noise_dropout,
+                                                  unconditional_guidance_scale=unconditional_guidance_scale,
+                                                  unconditional_conditioning=unconditional_conditioning)
+                if callback:
+                    callback(i)
+                if img_callback:
+                    img_callback(pred_x0, i)
+                if index % log_every_t == 0 or index == total_steps - 1:
+                    intermediates["x_inter"].append(img)
+                    intermediates["pred_x0"].append(pred_x0)
+        finally:
+            if callable(eng):
+                self.model.engine().cache_context_kv = False
+                self.model.engine().reset_context_cache()
+        return img, intermediates
+
+    @torch.no_grad()
+    def p_sample_ddim(self, x, c, t, index, repeat_noise=False, use_original_steps=False, quantize_denoised=False,
+                      temperature=1., noise_dropout=0., score_corrector=None, corrector_kwargs=None,
+                      unconditional_guidance_scale=1., unconditional_conditioning=None, dynamic_threshold=None):
+        from ctrlora_amd import hip
+        b, device = x.shape[0], x.device
+        e_u = None
+        if unconditional_conditioning is None or unconditional_guidance_scale == 1.:
+            e_c = self.model.apply_model(x, t, c)
+        else:
+            both = _cat_conds(c, unconditional_conditioning) if self.batch_cfg else None
+            if both is not None:
+                e = self.model.apply_model(torch.cat([x, x], 0), torch.cat([t, t], 0), both)
+                e_c, e_u = e[:b].contiguous(), e[b:].contiguous()
+            else:
+                e_c = self.model.apply_model(x, t, c)
+                e_u = self.model.apply_model(x, t, unconditional_conditioning)
+        if self.model.parameterization != "eps":
+            raise NotImplementedError("v-parameterisation is not used by the CtrLoRA configs")
+        sigma_nonzero = float(self.coef_table[index, 2]) != 0.0 if noise_dropout > 0. else True
+        # the reference draws randn for the sigma*noise term every step, also when sigma == 0 (:227)
+        noise = noise_like(x.shape, device, repeat_noise) * temperature
+        if noise_dropout > 0. and sigma_nonzero:
+            noise = torch.nn.functional.dropout(noise, p=noise_dropout)
+        x = x.float().contiguous()
+        x_prev, pred_x0 = torch.empty_like(x), torch.empty_like(x)
+        hip.ddim_step(x, e_c.float().contiguous(), None if e_u is None else e_u.float().contiguous(), noise.contiguous(),
+                      self.coef_table, index, float(unconditional_guidance_scale), x_prev, pred_x0)
+        return x_prev, pred_x0

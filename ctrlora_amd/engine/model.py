@@ -30,6 +30,40 @@ class CtrLoRAEngine:
         self.cache_context_kv = False
         self._kv: Optional[dict] = None
 
+    @classmethod
+    def from_executors(cls, unet: UNetE, controls: Sequence[ControlNetE]) -> "CtrLoRAEngine":
+        """Compose already-built executors (the cldm.* modules build and own theirs lazily)."""
+        hip.lib()
+        self = cls.__new__(cls)
+        self.cfg, self.dtype, self.device = unet.cfg, unet.dtype, unet.device
+        self.unet, self.controls = unet, list(controls)
+        self._rec, self.cache_context_kv, self._kv = None, False, None
+        return self
+
+    @torch.no_grad()
+    def forward_external_control(self, x_noisy, t, context, control: Optional[list], only_mid_control=False):
+        """ControlledUnetModel.forward with caller-supplied NCHW residuals (cldm/cldm.py:22-45); like the
+        reference it consumes `control` with pop()."""
+        B, _, H, W = x_noisy.shape
+        ctx = Ctx(self.dtype, self.device, False)
+        t = t.to(device=self.device, dtype=torch.long).contiguous()
+        c = self._ctx_in(context)
+        semb, hs, dims, h_mid = self.unet.encode(ctx, self._tok_in(x_noisy), t, c, B, H, W)
+        bufs = self.unet.alloc_decoder_inputs(ctx, B, dims)
+        self.unet.fill_without_control(ctx, bufs, hs, h_mid)
+        if control is not None:
+            sinks = self.unet.control_sinks(bufs, hs, h_mid)
+            mid = control.pop()
+            hip.axpby(self._tok_in(mid)[:, :sinks[-1][0].shape[1]], sinks[-1][0], 1.0, 1.0)
+            for k in range(len(sinks) - 2, -1, -1):
+                if only_mid_control:
+                    break
+                ck = control.pop()
+                hip.axpby(self._tok_in(ck)[:, :sinks[k][0].shape[1]], sinks[k][0], 1.0, 1.0)
+        eps_tok, _ = self.unet.decode(ctx, bufs, semb, c, B, dims[-1])
+        eps = torch.empty((B, self.cfg.out_channels, H, W), dtype=torch.float32, device=self.device)
+        return hip.tok_to_nchw(eps_tok, eps)
+
     # ---------------------------------------------------------------- boundary conversions
     def _tok_in(self, x_nchw: torch.Tensor) -> torch.Tensor:
         B, C, H, W = x_nchw.shape

@@ -1,0 +1,105 @@
+"""Drop-in boundary: the cldm / ldm mirror builds from configs/*.yaml with the
+reference's class paths and produces exactly the reference's state-dict keys and shapes
+(tests/golden/keys_*.json were dumped from the unmodified reference modules)."""
+import json
+import os
+
+import pytest
+import torch
+import yaml
+
+from tests.util import GOLDEN, ROOT
+
+
+def _cfg(name):
+    with open(os.path.join(ROOT, "configs", name)) as f:
+        return yaml.safe_load(f)
+
+
+def _tiny(params, rank=32):
+    p = dict(params)
+    p.update(model_channels=64, context_dim=96)
+    if "lora_rank" in p:
+        p["lora_rank"] = rank
+    return p
+
+
+def test_yaml_targets_resolve_and_keys_match_reference_tiny():
+    from ldm.util import instantiate_from_config
+    cfg = _cfg("ctrlora_finetune_sd15_rank128.yaml")["model"]["params"]
+    cn_cfg = dict(cfg["control_stage_config"]); cn_cfg["params"] = _tiny(cn_cfg["params"])
+    un_cfg = dict(cfg["unet_config"]); un_cfg["params"] = _tiny(un_cfg["params"])
+    cn = instantiate_from_config(cn_cfg)
+    un = instantiate_from_config(un_cfg)
+    keys = json.load(open(os.path.join(GOLDEN, "keys_tiny.json")))
+    assert {k: list(v.shape) for k, v in cn.state_dict().items()} == keys["controlnet"]
+    assert {k: list(v.shape) for k, v in un.state_dict().items()} == keys["unet"]
+    assert type(cn).__module__ == "cldm.cldm_ctrlora_finetune" and type(un).__module__ == "cldm.cldm"
+
+
+def test_full_ldm_builds_from_yaml_with_identity_encoders():
+    from ldm.util import instantiate_from_config
+    cfg = _cfg("ctrlora_finetune_sd15_rank32.yaml")["model"]
+    p = cfg["params"]
+    p["control_stage_config"]["params"] = _tiny(p["control_stage_config"]["params"])
+    p["unet_config"]["params"] = _tiny(p["unet_config"]["params"])
+    p["first_stage_config"] = {"target": "torch.nn.Identity"}
+    p["cond_stage_config"] = {"target": "torch.nn.Identity"}
+    model = instantiate_from_config(cfg)
+    assert model.control_scales == [1.0] * 13 and model.num_timesteps == 1000
+    names = model.trainable_names()
+    assert len(names) == 246
+    g = torch.load(os.path.join(GOLDEN, "model_tiny.pt"), weights_only=False)
+    assert sorted(names) == sorted(g["trainable_names"])
+    # schedule buffers bit-exact with the reference's DDPM.register_schedule
+    s = torch.load(os.path.join(GOLDEN, "schedule.pt"), weights_only=False)["ddpm"]
+    for k, v in s.items():
+        assert torch.equal(getattr(model, k), v), k
+
+
+def test_vae_and_clip_targets_import():
+    from ldm.util import get_obj_from_str
+    cfg = _cfg("ctrlora_finetune_sd15_rank128.yaml")["model"]["params"]
+    vae = get_obj_from_str(cfg["first_stage_config"]["target"])(**cfg["first_stage_config"]["params"])
+    n = sum(p.numel() for p in vae.encoder.parameters())
+    assert abs(n - 34.16e6) < 0.1e6          # VAE encoder 34.2 M params
+    z = vae.encode(torch.zeros(1, 3, 64, 64)).mode()
+    assert z.shape == (1, 4, 8, 8)
+    assert get_obj_from_str(cfg["cond_stage_config"]["target"]).__name__ == "FrozenCLIPEmbedder"
+
+
+@pytest.mark.parametrize("name", ["inference/ctrlora_sd15_rank128_2loras.yaml", "ctrlora_pretrain_sd15_9tasks_rank128.yaml"])
+def test_inference_and_pretrain_trees(name):
+    from ldm.util import instantiate_from_config
+    cs = _cfg(name)["model"]["params"]["control_stage_config"]
+    cs["params"] = _tiny(cs["params"])
+    if "tasks" in cs["params"]:
+        cs["params"]["tasks"] = ["hed", "canny"]
+    cn = instantiate_from_config(cs)
+    n0 = len(cn.state_dict())
+    if "tasks" in cs["params"]:
+        assert n0 == 652                     # 652 -> 816 keys after switch_lora (2 tasks)
+        cn.switch_lora("canny")
+        assert len(cn.state_dict()) == 816
+        with pytest.raises(AssertionError):
+            cn.switch_lora("nope")
+    else:
+        assert n0 == 816                     # lora_num = 2: 816 -> 1062 after switch_lora(0)
+        cn.switch_lora(0)
+        assert len(cn.state_dict()) == 1062
+        sd = cn.bank_state(1)
+        keys = json.load(open(os.path.join(GOLDEN, "keys_tiny.json")))["controlnet"]
+        assert {k: list(v.shape) for k, v in sd.items()} == keys
+
+
+def test_lora_fuse_unfuse_roundtrip_cpu():
+    from cldm.lora import LoRACompatibleLinear, LoRALinearLayer
+    g = torch.load(os.path.join(GOLDEN, "lora.pt"), weights_only=False)
+    lin = LoRACompatibleLinear(96, 64, lora_layer=LoRALinearLayer(96, 64, rank=32))
+    lin.load_state_dict(g["state"])
+    w0 = lin.weight.data.clone()
+    lin._fuse_lora()
+    assert lin.lora_layer is None
+    assert float((lin.weight.data - g["w_fused"]).abs().max()) < 1e-6
+    lin._unfuse_lora()
+    assert float((lin.weight.data - w0).abs().max()) < 1e-6
