@@ -129,12 +129,13 @@ class ControlLDM(LatentDiffusion):
         for ex, owner in zip(self.engine().controls, self._executor_owners()):
             bound = owner.__dict__.get("_bound")
             if bound:
+                if bound[0].grad is None or bound[-1].grad is None:
+                    # a foreign optimizer ran zero_grad(set_to_none=True): gradients were cleared -> re-attach
+                    ex.tr.flat_grad.zero_()
+                    for p, t in zip(bound, ex.tr.items):
+                        p.grad = t.grad
                 ver = trainables_version(bound)
                 if owner.__dict__.get("_bound_version") != ver:
-                    for p, t in zip(bound, ex.tr.items):       # optimizer.zero_grad(set_to_none=True) detaches .grad
-                        if p.grad is None or p.grad.data_ptr() != t.grad.data_ptr():
-                            t.grad.zero_()
-                            p.grad = t.grad
                     ex.repack()
                     owner.__dict__["_bound_version"] = ver
 

@@ -1,0 +1,67 @@
+"""Data-parallel LoRA fine-tuning: one process per GPU, RCCL (torch.distributed backend "nccl" on ROCm)
+over xGMI, all-reduce on the optimizer's gradient subset ONLY.
+
+The reference trains through Lightning DDP, which all-reduces every parameter that received a gradient
+(~3.5 GB fp32 per step incl. 0.5 G dead UNet-decoder weight gradients).  Here the trainable
+gradients live in one flat fp32 buffer per ControlNet (148 MB for rank 128) laid out in backward-completion
+order, so the exchange is a handful of large contiguous all-reduces launched while the remaining backward is
+still running (the ControlNet backward calls `on_stage_done(start, end)` after each encoder stage).
+Averaging is folded into the optimizer (grad_scale = 1 / world_size).
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.distributed as dist
+
+
+class GradAllReduce:
+    def __init__(self, executors, group=None, bucket_bytes: int = 32 << 20, overlap: bool = True):
+        self.group = group
+        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.bucket_elems = max(1, bucket_bytes // 4)
+        self.overlap = overlap
+        self.enabled = True          # set False on non-final gradient-accumulation micro-steps
+        self.executors = list(executors)
+        self._pending: List = []
+        self._lo = {id(ex): 0 for ex in self.executors}
+        self._hi = {id(ex): 0 for ex in self.executors}
+        self.launched_bytes = 0
+        self.launches = 0
+        for ex in self.executors:
+            ex.on_stage_done = (lambda s, e, ex=ex: self._stage_done(ex, s, e))
+
+    def _launch(self, ex, lo, hi):
+        if hi <= lo or self.world_size == 1:
+            return
+        buf = ex.tr.flat_grad[lo:hi]
+        self._pending.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.launched_bytes += (hi - lo) * 4
+        self.launches += 1
+
+    def _stage_done(self, ex, start, end):
+        if not self.enabled:
+            return
+        k = id(ex)
+        # stages complete in increasing offset order; anything else falls back to the final flush
+        if start == self._hi[k]:
+            self._hi[k] = end
+            if self.overlap and self._hi[k] - self._lo[k] >= self.bucket_elems:
+                self._launch(ex, self._lo[k], self._hi[k])
+                self._lo[k] = self._hi[k]
+
+    def on_backward_done(self):
+        """Called at the end of the engine backward: flush what has not been launched yet."""
+        if not self.enabled:
+            return
+        for ex in self.executors:
+            k = id(ex)
+            self._launch(ex, self._lo[k], ex.tr.numel)
+            self._lo[k] = self._hi[k] = 0
+
+    def wait(self):
+        """Before the optimizer step: the current stream waits for every outstanding all-reduce."""
+        for w in self._pending:
+            w.wait()
+        self._pending.clear()
