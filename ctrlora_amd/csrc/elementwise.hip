@@ -267,24 +267,38 @@ __global__ void pool2x2_kernel(const T* __restrict__ in, long ldi, T* __restrict
 template <typename T>
 __global__ void colsum_kernel(const T* __restrict__ in, long ldi, float* __restrict__ out, long ldo, int HW, int C,
                               int ppc, float scale) {
+  __shared__ float red[256 * 8];
   const int C8 = C / 8;
   const int b = blockIdx.y, p0 = blockIdx.x * ppc, p1 = min(HW, p0 + ppc);
   const int VX = blockDim.x < C8 ? blockDim.x : C8;
   const int PY = blockDim.x / VX;
   const int vx = threadIdx.x % VX, py = threadIdx.x / VX;
-  if (py >= PY) return;
-  for (int v = vx; v < C8; v += VX) {
+  const bool live = py < PY;
+  // uniform trip count (C8 <= VX, or C8 a multiple of VX is NOT required: guard inside)
+  for (int v0 = 0; v0 < C8; v0 += VX) {
+    const int v = v0 + vx;
     float s[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = 0.f;
-    for (int p = p0 + py; p < p1; p += PY) {
-      float f[8];
-      load8(in + ((long)b * HW + p) * ldi + v * 8, f);
+    if (live && v < C8) {
+      for (int p = p0 + py; p < p1; p += PY) {
+        float f[8];
+        load8(in + ((long)b * HW + p) * ldi + v * 8, f);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s[e] += f[e];
+        for (int e = 0; e < 8; ++e) s[e] += f[e];
+      }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(out + (long)b * ldo + v * 8 + e, s[e] * scale);
+    for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = s[e];
+    __syncthreads();
+    if (py == 0 && v < C8) {
+      for (int k = 1; k < PY; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += red[(k * VX + vx) * 8 + e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) atomicAdd(out + (long)b * ldo + v * 8 + e, s[e] * scale);
+    }
+    __syncthreads();
   }
 }
 

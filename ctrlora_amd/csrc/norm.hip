@@ -81,40 +81,34 @@ __global__ void gn_partial_kernel(const T* __restrict__ x, long ldx, int HW, int
   }
 }
 
-// one block per batch sample: per-(b,group) mean/rstd and per-(b,channel) scale/shift
+// per-(b,group) mean/rstd and per-(b,channel) scale/shift
 __global__ void gn_finalize_kernel(const float* __restrict__ partial, int nchunk, int HW, int C, int G,
                                    float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ stats /*[B][G][2]*/, float* __restrict__ coef /*[B][C][2]*/) {
-  extern __shared__ double sm[];  // [C][2] then [G][2]
-  double* cs = sm; double* gs = sm + 2 * C;
-  const int b = blockIdx.x, cg = C / G;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    double s = 0, q = 0;
-    for (int k = 0; k < nchunk; ++k) {
-      const float* p = partial + (((long)b * nchunk + k) * C + c) * 2;
-      s += p[0]; q += p[1];
-    }
-    cs[2 * c] = s; cs[2 * c + 1] = q;
+  // one wave per (sample, group): lanes sweep the group's (chunk, channel) partials, coalesced
+  const int g = blockIdx.x, b = blockIdx.y, cg = C / G, lane = threadIdx.x;
+  double s = 0, q = 0;
+  const int total = nchunk * cg;
+  for (int i = lane; i < total; i += 64) {
+    const int k = i / cg, c = g * cg + (i - k * cg);
+    const float2 p = *reinterpret_cast<const float2*>(partial + (((long)b * nchunk + k) * C + c) * 2);
+    s += p.x; q += p.y;
   }
-  __syncthreads();
-  for (int g = threadIdx.x; g < G; g += blockDim.x) {
-    double s = 0, q = 0;
-    for (int c = g * cg; c < (g + 1) * cg; ++c) { s += cs[2 * c]; q += cs[2 * c + 1]; }
-    const double n = (double)HW * cg;
-    const double mean = s / n;
-    double var = q / n - mean * mean;
-    if (var < 0) var = 0;
-    const double rstd = 1.0 / sqrt(var + (double)eps);
-    gs[2 * g] = mean; gs[2 * g + 1] = rstd;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+  const double n = (double)HW * cg;
+  const double mean = s / n;
+  double var = q / n - mean * mean;
+  if (var < 0) var = 0;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  if (lane == 0) {
     stats[((long)b * G + g) * 2] = (float)mean;
     stats[((long)b * G + g) * 2 + 1] = (float)rstd;
   }
-  __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const int g = c / cg;
-    const double sc = gs[2 * g + 1] * (double)gamma[c];
+  for (int c = g * cg + lane; c < (g + 1) * cg; c += 64) {
+    const double sc = rstd * (double)gamma[c];
     coef[((long)b * C + c) * 2] = (float)sc;
-    coef[((long)b * C + c) * 2 + 1] = (float)((double)beta[c] - gs[2 * g] * sc);
+    coef[((long)b * C + c) * 2 + 1] = (float)((double)beta[c] - mean * sc);
   }
 }
 
@@ -152,7 +146,7 @@ static int gn_fwd_t(const GnArgs& a, hipStream_t st) {
   dim3 grid(g.nchunk, a.B);
   hipLaunchKernelGGL((gn_partial_kernel<T>), grid, dim3(g.threads), g.threads * 64, st,
                      (const T*)a.x, a.ldx, a.HW, a.C, g.VX, g.PY, g.ppc, g.nchunk, partial);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.B), dim3(256), (2 * a.C + 2 * a.G) * sizeof(double), st,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.G, a.B), dim3(64), 0, st,
                      partial, g.nchunk, a.HW, a.C, a.G, a.eps, a.gamma, a.beta, a.stats, coef);
   if (a.silu)
     hipLaunchKernelGGL((gn_apply_kernel<T, true>), grid, dim3(g.threads), 0, st,
@@ -227,31 +221,26 @@ __global__ void gn_bwd_finalize_kernel(const float* __restrict__ partial, int nc
                                        const float* __restrict__ gamma, const float* __restrict__ stats,
                                        float* __restrict__ bcoef /*[B][C][4]: k1,k2,k3,_*/,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  extern __shared__ double sm[];
-  double* cs = sm; double* gs = sm + 2 * C;
-  const int b = blockIdx.x, cg = C / G;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  // one wave per (sample, group); lane = channel within the group (two rounds when cg > 64)
+  const int g = blockIdx.x, b = blockIdx.y, cg = C / G, lane = threadIdx.x;
+  double s1 = 0, s2 = 0;
+  for (int c = g * cg + lane; c < (g + 1) * cg; c += 64) {
     double s = 0, q = 0;
     for (int k = 0; k < nchunk; ++k) {
-      const float* p = partial + (((long)b * nchunk + k) * C + c) * 2;
-      s += p[0]; q += p[1];
+      const float2 p = *reinterpret_cast<const float2*>(partial + (((long)b * nchunk + k) * C + c) * 2);
+      s += p.x; q += p.y;
     }
-    cs[2 * c] = s; cs[2 * c + 1] = q;
     if (dgamma) { atomicAdd(dgamma + c, (float)q); atomicAdd(dbeta + c, (float)s); }
+    s1 += gamma[c] * s; s2 += gamma[c] * q;
   }
-  __syncthreads();
-  for (int g = threadIdx.x; g < G; g += blockDim.x) {
-    double s1 = 0, s2 = 0;
-    for (int c = g * cg; c < (g + 1) * cg; ++c) { s1 += gamma[c] * cs[2 * c]; s2 += gamma[c] * cs[2 * c + 1]; }
-    const double n = (double)HW * cg;
-    gs[2 * g] = s1 / n; gs[2 * g + 1] = s2 / n;
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const int g = c / cg;
-    const double rstd = stats[((long)b * G + g) * 2 + 1];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+  const double n = (double)HW * cg;
+  const double rstd = stats[((long)b * G + g) * 2 + 1];
+  const float k2 = (float)(rstd * s1 / n), k3 = (float)(rstd * s2 / n);
+  for (int c = g * cg + lane; c < (g + 1) * cg; c += 64) {
     float* o = bcoef + ((long)b * C + c) * 4;
-    o[0] = (float)(rstd * gamma[c]); o[1] = (float)(rstd * gs[2 * g]); o[2] = (float)(rstd * gs[2 * g + 1]); o[3] = 0.f;
+    o[0] = (float)(rstd * gamma[c]); o[1] = k2; o[2] = k3; o[3] = 0.f;
   }
 }
 
@@ -305,7 +294,7 @@ static int gn_bwd_t(const GnBwdArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((gn_bwd_partial_kernel<T, S>), grid, dim3(g.threads), g.threads * 64, st, (const T*)a.x,   \
                      a.ldx, (const T*)a.dy, a.lddy, a.HW, a.C, a.G, g.VX, g.PY, g.ppc, g.nchunk, a.gamma,       \
                      a.beta, a.stats, partial);                                                                \
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(a.B), dim3(256), (2 * a.C + 2 * a.G) * sizeof(double), st,    \
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(a.G, a.B), dim3(64), 0, st,                                    \
                      partial, g.nchunk, a.HW, a.C, a.G, a.gamma, a.stats, bcoef, a.dgamma, a.dbeta);            \
   hipLaunchKernelGGL((gn_bwd_apply_kernel<T, S>), grid, dim3(g.threads), 0, st, (const T*)a.x, a.ldx,           \
                      (const T*)a.dy, a.lddy, (const T*)a.accum, a.ldacc, (T*)a.dx, a.lddx, a.HW, a.C, a.G,      \
@@ -326,7 +315,7 @@ int gn_bwd(const GnBwdArgs& a, int dtype, hipStream_t st) {
 
 // ------------------------------------------------------------------ LayerNorm
 
-static constexpr int LN_MAXV = 4;  // vectors of 8 per lane -> D <= 2048
+static constexpr int LN_MAXV = 3;  // vectors of 8 per lane -> D <= 1536 (SD1.5: 320 / 640 / 1280)
 
 template <typename T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y,
@@ -374,25 +363,38 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, lo
 }
 
 // dx = rstd * (dyh - mean(dyh) - xh * mean(dyh * xh)),  dyh = dy * gamma ; optional (+ accum)
-// dgamma += sum_rows dy * xh ; dbeta += sum_rows dy   (fp32 atomics, one per column per block)
-template <typename T>
+// WG: dgamma += sum_rows dy * xh ; dbeta += sum_rows dy  (per-lane column sums -> LDS across the 4 waves
+// -> one fp32 atomic per column per workgroup)
+template <typename T, bool WG>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy,
                                                      long lddy, const T* __restrict__ accum, long ldacc,
                                                      T* __restrict__ dx, long lddx, int M, int D,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ stats,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float red[WG ? 2 * LN_MAXV * 512 : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int D8 = D / 8;
-  float gsum[LN_MAXV][8], bsum[LN_MAXV][8];
+  float gsum[WG ? LN_MAXV : 1][8], bsum[WG ? LN_MAXV : 1][8];
+  if (WG) {
 #pragma unroll
-  for (int k = 0; k < LN_MAXV; ++k)
+    for (int k = 0; k < LN_MAXV; ++k)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { gsum[k][e] = 0.f; bsum[k][e] = 0.f; }
+      for (int e = 0; e < 8; ++e) { gsum[k][e] = 0.f; bsum[k][e] = 0.f; }
+    for (int i = threadIdx.x; i < 2 * LN_MAXV * 512; i += 256) red[i] = 0.f;
+  }
+  float gam[LN_MAXV][8];
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    const int v = lane + 64 * k;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gam[k][e] = v < D8 ? gamma[v * 8 + e] : 0.f;
+  }
   for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
     const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
-    float xh[LN_MAXV][8], dh[LN_MAXV][8];
     float c1 = 0.f, c2 = 0.f;
+    // pass 1: row statistics of dyh (+ column sums); pass 2 re-reads the row (L1/L2 resident) to keep
+    // the register footprint small enough for >= 3 waves per SIMD
 #pragma unroll
     for (int k = 0; k < LN_MAXV; ++k) {
       const int v = lane + 64 * k;
@@ -402,11 +404,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, lo
         load8(dy + row * lddy + v * 8, d);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          xh[k][e] = (f[e] - mean) * rstd;
-          gsum[k][e] += d[e] * xh[k][e];
-          bsum[k][e] += d[e];
-          dh[k][e] = d[e] * gamma[v * 8 + e];
-          c1 += dh[k][e]; c2 += dh[k][e] * xh[k][e];
+          const float xh = (f[e] - mean) * rstd;
+          if (WG) { gsum[k][e] += d[e] * xh; bsum[k][e] += d[e]; }
+          const float dh = d[e] * gam[k][e];
+          c1 += dh; c2 += dh * xh;
         }
       }
     }
@@ -415,36 +416,44 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, lo
     for (int k = 0; k < LN_MAXV; ++k) {
       const int v = lane + 64 * k;
       if (v < D8) {
-        float o[8];
+        float f[8], d[8], o[8];
+        load8(x + row * ldx + v * 8, f);
+        load8(dy + row * lddy + v * 8, d);
         if (accum) load8(accum + row * ldacc + v * 8, o);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float r = rstd * (dh[k][e] - c1 - xh[k][e] * c2);
+          const float xh = (f[e] - mean) * rstd;
+          const float r = rstd * (d[e] * gam[k][e] - c1 - xh * c2);
           o[e] = accum ? o[e] + r : r;
         }
         store8(dx + row * lddx + v * 8, o);
       }
     }
   }
-  if (dgamma) {
-    // one atomic per column per wave (grid is capped, so this stays cheap)
+  if (WG) {
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < LN_MAXV; ++k) {
       const int v = lane + 64 * k;
       if (v < D8) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          atomicAdd(dgamma + v * 8 + e, gsum[k][e]);
-          atomicAdd(dbeta + v * 8 + e, bsum[k][e]);
+          atomicAdd(&red[v * 8 + e], gsum[k][e]);
+          atomicAdd(&red[LN_MAXV * 512 + v * 8 + e], bsum[k][e]);
         }
       }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+      atomicAdd(dgamma + c, red[c]);
+      atomicAdd(dbeta + c, red[LN_MAXV * 512 + c]);
     }
   }
 }
 
 static int ln_grid(int M) {
   int g = (M + 3) / 4;
-  return g < 1024 ? g : 1024;
+  return g < 2048 ? g : 2048;
 }
 
 int ln_fwd(const LnArgs& a, int dtype, hipStream_t st) {
@@ -462,16 +471,16 @@ int ln_fwd(const LnArgs& a, int dtype, hipStream_t st) {
 int ln_bwd(const LnBwdArgs& a, int dtype, hipStream_t st) {
   if (a.D % 8 || a.D > 64 * LN_MAXV * 8 || a.ldx % 8 || a.lddy % 8 || a.lddx % 8) return CL_EINVAL;
   if ((a.dgamma == nullptr) != (a.dbeta == nullptr)) return CL_EINVAL;
-  int grid = ln_grid(a.M);
-  if (a.dgamma && grid > 256) grid = 256;  // fewer, longer blocks: fewer dgamma atomics
-  if (dtype == CL_BF16)
-    hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)a.x, a.ldx,
-                       (const bf16_t*)a.dy, a.lddy, (const bf16_t*)a.accum, a.ldacc, (bf16_t*)a.dx, a.lddx, a.M,
-                       a.D, a.gamma, a.stats, a.dgamma, a.dbeta);
-  else
-    hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)a.x, a.ldx,
-                       (const float*)a.dy, a.lddy, (const float*)a.accum, a.ldacc, (float*)a.dx, a.lddx, a.M, a.D,
-                       a.gamma, a.stats, a.dgamma, a.dbeta);
+  int grid = (a.M + 3) / 4;
+  if (grid > 2048) grid = 2048;
+  if (a.dgamma && grid > 512) grid = 512;  // bounds the same-address atomics per column
+#define LN_BWD_LAUNCH(TT, WG)                                                                                   \
+  hipLaunchKernelGGL((ln_bwd_kernel<TT, WG>), dim3(grid), dim3(256), 0, st, (const TT*)a.x, a.ldx,             \
+                     (const TT*)a.dy, a.lddy, (const TT*)a.accum, a.ldacc, (TT*)a.dx, a.lddx, a.M, a.D, a.gamma, \
+                     a.stats, a.dgamma, a.dbeta)
+  if (dtype == CL_BF16) { if (a.dgamma) LN_BWD_LAUNCH(bf16_t, true); else LN_BWD_LAUNCH(bf16_t, false); }
+  else { if (a.dgamma) LN_BWD_LAUNCH(float, true); else LN_BWD_LAUNCH(float, false); }
+#undef LN_BWD_LAUNCH
   CL_CHECK_LAUNCH();
   return CL_OK;
 }
