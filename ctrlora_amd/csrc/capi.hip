@@ -18,7 +18,14 @@ static GemmParams base_params() {
 
 extern "C" {
 
-int cl_abi_version(void) { return 1; }
+int cl_abi_version(void) { return 2; }
+
+int cl_set_workspace(void* ptr, long bytes) {
+  if (bytes < 0 || (bytes > 0 && !ptr) || (reinterpret_cast<uintptr_t>(ptr) & 15)) return CL_EINVAL;
+  gemm_set_workspace(ptr, bytes);
+  return CL_OK;
+}
+int cl_gemm_force_config(int cfg) { g_gemm_force_cfg = cfg; return CL_OK; }
 
 int cl_gemm(const cl_gemm_params* p, int dtype, void* stream) {
   if (!p) return CL_EINVAL;

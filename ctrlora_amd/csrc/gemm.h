@@ -32,10 +32,14 @@ struct GemmParams {
   int act;
   void* C; long ldc;
   int out_f32;                         // store fp32 regardless of T
-  int atomic;                          // fp32 atomicAdd into C (split-K / grad accumulation)
-  int splitk;                          // >= 1
+  int atomic;                          // fp32 atomicAdd into C (grad accumulation; caller may set splitk)
+  int splitk;                          // atomic mode: K splits.  Otherwise chosen by the launcher (workspace slabs)
 };
 
 int launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);
+// Device scratch for the deterministic split-K path (fp32 partial slabs).  Owned by the host;
+// one workspace per process, used stream-ordered by whichever stream launches the GEMM.
+void gemm_set_workspace(void* p, long bytes);
+extern int g_gemm_force_cfg;   // tuning/probe hook (tile configuration override), -1 = heuristic
 
 }  // namespace cl

@@ -2,7 +2,7 @@
 //
 //   out[M,N] = epilogue( A1[M,K1].W1[N,K1]^T  (+ A2[M,K2].W2[N,K2]^T) )
 //
-// One kernel serves every dense contraction on the CtrLoRA hot path:
+// One kernel family serves every dense contraction on the CtrLoRA hot path:
 //   * nn.Linear / LoRACompatibleLinear  (cldm/lora.py:285-291): the rank-r
 //     LoRA up-projection is folded in as a second K segment
 //     ([x | xA^T] . [W | B]^T), fp32-accumulated in the same MFMA chain;
@@ -15,171 +15,105 @@
 //     (openaimodel.py:272) or skip add (:274) in the epilogue;
 //   * all data-gradients (same kernel, pre-transposed / tap-flipped weights).
 //
-// Structure: 256 threads = 4 wave64 in a 2x2 grid, BMxBN output tile, 64-byte
-// K steps (32 bf16 / 16 f32), operands staged HBM->LDS with
-// global_load_lds_dwordx4 (no VGPR round trip), double buffered, one barrier
-// per K step.  Fragments are read with ds_read_b128 and fed to
-// v_mfma_f32_16x16x32_bf16 (or 4x v_mfma_f32_16x16x4_f32 in parity mode).
-// The accumulator tile is staged through LDS so the epilogue reads residuals
-// and writes outputs as whole 16-byte vectors.
+// Structure (per workgroup): NW wave64s in a WGM x WGN grid over a BM x BN
+// output tile.  K is walked in 64-byte "substeps" (32 bf16 / 16 f32 per row):
+// a substep's A and B rows are staged HBM->LDS by global_load_lds_dwordx4 (no
+// VGPR round trip) into one slot of an R-slot LDS ring; a slot is a stack of
+// 16-row x 64-byte groups (1 KiB = one wave-wide DMA instruction), which is
+// conflict-free for the ds_read_b128 fragment reads of v_mfma_f32_16x16x32_bf16
+// (or 4x v_mfma_f32_16x16x4_f32 in fp32 parity mode).  Each loop iteration
+// consumes KSUB substeps behind ONE raw s_barrier and a COUNTED s_waitcnt
+// vmcnt, so R-KSUB substeps of DMA stay in flight across the barrier while
+// the MFMAs run.  BN = 160 tiles exist because every wide channel count of
+// SD1.5 (320/640/960/1280/1920/2560) is a multiple of 160: no N-padding waste
+// and workgroup counts that are multiples of the 256 CUs at the hot shapes.
+//
+// Deep-K / small-MN products (the 8x8 and 16x16 levels: K = 9*1280..9*2560,
+// M = B*64 .. B*256) are split along K: each split writes an fp32 partial slab
+// into the host-provided workspace and a second kernel sums the slabs and
+// applies the epilogue -- deterministic, unlike atomics.  (fp32 atomics remain
+// for the weight-gradient accumulation into the flat gradient buffer.)
+//
+// Workgroup ids are remapped so that each XCD (private L2) owns a contiguous
+// range of output tiles: neighbouring tiles share A rows / conv halos.
 #include "gemm.h"
 #include "mma.h"
 
 namespace cl {
 
-template <typename T, int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
-  constexpr int KPB = 64 / (int)sizeof(T);  // elements per 64-byte K step
-  constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
-  constexpr int AJ = BM / 64, BJ = BN / 64;  // glds instructions per wave per tile
-  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
-  constexpr int EST = WN + 4;                // padded fp32 row stride of the epilogue staging
-  constexpr int EPI_BYTES = 4 * 32 * EST * 4;
-  constexpr int SMEM = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
-  static_assert(FM % 2 == 0 || FM == 1, "FM");
-  __shared__ __attribute__((aligned(16))) char smem[SMEM];
+static void* g_ws = nullptr;
+static long g_ws_bytes = 0;
+void gemm_set_workspace(void* p, long bytes) { g_ws = p; g_ws_bytes = bytes; }
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+template <int N> __device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
-  const int taps = (p.mode == GEMM_LINEAR) ? 1 : 9;
-  const int cpt = p.K1 / KPB;  // K steps per tap
-  const int ks1 = taps * cpt;
-  const int ks2 = p.K2 / KPB;
-  int kbeg = 0, kend = ks1 + ks2;
-  if (gridDim.z > 1) {
-    const int per = (kend + gridDim.z - 1) / gridDim.z;
-    kbeg = blockIdx.z * per;
-    kend = min(kend, kbeg + per);
-    if (kbeg >= kend) return;
+struct EpiArgs {
+  const float* bias; const void* rowbias; long ldrb; int rows_per_batch;
+  const void* residual; long ldr; float alpha, beta; int act;
+  void* C; long ldc; int out_f32; int atomic; int M, N;
+};
+
+// apply the epilogue to 8 consecutive columns of one row and store
+template <typename T>
+__device__ __forceinline__ void epilogue8(const EpiArgs& e, float v[8], int grow, int gcol) {
+  if (e.bias) {
+    const float4 b0 = *reinterpret_cast<const float4*>(e.bias + gcol);
+    const float4 b1 = *reinterpret_cast<const float4*>(e.bias + gcol + 4);
+    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+    v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
   }
-
-  // ---- per-lane source rows (fixed across the K loop) ----
-  const int lrow = lane >> 2;          // row within a 16-row glds group
-  const int lchk = (lane & 3) * 16;    // 16-byte chunk within the 64-byte K step
-  const char* a1[AJ]; const char* a2[AJ];
-  int ab[AJ], ay[AJ], ax[AJ];
+  if (e.rowbias) {
+    float rb[8];
+    load8(reinterpret_cast<const T*>(e.rowbias) + (long)(grow / e.rows_per_batch) * e.ldrb + gcol, rb);
 #pragma unroll
-  for (int j = 0; j < AJ; ++j) {
-    int r = m0 + (j * 4 + wave) * 16 + lrow;
-    r = min(r, p.M - 1);
-    a2[j] = p.A2 ? (const char*)p.A2 + ((long)r * p.lda2) * sizeof(T) + lchk : nullptr;
-    if (p.mode == GEMM_LINEAR) {
-      a1[j] = (const char*)p.A1 + ((long)r * p.lda1) * sizeof(T) + lchk;
-      ab[j] = ay[j] = ax[j] = 0;
-    } else {
-      const int ox = r % p.Wout; const int t = r / p.Wout;
-      ax[j] = ox; ay[j] = t % p.Hout; ab[j] = t / p.Hout;
-      a1[j] = (const char*)p.A1 + lchk;
-    }
+    for (int i = 0; i < 8; ++i) v[i] += rb[i];
   }
-  const char* w1[BJ]; const char* w2[BJ];
+  if (e.act == ACT_SILU) {
 #pragma unroll
-  for (int j = 0; j < BJ; ++j) {
-    int n = n0 + (j * 4 + wave) * 16 + lrow;
-    n = min(n, p.N - 1);
-    w1[j] = (const char*)p.W1 + ((long)n * p.ldw1) * sizeof(T) + lchk;
-    w2[j] = p.W2 ? (const char*)p.W2 + ((long)n * p.ldw2) * sizeof(T) + lchk : nullptr;
+    for (int i = 0; i < 8; ++i) v[i] = silu_f(v[i]);
   }
-  const char* zpage = (const char*)p.zero_page + lchk;
-
-  auto issue = [&](int kt, int buf) {
-    char* As = smem + buf * STAGE;
-    char* Bs = As + A_BYTES;
-    if (kt < ks1) {
-      if (p.mode == GEMM_LINEAR) {
 #pragma unroll
-        for (int j = 0; j < AJ; ++j) glds16(a1[j] + (long)kt * 64, As + (j * 4 + wave) * 1024);
-      } else {
-        const int tap = kt / cpt, cc = kt - tap * cpt;
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const int sy = (p.mode == GEMM_CONV_S2) ? 2 : 1;
-        const bool virt = (p.mode == GEMM_CONV_UP2) | (p.mode == GEMM_CONV_T2);
+  for (int i = 0; i < 8; ++i) v[i] *= e.alpha;
+  if (e.residual) {
+    float rs[8];
+    load8(reinterpret_cast<const T*>(e.residual) + (long)grow * e.ldr + gcol, rs);
 #pragma unroll
-        for (int j = 0; j < AJ; ++j) {
-          const int vy = ay[j] * sy + ky - 1, vx = ax[j] * sy + kx - 1;
-          bool ok; int iy, ix;
-          if (virt) {
-            ok = ((unsigned)vy < (unsigned)(2 * p.Hin)) & ((unsigned)vx < (unsigned)(2 * p.Win));
-            if (p.mode == GEMM_CONV_T2) ok = ok & !((vy | vx) & 1);
-            iy = vy >> 1; ix = vx >> 1;
-          } else {
-            ok = ((unsigned)vy < (unsigned)p.Hin) & ((unsigned)vx < (unsigned)p.Win);
-            iy = vy; ix = vx;
-          }
-          const long pix = ((long)ab[j] * p.Hin + iy) * p.Win + ix;
-          const char* src = ok ? a1[j] + (pix * p.lda1 + (long)cc * KPB) * sizeof(T) : zpage;
-          glds16(src, As + (j * 4 + wave) * 1024);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < BJ; ++j) glds16(w1[j] + (long)kt * 64, Bs + (j * 4 + wave) * 1024);
-    } else {
-      const long off = (long)(kt - ks1) * 64;
-#pragma unroll
-      for (int j = 0; j < AJ; ++j) glds16(a2[j] + off, As + (j * 4 + wave) * 1024);
-#pragma unroll
-      for (int j = 0; j < BJ; ++j) glds16(w2[j] + off, Bs + (j * 4 + wave) * 1024);
-    }
-  };
-
-  f32x4_t acc[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  // fragment addresses: row (lane&15) of a 16-row group, 16-byte chunk (lane>>4)
-  const int frag_off = ((lane & 15) * 4 + (lane >> 4)) * 16;
-
-  // Fragment reads are inline asm: hipcc otherwise drains vmcnt(0) in front of
-  // every ds_read while an LDS-DMA is in flight, serialising prefetch and MFMA.
-  const uint32_t lds_base = (uint32_t)(uintptr_t)smem;
-  const uint32_t a_frag = lds_base + (wm * WM) * 64 + frag_off;
-  const uint32_t b_frag = lds_base + A_BYTES + (wn * WN) * 64 + frag_off;
-  auto compute = [&](int buf) {
-    const uint32_t aa = a_frag + buf * STAGE, ba = b_frag + buf * STAGE;
-    u32x4_t af[FM], bfr[FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[i]) : "v"(aa), "i"(i * 1024) : "memory");
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bfr[j]) : "v"(ba), "i"(j * 1024) : "memory");
-    if constexpr (FM == 4 && FN == 4) {
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]),
-                     "+v"(bfr[0]), "+v"(bfr[1]), "+v"(bfr[2]), "+v"(bfr[3]) :: "memory");
-    } else {
-      static_assert(FM == 2 && FN == 2, "tile");
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(af[0]), "+v"(af[1]), "+v"(bfr[0]), "+v"(bfr[1]) :: "memory");
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
-  };
-
-  issue(kbeg, 0);
-  for (int kt = kbeg; kt < kend; ++kt) {
-    const int buf = (kt - kbeg) & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // tile kt landed for every wave; buffer buf^1 is free
-    if (kt + 1 < kend) issue(kt + 1, buf ^ 1);
-    compute(buf);
+    for (int i = 0; i < 8; ++i) v[i] += e.beta * rs[i];
   }
-  __syncthreads();  // all waves done with the operand tiles; reuse LDS for the epilogue
+  if (e.atomic) {
+    float* dst = reinterpret_cast<float*>(e.C) + (long)grow * e.ldc + gcol;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(dst + i, v[i]);
+  } else if (e.out_f32) {
+    store8(reinterpret_cast<float*>(e.C) + (long)grow * e.ldc + gcol, v);
+  } else {
+    store8(reinterpret_cast<T*>(e.C) + (long)grow * e.ldc + gcol, v);
+  }
+}
 
-  // ---- epilogue: stage 32 x WN fp32 per wave, read back row-contiguous ----
-  float* stg = reinterpret_cast<float*>(smem) + wave * (32 * EST);
+__device__ __forceinline__ EpiArgs epi_of(const GemmParams& p) {
+  EpiArgs e;
+  e.bias = p.bias; e.rowbias = p.rowbias; e.ldrb = p.ldrb; e.rows_per_batch = p.rows_per_batch;
+  e.residual = p.residual; e.ldr = p.ldr; e.alpha = p.alpha; e.beta = p.beta; e.act = p.act;
+  e.C = p.C; e.ldc = p.ldc; e.out_f32 = p.out_f32; e.atomic = p.atomic; e.M = p.M; e.N = p.N;
+  return e;
+}
+
+// Accumulator tile -> memory: each wave stages 32 (or 16) x WN fp32 through LDS so that residual
+// reads and output writes are whole 16-byte vectors along rows, then applies the epilogue.
+template <typename T, int FM, int FN>
+__device__ __forceinline__ void store_tile(const GemmParams& p, f32x4_t (&acc)[FM][FN], float* stg, int row0,
+                                           int col0, int lane, float* slab, int zsplit) {
+  constexpr int WN = FN * 16;
+  constexpr int EST = WN + 4;
   constexpr int LPR = WN / 8;      // lanes per output row
-  constexpr int RPI = 64 / LPR;    // rows per read iteration
-  constexpr int ITERS = 32 / RPI;
+  constexpr int RPI = 64 / LPR;    // rows per read iteration (lanes idle when 64 % LPR != 0)
   constexpr int PASSES = (FM + 1) / 2;
   constexpr int FPP = (FM >= 2) ? 2 : 1;  // m-frags per pass
+  constexpr int ITERS = (FPP * 16 + RPI - 1) / RPI;
+  const EpiArgs e = epi_of(p);
 #pragma unroll
   for (int ps = 0; ps < PASSES; ++ps) {
 #pragma unroll
@@ -197,44 +131,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     for (int it = 0; it < ITERS; ++it) {
       const int rr = it * RPI + lane / LPR;
       const int cg = (lane % LPR) * 8;
-      const int grow = m0 + wm * WM + ps * 32 + rr;
-      const int gcol = n0 + wn * WN + cg;
-      if (rr < FPP * 16 && grow < p.M && gcol < p.N) {
+      const int grow = row0 + ps * 32 + rr;
+      const int gcol = col0 + cg;
+      if (lane < RPI * LPR && rr < FPP * 16 && grow < p.M && gcol < p.N) {
         float v[8];
         const float4 s0 = *reinterpret_cast<const float4*>(&stg[rr * EST + cg]);
         const float4 s1 = *reinterpret_cast<const float4*>(&stg[rr * EST + cg + 4]);
         v[0] = s0.x; v[1] = s0.y; v[2] = s0.z; v[3] = s0.w;
         v[4] = s1.x; v[5] = s1.y; v[6] = s1.z; v[7] = s1.w;
-        if (p.bias) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += p.bias[gcol + e];
-        }
-        if (p.rowbias) {
-          float rb[8];
-          load8(reinterpret_cast<const T*>(p.rowbias) + (long)(grow / p.rows_per_batch) * p.ldrb + gcol, rb);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += rb[e];
-        }
-        if (p.act == ACT_SILU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
-        if (p.residual) {
-          float rs[8];
-          load8(reinterpret_cast<const T*>(p.residual) + (long)grow * p.ldr + gcol, rs);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += p.beta * rs[e];
-        }
-        if (p.atomic) {
-          float* dst = reinterpret_cast<float*>(p.C) + (long)grow * p.ldc + gcol;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) atomicAdd(dst + e, v[e]);
-        } else if (p.out_f32) {
-          store8(reinterpret_cast<float*>(p.C) + (long)grow * p.ldc + gcol, v);
+        if (slab) {   // split-K partial: raw accumulators, epilogue applied by the reduce kernel
+          store8(slab + ((long)zsplit * p.M + grow) * p.N + gcol, v);
         } else {
-          store8(reinterpret_cast<T*>(p.C) + (long)grow * p.ldc + gcol, v);
+          epilogue8<T>(e, v, grow, gcol);
         }
       }
     }
@@ -242,26 +150,570 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   }
 }
 
+template <typename T, int BM, int BN, int WGM, int WGN, int KSUB, int R>
+__global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_kernel(GemmParams p, int tiles_m, int tiles_n,
+                                                              float* __restrict__ slab) {
+  constexpr int NW = WGM * WGN;
+  constexpr int KPB = 64 / (int)sizeof(T);   // elements per 64-byte substep row
+  constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 16, FN = WN / 16;
+  constexpr int AG = BM / 16, BG = BN / 16;  // 1 KiB groups per slot
+  constexpr int AJ = AG / NW, BJ = (BG + NW - 1) / NW;
+  constexpr int G = AJ + BJ;                 // DMA instructions per wave per substep
+  constexpr int D = R - KSUB;                // prefetch distance in substeps
+  constexpr int SLOT = (AG + BG) * 1024;
+  constexpr int EST = WN + 4;                // padded fp32 row stride of the epilogue staging
+  constexpr int EROWS = (FM >= 2) ? 32 : 16;
+  constexpr int EPI_BYTES = NW * EROWS * EST * 4;
+  constexpr int SMEM = (R * SLOT > EPI_BYTES) ? R * SLOT : EPI_BYTES;
+  static_assert(AG % NW == 0 && WM % 16 == 0 && WN % 16 == 0 && WN % 8 == 0, "tile shape");
+  static_assert(D >= KSUB && D >= 1, "ring too shallow");
+  static_assert(FM == 1 || FM % 2 == 0, "FM");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  // ---- XCD-aware tile id: XCD x (= workgroup id mod 8) owns tiles [x*nt/8, (x+1)*nt/8)
+  const int nt = tiles_m * tiles_n;
+  int pid = blockIdx.x;
+  const int zsplit = pid / nt;
+  pid -= zsplit * nt;
+  {
+    const int q = nt >> 3, r = nt & 7, xcd = pid & 7, idx = pid >> 3;
+    pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (pid / tiles_n) * BM, n0 = (pid % tiles_n) * BN;
+
+  const int taps = (p.mode == GEMM_LINEAR) ? 1 : 9;
+  const int cpt = p.K1 / KPB;  // substeps per tap
+  const int ks1 = taps * cpt;
+  const int ks2 = p.K2 / KPB;
+  int kbeg = 0, kend = ks1 + ks2;
+  if (p.splitk > 1) {
+    const int per = (kend + p.splitk - 1) / p.splitk;
+    kbeg = zsplit * per;
+    kend = min(kend, kbeg + per);
+  }
+
+  // ---- per-lane source rows (fixed across the K loop) ----
+  const int lrow = lane >> 2;          // row within a 16-row DMA group
+  const int lchk = (lane & 3) * 16;    // 16-byte chunk within the 64-byte substep row
+  const char* a1[AJ]; const char* a2[AJ];
+  int ab[AJ], ay[AJ], ax[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    int r = m0 + (j * NW + wave) * 16 + lrow;
+    r = min(r, p.M - 1);
+    a2[j] = p.A2 ? (const char*)p.A2 + ((long)r * p.lda2) * sizeof(T) + lchk : nullptr;
+    if (p.mode == GEMM_LINEAR) {
+      a1[j] = (const char*)p.A1 + ((long)r * p.lda1) * sizeof(T) + lchk;
+      ab[j] = ay[j] = ax[j] = 0;
+    } else {
+      const int ox = r % p.Wout; const int t = r / p.Wout;
+      ax[j] = ox; ay[j] = t % p.Hout; ab[j] = t / p.Hout;
+      a1[j] = (const char*)p.A1 + lchk;
+    }
+  }
+  const char* w1[BJ]; const char* w2[BJ];
+  int bgrp[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    // the last wave(s) re-issue the final group when BG is not a multiple of NW (same bytes, same place):
+    // every wave then has exactly G DMA instructions per substep, which the counted vmcnt relies on
+    bgrp[j] = min(j * NW + wave, BG - 1);
+    int n = n0 + bgrp[j] * 16 + lrow;
+    n = min(n, p.N - 1);
+    w1[j] = (const char*)p.W1 + ((long)n * p.ldw1) * sizeof(T) + lchk;
+    w2[j] = p.W2 ? (const char*)p.W2 + ((long)n * p.ldw2) * sizeof(T) + lchk : nullptr;
+  }
+  const char* zpage = (const char*)p.zero_page + lchk;
+
+  // NOTE: element-wise selects only -- selecting between the pointer ARRAYS (w1 vs w2) in two
+  // branches makes hipcc spill them to scratch and serialise the DMA behind scratch loads.
+  auto issue = [&](int kt, int slot) {
+    char* As = smem + slot * SLOT;
+    char* Bs = As + AG * 1024;
+    const bool seg2 = kt >= ks1;
+    const long koff = (long)(seg2 ? kt - ks1 : kt) * 64;
+    if (seg2 || p.mode == GEMM_LINEAR) {
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) glds16((seg2 ? a2[j] : a1[j]) + koff, As + (j * NW + wave) * 1024);
+    } else {
+      const int tap = kt / cpt, cc = kt - tap * cpt;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int sy = (p.mode == GEMM_CONV_S2) ? 2 : 1;
+      const bool virt = (p.mode == GEMM_CONV_UP2) | (p.mode == GEMM_CONV_T2);
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        const int vy = ay[j] * sy + ky - 1, vx = ax[j] * sy + kx - 1;
+        bool ok; int iy, ix;
+        if (virt) {
+          ok = ((unsigned)vy < (unsigned)(2 * p.Hin)) & ((unsigned)vx < (unsigned)(2 * p.Win));
+          if (p.mode == GEMM_CONV_T2) ok = ok & !((vy | vx) & 1);
+          iy = vy >> 1; ix = vx >> 1;
+        } else {
+          ok = ((unsigned)vy < (unsigned)p.Hin) & ((unsigned)vx < (unsigned)p.Win);
+          iy = vy; ix = vx;
+        }
+        const long pix = ((long)ab[j] * p.Hin + iy) * p.Win + ix;
+        const char* src = ok ? a1[j] + (pix * p.lda1 + (long)cc * KPB) * sizeof(T) : zpage;
+        glds16(src, As + (j * NW + wave) * 1024);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) glds16((seg2 ? w2[j] : w1[j]) + koff, Bs + bgrp[j] * 1024);
+  };
+
+  f32x4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses: row (lane&15) of a 16-row group, 16-byte chunk (lane>>4)
+  const int frag_off = ((lane & 15) * 4 + (lane >> 4)) * 16;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)smem;
+  const uint32_t a_frag = lds_base + (wm * FM) * 1024 + frag_off;
+  const uint32_t b_frag = lds_base + AG * 1024 + (wn * FN) * 1024 + frag_off;
+
+  // Fragment reads are inline asm: hipcc otherwise drains vmcnt(0) in front of every
+  // ds_read it can see while an LDS-DMA is in flight, serialising prefetch and MFMA.
+  auto read_frags = [&](int slot, u32x4_t (&af)[FM], u32x4_t (&bfr)[FN]) {
+    const uint32_t aa = a_frag + slot * SLOT, ba = b_frag + slot * SLOT;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[i]) : "v"(aa), "i"(i * 1024) : "memory");
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bfr[j]) : "v"(ba), "i"(j * 1024) : "memory");
+  };
+  // tie the wait to the registers so the MFMAs cannot be hoisted above it
+  auto wait_frags = [&](u32x4_t (&af)[FM], u32x4_t (&bfr)[FN]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < FM; ++i) asm volatile("" : "+v"(af[i]));
+#pragma unroll
+    for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(bfr[j]));
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mma_all = [&](const u32x4_t (&af)[FM], const u32x4_t (&bfr)[FN]) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
+  };
+
+  // ---- prologue: D substeps in flight
+  const int total = kend - kbeg;
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+    if (s < total) issue(kbeg + s, s % R);
+
+  for (int it = 0; it < total; it += KSUB) {
+    // substeps it .. it+KSUB-1 must have landed; (D-KSUB) newer substeps may stay in flight
+    if (it + D <= total) wait_vm<(D - KSUB) * G>();
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();   // every wave's DMA landed; slots of iteration it-KSUB are free
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < KSUB; ++s) {
+      const int kn = it + D + s;
+      if (kn < total) issue(kbeg + kn, kn % R);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (KSUB == 1) {
+      u32x4_t af[FM], bfr[FN];
+      read_frags(it % R, af, bfr);
+      wait_frags(af, bfr);
+      mma_all(af, bfr);
+    } else {
+      static_assert(KSUB == 2, "KSUB");
+      u32x4_t af0[FM], bf0[FN], af1[FM], bf1[FN];
+      const bool two = it + 1 < total;
+      read_frags(it % R, af0, bf0);
+      wait_frags(af0, bf0);
+      // second substep's fragment reads are issued before, and land under, the first substep's MFMAs
+      // (plain lgkmcnt(0) waits only: a counted lgkmcnt would also count compiler-issued s_loads)
+      if (two) read_frags((it + 1) % R, af1, bf1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_all(af0, bf0);
+      if (two) {
+        wait_frags(af1, bf1);
+        mma_all(af1, bf1);
+      }
+    }
+  }
+  __syncthreads();  // all waves done with the operand slots; reuse LDS for the epilogue
+
+  // ---- epilogue
+  store_tile<T, FM, FN>(p, acc, reinterpret_cast<float*>(smem) + wave * (EROWS * EST), m0 + wm * WM, n0 + wn * WN,
+                        lane, slab, zsplit);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Full-line variant (the production path whenever every K segment is a multiple of 128 bytes).
+//
+// A pipeline stage is 128 bytes of K per row -- a whole cache line per row per DMA, which is what
+// the vector-memory path wants (64-byte half-line fetches cost the same address-processing slots) --
+// staged 8 rows per global_load_lds instruction.  The LDS image of an instruction is lane-linear
+// ([8 rows][128 B]), so the bank-conflict fix is an XOR swizzle applied on the SOURCE side: the lane
+// that fills 16-byte slot q of row r fetches logical chunk q ^ ((r >> 1) & 7); the MFMA fragment read
+// of (row r, chunk c) then goes to slot c ^ ((r >> 1) & 7).  For the ds_read_b128 lane groups of a
+// 16x16x32 fragment (16 rows x chunks {g, g+4}) this spreads every group over all sixteen 16-byte
+// bank slots: conflict-free.
+//
+// 8 waves (4 x 2) own a 256 x BN tile; 3 LDS slots.  Iteration s:
+//     vmcnt(0) [own DMA of stage s+1] -> s_barrier -> issue DMA of stage s+2 -> ds_read k-half 1 of
+//     stage s -> MFMA k-half 0 (operands already in registers) -> ds_read k-half 0 of stage s+1 ->
+//     MFMA k-half 1
+// so MFMA issue resumes straight after the barrier and every LDS read is covered by MFMAs.
+template <typename T, int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p, int tiles_m, int tiles_n,
+                                                                 float* __restrict__ slab) {
+  constexpr int NW = WGM * WGN;
+  constexpr int R = 3;
+  constexpr int KPS = 128 / (int)sizeof(T);  // elements per stage row
+  constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 16, FN = WN / 16;
+  constexpr int AI = BM / 8, BI = BN / 8;    // DMA instructions (8 rows x 128 B) per stage
+  constexpr int AJ = AI / NW, BJ = (BI + NW - 1) / NW;
+  constexpr int SLOT = (AI + BI) * 1024;
+  constexpr int EST = WN + 4;
+  constexpr int EROWS = (FM >= 2) ? 32 : 16;
+  static_assert(AI % NW == 0 && WM % 16 == 0 && WN % 16 == 0, "tile shape");
+  static_assert(NW * EROWS * EST * 4 <= R * SLOT, "epilogue staging must fit in the ring");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  const int nt = tiles_m * tiles_n;
+  int pid = blockIdx.x;
+  const int zsplit = pid / nt;
+  pid -= zsplit * nt;
+  {
+    const int q = nt >> 3, r = nt & 7, xcd = pid & 7, idx = pid >> 3;
+    pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (pid / tiles_n) * BM, n0 = (pid % tiles_n) * BN;
+
+  const int taps = (p.mode == GEMM_LINEAR) ? 1 : 9;
+  const int cpt = p.K1 / KPS;  // stages per tap
+  const int ks1 = taps * cpt;
+  const int ks2 = p.K2 / KPS;
+  int kbeg = 0, kend = ks1 + ks2;
+  if (p.splitk > 1) {
+    const int per = (kend + p.splitk - 1) / p.splitk;
+    kbeg = zsplit * per;
+    kend = min(kend, kbeg + per);
+  }
+  const int total = kend - kbeg;
+
+  // ---- per-lane DMA sources: row (lane >> 3) of an 8-row group, source chunk = slot ^ swizzle(row)
+  const int lrow = lane >> 3, lslot = lane & 7;
+  const char* a1[AJ]; const char* a2[AJ];
+  int ab[AJ], ay[AJ], ax[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int inst = j * NW + wave;
+    const int chunk = (lslot ^ (((inst & 1) << 2) | (lrow >> 1))) * 16;
+    int r = m0 + inst * 8 + lrow;
+    r = min(r, p.M - 1);
+    a2[j] = p.A2 ? (const char*)p.A2 + ((long)r * p.lda2) * sizeof(T) + chunk : nullptr;
+    if (p.mode == GEMM_LINEAR) {
+      a1[j] = (const char*)p.A1 + ((long)r * p.lda1) * sizeof(T) + chunk;
+      ab[j] = ay[j] = ax[j] = 0;
+    } else {
+      const int ox = r % p.Wout; const int t = r / p.Wout;
+      ax[j] = ox; ay[j] = t % p.Hout; ab[j] = t / p.Hout;
+      a1[j] = (const char*)p.A1 + chunk;
+    }
+  }
+  const char* w1[BJ]; const char* w2[BJ];
+  int binst[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    binst[j] = j * NW + wave;                      // >= BI: this wave has no B instruction j
+    const int inst = min(binst[j], BI - 1);
+    const int chunk = (lslot ^ (((inst & 1) << 2) | (lrow >> 1))) * 16;
+    int n = n0 + inst * 8 + lrow;
+    n = min(n, p.N - 1);
+    w1[j] = (const char*)p.W1 + ((long)n * p.ldw1) * sizeof(T) + chunk;
+    w2[j] = p.W2 ? (const char*)p.W2 + ((long)n * p.ldw2) * sizeof(T) + chunk : nullptr;
+  }
+  const char* zpage = (const char*)p.zero_page + lslot * 16;
+
+  auto issue = [&](int kt, int slot) {
+    char* As = smem + slot * SLOT;
+    char* Bs = As + AI * 1024;
+    const bool seg2 = kt >= ks1;
+    const long koff = (long)(seg2 ? kt - ks1 : kt) * 128;
+    if (seg2 || p.mode == GEMM_LINEAR) {
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) glds16((seg2 ? a2[j] : a1[j]) + koff, As + (j * NW + wave) * 1024);
+    } else {
+      const int tap = kt / cpt, cc = kt - tap * cpt;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int sy = (p.mode == GEMM_CONV_S2) ? 2 : 1;
+      const bool virt = (p.mode == GEMM_CONV_UP2) | (p.mode == GEMM_CONV_T2);
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        const int vy = ay[j] * sy + ky - 1, vx = ax[j] * sy + kx - 1;
+        bool ok; int iy, ix;
+        if (virt) {
+          ok = ((unsigned)vy < (unsigned)(2 * p.Hin)) & ((unsigned)vx < (unsigned)(2 * p.Win));
+          if (p.mode == GEMM_CONV_T2) ok = ok & !((vy | vx) & 1);
+          iy = vy >> 1; ix = vx >> 1;
+        } else {
+          ok = ((unsigned)vy < (unsigned)p.Hin) & ((unsigned)vx < (unsigned)p.Win);
+          iy = vy; ix = vx;
+        }
+        const long pix = ((long)ab[j] * p.Hin + iy) * p.Win + ix;
+        const char* src = ok ? a1[j] + (pix * p.lda1 + (long)cc * KPS) * sizeof(T) : zpage;
+        glds16(src, As + (j * NW + wave) * 1024);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j)
+      if (binst[j] < BI) glds16((seg2 ? w2[j] : w1[j]) + koff, Bs + binst[j] * 1024);
+  };
+
+  f32x4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read address: row lr of a 16-row fragment, logical chunk (4*half + g) -> slot ^ (lr >> 1)
+  const int lr = lane & 15, g = lane >> 4;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)smem;
+  const uint32_t frag0 = lr * 128 + ((g ^ (lr >> 1)) * 16);      // k-half 0; k-half 1 = frag0 ^ 64
+  const uint32_t a_base = lds_base + (wm * FM) * 2048;
+  const uint32_t b_base = lds_base + AI * 1024 + (wn * FN) * 2048;
+
+  auto read_frags = [&](int slot, int half, u32x4_t (&af)[FM], u32x4_t (&bfr)[FN]) {
+    const uint32_t off = (half ? (frag0 ^ 64u) : frag0) + slot * SLOT;
+    const uint32_t aa = a_base + off, ba = b_base + off;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[i]) : "v"(aa), "i"(i * 2048) : "memory");
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bfr[j]) : "v"(ba), "i"(j * 2048) : "memory");
+  };
+  auto wait_frags = [&](u32x4_t (&af)[FM], u32x4_t (&bfr)[FN]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < FM; ++i) asm volatile("" : "+v"(af[i]));
+#pragma unroll
+    for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(bfr[j]));
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mma_all = [&](const u32x4_t (&af)[FM], const u32x4_t (&bfr)[FN]) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
+  };
+
+  // ---- prologue: stages 0 and 1 in flight; stage 0 landed and its k-half 0 in registers
+  u32x4_t fa[FM], fb[FN], ga[FM], gb[FN];
+  issue(kbeg, 0);
+  if (total > 1) {
+    issue(kbeg + 1, 1);
+    // stage 0's DMA is the older half of this wave's outstanding loads; waiting for all of them is
+    // simplest and only costs the first iteration
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  read_frags(0, 0, fa, fb);
+  wait_frags(fa, fb);
+
+  for (int s = 0; s < total; ++s) {
+    const int slot = s % R;
+    // own DMA of stage s+1 (issued one iteration ago) has landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // stage s+1 visible to all waves; slot (s+2)%R no longer read
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 2 < total) issue(kbeg + s + 2, (s + 2) % R);
+    read_frags(slot, 1, ga, gb);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_all(fa, fb);
+    wait_frags(ga, gb);
+    if (s + 1 < total) read_frags((s + 1) % R, 0, fa, fb);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_all(ga, gb);
+    wait_frags(fa, fb);
+  }
+  __syncthreads();  // all waves done with the operand slots; reuse LDS for the epilogue
+
+  store_tile<T, FM, FN>(p, acc, reinterpret_cast<float*>(smem) + wave * (EROWS * EST), m0 + wm * WM, n0 + wn * WN,
+                        lane, slab, zsplit);
+}
+
+// sum the split-K slabs and apply the epilogue: one lane per 8 output columns
 template <typename T>
-static int launch_t(const GemmParams& p, hipStream_t stream) {
-  const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-  const int sk = p.splitk > 1 ? p.splitk : 1;
-  // 128x128 tiles once they fill the chip (256 CUs), else 64x64 for more workgroups.
-  if (t128 * sk >= 192) {
-    dim3 grid((p.N + 127) / 128, (p.M + 127) / 128, sk);
-    hipLaunchKernelGGL((gemm_kernel<T, 128, 128>), grid, dim3(256), 0, stream, p);
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, const float* __restrict__ slab, int splits) {
+  const int n8 = p.N / 8;
+  const long total = (long)p.M * n8;
+  const EpiArgs e = epi_of(p);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int grow = (int)(i / n8), gcol = (int)(i % n8) * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < splits; ++z) {
+      float t[8];
+      load8(slab + ((long)z * p.M + grow) * p.N + gcol, t);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += t[k];
+    }
+    epilogue8<T>(e, v, grow, gcol);
+  }
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN, int KSUB, int R>
+static int launch_cfg(const GemmParams& p0, hipStream_t stream) {
+  constexpr int NW = WGM * WGN;
+  constexpr int SLOT = (BM / 16 + BN / 16) * 1024;
+  constexpr int WN = BN / WGN, FM = BM / WGM / 16;
+  constexpr int EPI = NW * ((FM >= 2) ? 32 : 16) * (WN + 4) * 4;
+  constexpr int SMEM = (R * SLOT > EPI) ? R * SLOT : EPI;
+  auto kern = &gemm_kernel<T, BM, BN, WGM, WGN, KSUB, R>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (SMEM > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
+      return CL_ELAUNCH;
+    attr_set = true;
+  }
+  GemmParams p = p0;
+  const int kpb = 64 / (int)sizeof(T);
+  const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
+  const long tiles = (long)tm * tn;
+  const int ksub = ((p.mode == GEMM_LINEAR ? 1 : 9) * p.K1 + p.K2) / kpb;
+  float* slab = nullptr;
+  if (p.atomic) {
+    if (p.splitk < 1) p.splitk = 1;
+    if (p.splitk > ksub) p.splitk = ksub > 0 ? ksub : 1;
   } else {
-    dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, sk);
-    hipLaunchKernelGGL((gemm_kernel<T, 64, 64>), grid, dim3(256), 0, stream, p);
+    // deterministic split-K through the workspace when the tile grid cannot fill the chip
+    int sk = 1;
+    if (p.splitk <= 1 && tiles < 160 && ksub >= 32 && g_ws) {
+      sk = (int)((256 + tiles - 1) / tiles);
+      if (sk > ksub / 16) sk = ksub / 16;
+      if (sk > 16) sk = 16;
+      while (sk > 1 && (long)sk * p.M * p.N * 4 > g_ws_bytes) --sk;
+      if (sk < 1) sk = 1;
+    }
+    p.splitk = sk;
+    if (sk > 1) slab = reinterpret_cast<float*>(g_ws);
+  }
+  // every split must own at least one substep (the kernel assumes total >= 1 except for empty K)
+  if (p.splitk > 1) {
+    const int per = (ksub + p.splitk - 1) / p.splitk;
+    p.splitk = (ksub + per - 1) / per;
+  }
+  const long grid = tiles * p.splitk;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), SMEM, stream, p, tm, tn, slab);
+  if (slab) {
+    const long total = (long)p.M * (p.N / 8);
+    int rg = (int)((total + 255) / 256); if (rg > 4096) rg = 4096;
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(rg), dim3(256), 0, stream, p, slab, p.splitk);
   }
   CL_CHECK_LAUNCH();
   return CL_OK;
+}
+
+// choose the split-K factor: `want` workgroups in flight, at least `min_steps` pipeline steps per split
+static int pick_splitk(GemmParams& p, long tiles, int steps, int want, int min_steps, float** slab) {
+  *slab = nullptr;
+  if (p.atomic) {
+    if (p.splitk < 1) p.splitk = 1;
+    if (p.splitk > steps) p.splitk = steps > 0 ? steps : 1;
+  } else {
+    int sk = 1;
+    if (tiles < want && steps >= 2 * min_steps && g_ws) {
+      sk = (int)((want + tiles - 1) / tiles);
+      if (sk > steps / min_steps) sk = steps / min_steps;
+      if (sk > 32) sk = 32;
+      while (sk > 1 && (long)sk * p.M * p.N * 4 > g_ws_bytes) --sk;
+      if (sk < 1) sk = 1;
+    }
+    p.splitk = sk;
+    if (sk > 1) *slab = reinterpret_cast<float*>(g_ws);
+  }
+  if (p.splitk > 1) {   // every split owns at least one step
+    const int per = (steps + p.splitk - 1) / p.splitk;
+    p.splitk = (steps + per - 1) / per;
+  }
+  return p.splitk;
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN>
+static int launch_fl(const GemmParams& p0, hipStream_t stream) {
+  constexpr int NW = WGM * WGN;
+  constexpr int SMEM = 3 * (BM / 8 + BN / 8) * 1024;
+  auto kern = &gemm_fl_kernel<T, BM, BN, WGM, WGN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (SMEM > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
+      return CL_ELAUNCH;
+    attr_set = true;
+  }
+  GemmParams p = p0;
+  const int kps = 128 / (int)sizeof(T);
+  const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
+  const long tiles = (long)tm * tn;
+  const int steps = ((p.mode == GEMM_LINEAR ? 1 : 9) * p.K1 + p.K2) / kps;
+  float* slab;
+  pick_splitk(p, tiles, steps, 256, 4, &slab);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * p.splitk)), dim3(NW * 64), SMEM, stream, p, tm, tn, slab);
+  if (slab) {
+    const long total = (long)p.M * (p.N / 8);
+    int rg = (int)((total + 255) / 256); if (rg > 4096) rg = 4096;
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(rg), dim3(256), 0, stream, p, slab, p.splitk);
+  }
+  CL_CHECK_LAUNCH();
+  return CL_OK;
+}
+
+int g_gemm_force_cfg = -1;   // probe / tuning hook: >= 0 forces a tile configuration
+
+template <typename T>
+static int launch_t(const GemmParams& p, hipStream_t stream) {
+  int cfg = g_gemm_force_cfg;
+  if (cfg < 0) {
+    if (p.M <= 64 || p.N <= 64) cfg = 0;
+    else if (p.N % 160 == 0) cfg = 2;
+    else cfg = 1;
+    // small problems: more, smaller workgroups
+    if (cfg != 0 && (long)((p.M + 127) / 128) * ((p.N + 127) / 128) < 48 && p.atomic) cfg = 0;
+  }
+  switch (cfg) {
+    case 0: return launch_cfg<T, 64, 64, 2, 2, 1, 4>(p, stream);
+    case 1: return launch_cfg<T, 128, 128, 2, 2, 2, 4>(p, stream);
+    case 2: return launch_cfg<T, 128, 160, 2, 2, 2, 4>(p, stream);
+    case 3: return launch_cfg<T, 128, 160, 2, 2, 1, 4>(p, stream);
+    case 4: return launch_cfg<T, 128, 160, 2, 2, 2, 6>(p, stream);
+    case 5: return launch_cfg<T, 256, 160, 4, 2, 2, 4>(p, stream);
+    case 6: return launch_cfg<T, 128, 128, 2, 2, 1, 2>(p, stream);   // the round-0 structure, for A/B
+    case 7: return launch_cfg<T, 256, 128, 4, 2, 2, 4>(p, stream);
+    case 8: case 9: {
+      const int kps = 128 / (int)sizeof(T);
+      if (p.K1 % kps || p.K2 % kps) return launch_cfg<T, 128, 128, 2, 2, 2, 4>(p, stream);
+      return cfg == 8 ? launch_fl<T, 256, 160, 4, 2>(p, stream) : launch_fl<T, 256, 128, 4, 2>(p, stream);
+    }
+    default: return CL_EINVAL;
+  }
 }
 
 int launch_gemm(const GemmParams& p, int dtype, hipStream_t stream) {
   const int kpb = dtype == CL_BF16 ? 32 : 16;
   if (p.M <= 0 || p.N <= 0) return CL_OK;
   if (p.K1 % kpb || p.K2 % kpb || p.N % 8 || p.ldc % 8) return CL_EINVAL;
+  if (p.K1 <= 0) return CL_EINVAL;
   if (p.mode != GEMM_LINEAR && !p.zero_page) return CL_EINVAL;
   if (p.K2 && (!p.A2 || !p.W2)) return CL_EINVAL;
   if (p.atomic == 0 && p.splitk > 1) return CL_EINVAL;

@@ -49,6 +49,8 @@ _lib = None
 _P, _L, _I, _F = C.c_void_p, C.c_long, C.c_int, C.c_float
 _SIGS = {
     "cl_abi_version": [],
+    "cl_set_workspace": [_P, _L],
+    "cl_gemm_force_config": [_I],
     "cl_gemm": [C.POINTER(GemmParams), _I, _P],
     "cl_lora_down": [_I, _P, _L, _P, _I, _P, _L, _I, _I, _P],
     "cl_lora_linear_fwd": [_I, _P, _L, _P, _P, _P, _L, _P, _I, _P, _L, _I, _P, _L, _I, _I, _I, _P],
@@ -136,6 +138,16 @@ def ld(t: Optional[torch.Tensor]) -> int:
 
 
 _zero_pages = {}
+_workspace = None
+WORKSPACE_BYTES = 64 << 20
+
+
+def ensure_workspace(device) -> None:
+    """Register the split-K scratch (fp32 partial slabs) with the library once per process."""
+    global _workspace
+    if _workspace is None:
+        _workspace = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+        _chk(lib().cl_set_workspace(_workspace.data_ptr(), WORKSPACE_BYTES), "cl_set_workspace")
 
 
 def zero_page(device) -> torch.Tensor:
@@ -155,6 +167,8 @@ def gemm(a1, w1, out, *, a2=None, w2=None, bias=None, rowbias=None, rows_per_bat
     a1: [M,K1] (LINEAR) or the NHWC activation [B*Hin*Win, C] (conv modes, conv=(B,Hin,Win,Hout,Wout)).
     """
     p = GemmParams()
+    if _workspace is None:
+        ensure_workspace(a1.device)
     dty = dt(a1) if dtype is None else dtype
     p.A1 = a1.data_ptr(); p.lda1 = ld(a1); p.K1 = a1.shape[1] if k1 is None else k1
     p.W1 = w1.data_ptr(); p.ldw1 = ld(w1)

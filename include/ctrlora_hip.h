@@ -35,6 +35,14 @@ extern "C" {
 
 int cl_abi_version(void);
 
+/* Scratch for the deterministic split-K path of the contraction kernels (fp32 partial slabs for
+ * the deep-K / small-MN products of the 8x8 and 16x16 UNet levels).  The library never allocates:
+ * the host (torch) owns the buffer and registers it once per process; without one, split-K is off.
+ * 64 MiB covers every CtrLoRA shape at batch 16.  Used stream-ordered on the launching stream. */
+int cl_set_workspace(void* device_ptr, long bytes);
+/* tuning hook: force a tile configuration of csrc/gemm.hip (-1 = built-in heuristic) */
+int cl_gemm_force_config(int cfg);
+
 /* ---- dense contractions -------------------------------------------------------------
  * One MFMA kernel family (csrc/gemm.hip) behind all of them:
  *   out[M,N] = act( A1.W1^T + A2.W2^T + bias[n] + rowbias[m / rows_per_batch, n] ) * alpha
@@ -64,8 +72,8 @@ typedef struct cl_gemm_params {
   int act;                            /* 0 none, 1 SiLU                                      */
   void* C; long ldc;
   int out_f32;                        /* store fp32 regardless of dtype                      */
-  int atomic;                         /* fp32 atomicAdd into C (required when splitk > 1)    */
-  int splitk;
+  int atomic;                         /* fp32 atomicAdd into C (gradient accumulation)       */
+  int splitk;                         /* K splits in atomic mode; otherwise chosen internally */
 } cl_gemm_params;
 
 /* Generic entry; the named operators below are thin fillers of cl_gemm_params. */

@@ -151,40 +151,74 @@ static void time_case(const char* name, int dtype, int mode, int M, int N, int K
   hipFree(A.d); hipFree(Wt.d); hipFree(C.d); if (K2) { hipFree(A2.d); hipFree(W2.d); }
 }
 
-int main(int argc, char** argv) {
-  hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, 0));
-  printf("device: %s  CUs=%d  arch=%s\n", prop.name, prop.multiProcessorCount, prop.gcnArchName);
-  HIPCHK(hipMalloc(&g_zero, 4096)); HIPCHK(hipMemset(g_zero, 0, 4096));
-
+static void correctness_suite(const char* tag) {
+  printf("---- correctness: %s\n", tag);
   case_linear("linear bf16 300x200x96 plain", CL_BF16, 300, 200, 96, 0, false, false, false, 0, 1.f, 0.f, true, 1);
   case_linear("linear bf16 300x200x96 bf16-out", CL_BF16, 300, 200, 96, 0, false, false, false, 0, 1.f, 0.f, false, 1);
   case_linear("linear bf16 bias+resid alpha/beta", CL_BF16, 257, 136, 160, 0, true, true, false, 0, 0.5f, 2.0f, true, 1);
   case_linear("linear bf16 lora K2=64", CL_BF16, 300, 200, 96, 64, true, false, false, 0, 1.f, 0.f, true, 1);
   case_linear("linear bf16 rowbias+silu", CL_BF16, 70, 72, 64, 0, true, false, true, ACT_SILU, 1.f, 0.f, true, 1);
   case_linear("linear bf16 splitK=3 atomic", CL_BF16, 100, 64, 32 * 9, 0, false, false, false, 0, 1.f, 0.f, true, 3);
-  case_linear("linear bf16 big-tile 1000x520x256", CL_BF16, 3000, 1032, 256, 0, true, true, false, 0, 1.f, 1.f, true, 1);
+  case_linear("linear bf16 big-tile 1500x520x256", CL_BF16, 1500, 520, 256, 0, true, true, false, 0, 1.f, 1.f, true, 1);
+  case_linear("linear bf16 N=320 (2x160) K odd substeps", CL_BF16, 1000, 320, 32 * 7, 32, true, true, false, 0, 1.f, 1.f, true, 1);
+  case_linear("linear bf16 ws split-K 300x640x2048", CL_BF16, 300, 640, 2048, 64, true, true, true, ACT_SILU, 0.5f, 1.f, false, 1);
+  case_linear("linear bf16 ws split-K 200x320x4096 f32out", CL_BF16, 200, 320, 4096, 0, true, false, false, 0, 1.f, 0.f, true, 1);
   case_linear("linear f32 130x72x48", CL_F32, 130, 72, 48, 0, true, true, false, 0, 1.f, 1.f, true, 1);
   case_linear("linear f32 lora K2=16 big", CL_F32, 2100, 1032, 64, 16, true, false, false, 0, 1.f, 0.f, true, 1);
+  case_linear("linear bf16 K%64 1000x320x448+64 bias+resid", CL_BF16, 1000, 320, 448, 64, true, true, false, 0, 1.f, 1.f, true, 1);
+  case_linear("linear bf16 K%64 300x200x128 rowbias+silu bf16out", CL_BF16, 300, 200, 128, 0, true, false, true, ACT_SILU, 1.f, 0.f, false, 1);
+  case_linear("linear bf16 K%64 one stage 520x136x64", CL_BF16, 520, 136, 64, 0, false, false, false, 0, 1.f, 0.f, true, 1);
+  case_linear("linear bf16 K%64 two stages 70x72x128", CL_BF16, 70, 72, 128, 0, true, false, false, 0, 1.f, 0.f, true, 1);
+  case_linear("linear f32 K%32 600x320x96+32", CL_F32, 600, 320, 96, 32, true, true, false, 0, 1.f, 1.f, true, 1);
   case_linear("linear bf16 M=8 (emb)", CL_BF16, 8, 1280, 320, 32, true, false, false, ACT_SILU, 1.f, 0.f, false, 1);
-
   case_conv("conv3x3 s1 bf16 2x12x12x32->64", CL_BF16, GEMM_CONV_S1, 2, 12, 12, 32, 64);
   case_conv("conv3x3 s1 bf16 big 2x40x40x64->136", CL_BF16, GEMM_CONV_S1, 2, 40, 40, 64, 136);
+  case_conv("conv3x3 s1 bf16 2x16x16x96->320", CL_BF16, GEMM_CONV_S1, 2, 16, 16, 96, 320);
+  case_conv("conv3x3 s1 bf16 deep-K 2x8x8x512->320 (ws split)", CL_BF16, GEMM_CONV_S1, 2, 8, 8, 512, 320);
   case_conv("conv3x3 s2 bf16 2x12x12x32->64", CL_BF16, GEMM_CONV_S2, 2, 12, 12, 32, 64);
   case_conv("conv3x3 up2 bf16 2x6x6x32->64", CL_BF16, GEMM_CONV_UP2, 2, 6, 6, 32, 64);
   case_conv("conv3x3 t2 bf16 2x6x6x32->64", CL_BF16, GEMM_CONV_T2, 2, 6, 6, 32, 64);
+  case_conv("conv3x3 s2 bf16 2x12x12x64->160", CL_BF16, GEMM_CONV_S2, 2, 12, 12, 64, 160);
+  case_conv("conv3x3 up2 bf16 2x6x6x64->72", CL_BF16, GEMM_CONV_UP2, 2, 6, 6, 64, 72);
+  case_conv("conv3x3 t2 bf16 2x6x6x128->64", CL_BF16, GEMM_CONV_T2, 2, 6, 6, 128, 64);
+  case_conv("conv3x3 s1 f32 2x9x7x32->40", CL_F32, GEMM_CONV_S1, 2, 9, 7, 32, 40);
   case_conv("conv3x3 s1 f32 1x9x7x16->24", CL_F32, GEMM_CONV_S1, 1, 9, 7, 16, 24);
+}
+
+int main(int argc, char** argv) {
+  hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, 0));
+  printf("device: %s  CUs=%d  arch=%s\n", prop.name, prop.multiProcessorCount, prop.gcnArchName);
+  HIPCHK(hipMalloc(&g_zero, 4096)); HIPCHK(hipMemset(g_zero, 0, 4096));
+  void* ws; HIPCHK(hipMalloc(&ws, 64 << 20)); gemm_set_workspace(ws, 64 << 20);
+
+  g_gemm_force_cfg = -1; correctness_suite("heuristic config");
+  const int cfgs[] = {0, 1, 2, 5, 8, 9};
+  for (int c : cfgs) { char tag[32]; snprintf(tag, 32, "forced cfg %d", c); g_gemm_force_cfg = c; correctness_suite(tag); }
+  g_gemm_force_cfg = -1;
 
   if (argc > 1 && !strcmp(argv[1], "--time")) {
-    time_case("gemm bf16 4096^3", CL_BF16, GEMM_LINEAR, 4096, 4096, 4096, 0, 0, 0);
-    time_case("gemm bf16 32768x320x320 (to_q @64^2 B8)", CL_BF16, GEMM_LINEAR, 32768, 320, 320, 0, 0, 0);
-    time_case("gemm bf16 32768x320x320+r128 (LoRA)", CL_BF16, GEMM_LINEAR, 32768, 320, 320, 0, 0, 0, 128);
-    time_case("gemm bf16 32768x2560x320 (GEGLU proj)", CL_BF16, GEMM_LINEAR, 32768, 2560, 320, 0, 0, 0);
-    time_case("gemm bf16 8192x1280x1280 (@16^2... )", CL_BF16, GEMM_LINEAR, 2048, 1280, 1280, 0, 0, 0);
-    time_case("conv bf16 320->320 @64^2 B8", CL_BF16, GEMM_CONV_S1, 8 * 64 * 64, 320, 320, 8, 64, 64);
-    time_case("conv bf16 640->640 @32^2 B8", CL_BF16, GEMM_CONV_S1, 8 * 32 * 32, 640, 640, 8, 32, 32);
-    time_case("conv bf16 1280->1280 @16^2 B8", CL_BF16, GEMM_CONV_S1, 8 * 16 * 16, 1280, 1280, 8, 16, 16);
-    time_case("conv bf16 1280->1280 @8^2 B8", CL_BF16, GEMM_CONV_S1, 8 * 8 * 8, 1280, 1280, 8, 8, 8);
-    time_case("conv bf16 2560->1280 @16^2 B8", CL_BF16, GEMM_CONV_S1, 8 * 16 * 16, 1280, 2560, 8, 16, 16);
+    const int tc[] = {6, 1, 2, 5, 8, 9};
+    for (int c : tc) {
+      g_gemm_force_cfg = c;
+      printf("---- timing, cfg %d (-1 heuristic, 6 = round-0 structure)\n", c);
+      time_case("gemm bf16 4096^3", CL_BF16, GEMM_LINEAR, 4096, 4096, 4096, 0, 0, 0);
+      time_case("gemm bf16 32768x320x320 (to_q @64^2 B8)", CL_BF16, GEMM_LINEAR, 32768, 320, 320, 0, 0, 0);
+      time_case("gemm bf16 32768x320x320+r128 (LoRA)", CL_BF16, GEMM_LINEAR, 32768, 320, 320, 0, 0, 0, 128);
+      time_case("gemm bf16 32768x128x320 (LoRA down)", CL_BF16, GEMM_LINEAR, 32768, 128, 320, 0, 0, 0);
+      time_case("gemm bf16 32768x2560x320 (GEGLU proj)", CL_BF16, GEMM_LINEAR, 32768, 2560, 320, 0, 0, 0);
+      time_case("gemm bf16 32768x320x1280 (FF out)", CL_BF16, GEMM_LINEAR, 32768, 320, 1280, 0, 0, 0);
+      time_case("gemm bf16 8192x640x640", CL_BF16, GEMM_LINEAR, 8192, 640, 640, 0, 0, 0);
+      time_case("gemm bf16 2048x1280x1280", CL_BF16, GEMM_LINEAR, 2048, 1280, 1280, 0, 0, 0);
+      time_case("gemm bf16 8192x5120x640 (GEGLU proj 32^2)", CL_BF16, GEMM_LINEAR, 8192, 5120, 640, 0, 0, 0);
+      time_case("gemm bf16 8192x640x2560 (FF out 32^2)", CL_BF16, GEMM_LINEAR, 8192, 640, 2560, 0, 0, 0);
+      time_case("conv bf16 320->320 @64^2 B8", CL_BF16, GEMM_CONV_S1, 8 * 64 * 64, 320, 320, 8, 64, 64);
+      time_case("conv bf16 960->320 @64^2 B8", CL_BF16, GEMM_CONV_S1, 8 * 64 * 64, 320, 960, 8, 64, 64);
+      time_case("conv bf16 640->640 @32^2 B8", CL_BF16, GEMM_CONV_S1, 8 * 32 * 32, 640, 640, 8, 32, 32);
+      time_case("conv bf16 1280->1280 @16^2 B8", CL_BF16, GEMM_CONV_S1, 8 * 16 * 16, 1280, 1280, 8, 16, 16);
+      time_case("conv bf16 1280->1280 @8^2 B8", CL_BF16, GEMM_CONV_S1, 8 * 8 * 8, 1280, 1280, 8, 8, 8);
+      time_case("conv bf16 2560->1280 @16^2 B8", CL_BF16, GEMM_CONV_S1, 8 * 16 * 16, 1280, 2560, 8, 16, 16);
+    }
+    g_gemm_force_cfg = -1;
     time_case("gemm f32 4096x1280x1280", CL_F32, GEMM_LINEAR, 4096, 1280, 1280, 0, 0, 0);
   }
   printf("probe_gemm: %s (%d failures)\n", g_fail ? "FAILED" : "ALL PASS", g_fail);
