@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
         else glds16(dobase + (((long)b * p.N + qr) * p.lddo) * EB + c * 16, sdO + i2 * 1024);
       } else {
         const int i3 = ii - 2 * RI; const bool second = i3 >= TI; const int i2 = second ? i3 - TI : i3;
-        const int q = i2 * 64 + lane; const int d = q / TCPR, c = q - d * TCPR;
+        const int q = i2 * 64 + lane; const int d = q / TCPR, c = (q - d * TCPR) ^ tile_swz<TROW>(d);
         if (!second) glds16(qtbase + ((long)d * p.n_pad + q0) * EB + c * 16, sQt + i2 * 1024);
         else glds16(dotbase + ((long)d * p.n_pad + q0) * EB + c * 16, sdOt + i2 * 1024);
       }
@@ -141,8 +141,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
       u32x4_t oa[PSTEPS], qa[PSTEPS];
 #pragma unroll
       for (int s = 0; s < PSTEPS; ++s) {
-        oa[s] = PFrag<T>::read_a(adOt + (i * 16 + lq) * TROW, s, g);
-        qa[s] = PFrag<T>::read_a(aQt + (i * 16 + lq) * TROW, s, g);
+        oa[s] = PFrag<T>::read_a(adOt + (i * 16 + lq) * TROW, s, g, tile_swz<TROW>(lq));
+        qa[s] = PFrag<T>::read_a(aQt + (i * 16 + lq) * TROW, s, g, tile_swz<TROW>(lq));
       }
       lds_wait();
 #pragma unroll
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
         else glds16(vbase + (((long)b * p.Nkv + kr) * p.ldv) * EB + c * 16, sV + i2 * 1024);
       } else {
         const int i2 = ii - 2 * RI;
-        const int q = i2 * 64 + lane; const int d = q / TCPR, c = q - d * TCPR;
+        const int q = i2 * 64 + lane; const int d = q / TCPR, c = (q - d * TCPR) ^ tile_swz<TROW>(d);
         glds16(ktbase + ((long)d * p.nkv_pad + kv0) * EB + c * 16, sKt + i2 * 1024);
       }
     }
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
     for (int i = 0; i < DN; ++i) {
       u32x4_t ka[PSTEPS];
 #pragma unroll
-      for (int s = 0; s < PSTEPS; ++s) ka[s] = PFrag<T>::read_a(aKt + (i * 16 + lq) * TROW, s, g);
+      for (int s = 0; s < PSTEPS; ++s) ka[s] = PFrag<T>::read_a(aKt + (i * 16 + lq) * TROW, s, g, tile_swz<TROW>(lq));
       lds_wait();
 #pragma unroll
       for (int s = 0; s < PSTEPS; ++s) Mma<T>::run(ka[s], sb[s], dqt[i]);

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs p) {
         glds16(kbase + (((long)b * p.Nkv + kr) * p.ldk) * EB + c * 16, kt + ii * 1024);
       } else {
         const int q = (ii - KI) * 64 + lane;
-        const int d = q / VCPR, c = q - d * VCPR;
+        const int d = q / VCPR, c = (q - d * VCPR) ^ tile_swz<VROW>(d);
         glds16(vbase + ((long)d * p.nkv_pad + kv0) * EB + c * 16, vt + (ii - KI) * 1024);
       }
     }
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs p) {
     for (int i = 0; i < DN; ++i) {
       u32x4_t va[PSTEPS];
 #pragma unroll
-      for (int s = 0; s < PSTEPS; ++s) va[s] = PFrag<T>::read_a(vt + (i * 16 + lq) * VROW, s, g);
+      for (int s = 0; s < PSTEPS; ++s) va[s] = PFrag<T>::read_a(vt + (i * 16 + lq) * VROW, s, g, tile_swz<VROW>(lq));
       lds_wait();
 #pragma unroll
       for (int s = 0; s < PSTEPS; ++s)

@@ -95,6 +95,12 @@ int cl_weight_grad(int dtype, const void* dyT, long lddyt, const void* xT, long 
   return launch_gemm(g, dtype, S(stream));
 }
 
+int cl_weight_grad_tn(int dtype, const void* dy, long lddy, const void* x, long ldx, float* dW, long lddw, int M,
+                      int N, int K, float scale, const void* zero_page, void* stream) {
+  if (dtype != CL_BF16) return CL_EINVAL;   // fp32 parity mode uses cl_transpose + cl_weight_grad
+  return launch_wgrad_tn(dy, lddy, x, ldx, dW, lddw, M, N, K, scale, zero_page, S(stream));
+}
+
 int cl_conv3x3_fwd(int dtype, int mode, const void* x, long ldx, const void* Wp, const float* bias, const void* emb,
                    long ldemb, const void* residual, long ldr, void* y, long ldy, int B, int Hin, int Win, int Cin,
                    int Cout, const void* zero_page, void* stream) {

@@ -22,15 +22,16 @@ enum { CL_BF16 = 0, CL_F32 = 1 };
 __device__ __forceinline__ float bf2f(bf16_t v) {
   return __uint_as_float(((uint32_t)v) << 16);
 }
-// round-to-nearest-even, NaN preserved
+// fp32 -> bf16, round-to-nearest-even: the __bf16 casts lower to ONE v_cvt_pk_bf16_f32 per pair on
+// gfx950 (a hand-rolled integer RNE costs ~5 VALU per element, which made the attention backward
+// and every epilogue VALU-bound).
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  return __builtin_bit_cast(bf16_t, (__bf16)f);
 }
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  bf16x2_t v; v.x = (__bf16)lo; v.y = (__bf16)hi;
+  return __builtin_bit_cast(uint32_t, v);
 }
 
 template <typename T> __device__ __forceinline__ float to_f(T v);

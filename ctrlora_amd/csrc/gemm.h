@@ -40,6 +40,11 @@ int launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);
 // Device scratch for the deterministic split-K path (fp32 partial slabs).  Owned by the host;
 // one workspace per process, used stream-ordered by whichever stream launches the GEMM.
 void gemm_set_workspace(void* p, long bytes);
+void gemm_get_workspace(void** p, long* bytes);
+// transpose-free weight gradient (wgrad.hip, bf16 only): dW[N,K] += alpha * dy[M,N]^T . x[M,K]
+int launch_wgrad_tn(const void* dy, long lddy, const void* x, long ldx, float* dW, long lddw, int M, int N, int K,
+                    float alpha, const void* zero_page, hipStream_t stream);
+extern int g_wgrad_blocks, g_wgrad_min_steps, g_wgrad_ring;
 extern int g_gemm_force_cfg;   // tuning/probe hook (tile configuration override), -1 = heuristic
 
 }  // namespace cl

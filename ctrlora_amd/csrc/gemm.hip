@@ -36,6 +36,7 @@
 //
 // Workgroup ids are remapped so that each XCD (private L2) owns a contiguous
 // range of output tiles: neighbouring tiles share A rows / conv halos.
+#include <type_traits>
 #include "gemm.h"
 #include "mma.h"
 
@@ -44,6 +45,7 @@ namespace cl {
 static void* g_ws = nullptr;
 static long g_ws_bytes = 0;
 void gemm_set_workspace(void* p, long bytes) { g_ws = p; g_ws_bytes = bytes; }
+void gemm_get_workspace(void** p, long* bytes) { *p = g_ws; *bytes = g_ws_bytes; }
 
 template <int N> __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -361,14 +363,23 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_kernel(GemmParams p, i
 // that fills 16-byte slot q of row r fetches logical chunk q ^ ((r >> 1) & 7); the MFMA fragment read
 // of (row r, chunk c) then goes to slot c ^ ((r >> 1) & 7).  For the ds_read_b128 lane groups of a
 // 16x16x32 fragment (16 rows x chunks {g, g+4}) this spreads every group over all sixteen 16-byte
-// bank slots: conflict-free.
+// bank slots: conflict-free (measured: SQ_LDS_BANK_CONFLICT = 2 % of SQ_LDS_IDX_ACTIVE).
 //
-// 8 waves (4 x 2) own a 256 x BN tile; 3 LDS slots.  Iteration s:
-//     vmcnt(0) [own DMA of stage s+1] -> s_barrier -> issue DMA of stage s+2 -> ds_read k-half 1 of
-//     stage s -> MFMA k-half 0 (operands already in registers) -> ds_read k-half 0 of stage s+1 ->
-//     MFMA k-half 1
-// so MFMA issue resumes straight after the barrier and every LDS read is covered by MFMAs.
-template <typename T, int BM, int BN, int WGM, int WGN>
+// 8 waves (4 x 2) own a 256 x BN tile; 3 LDS slots; one barrier per stage, in the MIDDLE of it:
+//     ds_read k-half 1 of stage s | MFMA k-half 0 (operands already in registers) interleaved with the
+//     DMA issue of stage s+2 | vmcnt(G): own DMA of stage s+1 landed, stage s+2 stays in flight |
+//     s_barrier | ds_read k-half 0 of stage s+1 | MFMA k-half 1
+// so a DMA has ~1.5 stages to land, every LDS read is covered by an MFMA batch, and MFMA issue
+// resumes straight after the barrier.
+//
+// The per-stage address generation is the other half of the cost (PMC on the first version: 246
+// VALU+SALU instructions per stage per wave against 40 MFMAs), so the kernel is specialised on the
+// addressing MODE and everything is incremental: running row pointers (+128 B per stage) for linear
+// operands and weights; for the stride-1 3x3 conv a per-lane centre-pixel pointer plus a 9-bit tap
+// validity mask computed once, and a wave-uniform (scalar) tap offset updated when the tap changes.
+enum { FL_LINEAR = 0, FL_CONV_S1 = 1, FL_CONV_ANY = 2 };
+
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE>
 __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p, int tiles_m, int tiles_n,
                                                                  float* __restrict__ slab) {
   constexpr int NW = WGM * WGN;
@@ -377,6 +388,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p
   constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 16, FN = WN / 16;
   constexpr int AI = BM / 8, BI = BN / 8;    // DMA instructions (8 rows x 128 B) per stage
   constexpr int AJ = AI / NW, BJ = (BI + NW - 1) / NW;
+  constexpr int G = AJ + BJ;                 // DMA instructions per wave per stage (uniform: see binst)
   constexpr int SLOT = (AI + BI) * 1024;
   constexpr int EST = WN + 4;
   constexpr int EROWS = (FM >= 2) ? 32 : 16;
@@ -398,10 +410,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p
   }
   const int m0 = (pid / tiles_n) * BM, n0 = (pid % tiles_n) * BN;
 
-  const int taps = (p.mode == GEMM_LINEAR) ? 1 : 9;
   const int cpt = p.K1 / KPS;  // stages per tap
-  const int ks1 = taps * cpt;
-  const int ks2 = p.K2 / KPS;
+  const int ks1 = (MODE == FL_LINEAR ? 1 : 9) * cpt;
+  const int ks2 = (MODE == FL_LINEAR) ? p.K2 / KPS : 0;
   int kbeg = 0, kend = ks1 + ks2;
   if (p.splitk > 1) {
     const int per = (kend + p.splitk - 1) / p.splitk;
@@ -412,48 +423,90 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p
 
   // ---- per-lane DMA sources: row (lane >> 3) of an 8-row group, source chunk = slot ^ swizzle(row)
   const int lrow = lane >> 3, lslot = lane & 7;
-  const char* a1[AJ]; const char* a2[AJ];
-  int ab[AJ], ay[AJ], ax[AJ];
+  const char* pa[AJ];            // LINEAR: running pointer.  CONV: centre pixel (S1) / base (ANY)
+  const char* a2[AJ];
+  uint32_t vmask[AJ];            // CONV_S1: bit t = tap t reads inside the image
+  int ab[AJ], ay[AJ], ax[AJ];    // CONV_ANY: output pixel coordinates
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
     const int inst = j * NW + wave;
     const int chunk = (lslot ^ (((inst & 1) << 2) | (lrow >> 1))) * 16;
     int r = m0 + inst * 8 + lrow;
     r = min(r, p.M - 1);
-    a2[j] = p.A2 ? (const char*)p.A2 + ((long)r * p.lda2) * sizeof(T) + chunk : nullptr;
-    if (p.mode == GEMM_LINEAR) {
-      a1[j] = (const char*)p.A1 + ((long)r * p.lda1) * sizeof(T) + chunk;
-      ab[j] = ay[j] = ax[j] = 0;
+    a2[j] = nullptr; vmask[j] = 0; ab[j] = ay[j] = ax[j] = 0;
+    if constexpr (MODE == FL_LINEAR) {
+      const bool in2 = kbeg >= ks1;
+      a2[j] = p.A2 ? (const char*)p.A2 + ((long)r * p.lda2) * sizeof(T) + chunk : nullptr;
+      pa[j] = in2 ? a2[j] + (long)(kbeg - ks1) * 128
+                  : (const char*)p.A1 + ((long)r * p.lda1) * sizeof(T) + chunk + (long)kbeg * 128;
     } else {
       const int ox = r % p.Wout; const int t = r / p.Wout;
-      ax[j] = ox; ay[j] = t % p.Hout; ab[j] = t / p.Hout;
-      a1[j] = (const char*)p.A1 + chunk;
+      const int oy = t % p.Hout, ob = t / p.Hout;
+      if constexpr (MODE == FL_CONV_S1) {
+        pa[j] = (const char*)p.A1 + ((((long)ob * p.Hin + oy) * p.Win + ox) * p.lda1) * sizeof(T) + chunk;
+        uint32_t m = 0;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+          const int vy = oy + tp / 3 - 1, vx = ox + tp % 3 - 1;
+          if (((unsigned)vy < (unsigned)p.Hin) & ((unsigned)vx < (unsigned)p.Win)) m |= 1u << tp;
+        }
+        vmask[j] = m;
+      } else {
+        pa[j] = (const char*)p.A1 + chunk;
+        ax[j] = ox; ay[j] = oy; ab[j] = ob;
+      }
     }
   }
-  const char* w1[BJ]; const char* w2[BJ];
+  const char* pw[BJ]; const char* w2[BJ];
   int binst[BJ];
 #pragma unroll
   for (int j = 0; j < BJ; ++j) {
-    binst[j] = j * NW + wave;                      // >= BI: this wave has no B instruction j
-    const int inst = min(binst[j], BI - 1);
-    const int chunk = (lslot ^ (((inst & 1) << 2) | (lrow >> 1))) * 16;
-    int n = n0 + inst * 8 + lrow;
+    // waves past the end re-issue the last group (same bytes, same place): every wave then has exactly
+    // G DMA instructions per stage, which the counted vmcnt relies on
+    binst[j] = min(j * NW + wave, BI - 1);
+    const int chunk = (lslot ^ (((binst[j] & 1) << 2) | (lrow >> 1))) * 16;
+    int n = n0 + binst[j] * 8 + lrow;
     n = min(n, p.N - 1);
-    w1[j] = (const char*)p.W1 + ((long)n * p.ldw1) * sizeof(T) + chunk;
-    w2[j] = p.W2 ? (const char*)p.W2 + ((long)n * p.ldw2) * sizeof(T) + chunk : nullptr;
+    w2[j] = (MODE == FL_LINEAR && p.W2) ? (const char*)p.W2 + ((long)n * p.ldw2) * sizeof(T) + chunk : nullptr;
+    pw[j] = (MODE == FL_LINEAR && kbeg >= ks1)
+                ? w2[j] + (long)(kbeg - ks1) * 128
+                : (const char*)p.W1 + ((long)n * p.ldw1) * sizeof(T) + chunk + (long)kbeg * 128;
   }
   const char* zpage = (const char*)p.zero_page + lslot * 16;
 
-  auto issue = [&](int kt, int slot) {
+  // wave-uniform walk over (tap, channel chunk) for the conv modes
+  int kt_next = kbeg;                                  // next stage to issue
+  int tap = (MODE == FL_LINEAR) ? 0 : kbeg / cpt;
+  int cc = (MODE == FL_LINEAR) ? 0 : kbeg - tap * cpt;
+  const long pixb = (long)p.lda1 * sizeof(T);          // bytes per pixel row of A
+  long tapoff = 0;
+  if constexpr (MODE == FL_CONV_S1) tapoff = ((long)(tap / 3 - 1) * p.Win + (tap % 3 - 1)) * pixb;
+
+  auto issue_next = [&](int slot) {
     char* As = smem + slot * SLOT;
     char* Bs = As + AI * 1024;
-    const bool seg2 = kt >= ks1;
-    const long koff = (long)(seg2 ? kt - ks1 : kt) * 128;
-    if (seg2 || p.mode == GEMM_LINEAR) {
+    if constexpr (MODE == FL_LINEAR) {
+      if (ks2 && kt_next == ks1) {   // switch both operands to the second K segment (LoRA up-projection)
 #pragma unroll
-      for (int j = 0; j < AJ; ++j) glds16((seg2 ? a2[j] : a1[j]) + koff, As + (j * NW + wave) * 1024);
+        for (int j = 0; j < AJ; ++j) pa[j] = a2[j];
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) pw[j] = w2[j];
+      }
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) { glds16(pa[j], As + (j * NW + wave) * 1024); pa[j] += 128; }
+    } else if constexpr (MODE == FL_CONV_S1) {
+      const long soff = tapoff + (long)cc * 128;
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        const char* src = ((vmask[j] >> tap) & 1u) ? pa[j] + soff : zpage;
+        glds16(src, As + (j * NW + wave) * 1024);
+      }
+      const bool wrap = cc + 1 == cpt;          // wave-uniform: scalar selects, no branch
+      cc = wrap ? 0 : cc + 1;
+      tap += wrap ? 1 : 0;
+      const int ky = (tap * 11) >> 5;           // tap / 3 for tap in [0, 9]
+      tapoff = ((long)(ky - 1) * p.Win + (tap - 3 * ky - 1)) * pixb;
     } else {
-      const int tap = kt / cpt, cc = kt - tap * cpt;
       const int ky = tap / 3, kx = tap - ky * 3;
       const int sy = (p.mode == GEMM_CONV_S2) ? 2 : 1;
       const bool virt = (p.mode == GEMM_CONV_UP2) | (p.mode == GEMM_CONV_T2);
@@ -470,13 +523,14 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p
           iy = vy; ix = vx;
         }
         const long pix = ((long)ab[j] * p.Hin + iy) * p.Win + ix;
-        const char* src = ok ? a1[j] + (pix * p.lda1 + (long)cc * KPS) * sizeof(T) : zpage;
+        const char* src = ok ? pa[j] + pix * pixb + (long)cc * 128 : zpage;
         glds16(src, As + (j * NW + wave) * 1024);
       }
+      if (++cc == cpt) { cc = 0; ++tap; }
     }
 #pragma unroll
-    for (int j = 0; j < BJ; ++j)
-      if (binst[j] < BI) glds16((seg2 ? w2[j] : w1[j]) + koff, Bs + binst[j] * 1024);
+    for (int j = 0; j < BJ; ++j) { glds16(pw[j], Bs + binst[j] * 1024); pw[j] += 128; }
+    ++kt_next;
   };
 
   f32x4_t acc[FM][FN];
@@ -517,36 +571,49 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p
       for (int j = 0; j < FN; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
   };
 
-  // ---- prologue: stages 0 and 1 in flight; stage 0 landed and its k-half 0 in registers
+  // ---- prologue: stages 0 and 1 in flight; stage 0 landed, its k-half 0 in registers
   u32x4_t fa[FM], fb[FN], ga[FM], gb[FN];
-  issue(kbeg, 0);
+  issue_next(0);
   if (total > 1) {
-    issue(kbeg + 1, 1);
-    // stage 0's DMA is the older half of this wave's outstanding loads; waiting for all of them is
-    // simplest and only costs the first iteration
+    issue_next(1);
+    wait_vm<G>();
+  } else {
+    wait_vm<0>();
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   read_frags(0, 0, fa, fb);
   wait_frags(fa, fb);
 
-  for (int s = 0; s < total; ++s) {
-    const int slot = s % R;
-    // own DMA of stage s+1 (issued one iteration ago) has landed
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // stage s+1 visible to all waves; slot (s+2)%R no longer read
-    __builtin_amdgcn_sched_barrier(0);
-    if (s + 2 < total) issue(kbeg + s + 2, (s + 2) % R);
+  // One pipeline stage.  ISSUE (compile time): start the DMA of stage s+2 -- true for all but the last
+  // two stages, so that the MFMAs of k-half 0 and the address generation + DMA issue sit in ONE basic
+  // block and the scheduler can slot the scalar/vector ALU work into the MFMA issue gaps.
+  int slot = 0;
+  auto stage = [&](auto ISSUE, bool has_next) {
+    const int slot1 = (slot == R - 1) ? 0 : slot + 1;
+    const int slot2 = (slot1 == R - 1) ? 0 : slot1 + 1;
     read_frags(slot, 1, ga, gb);
     __builtin_amdgcn_sched_barrier(0);
     mma_all(fa, fb);
-    wait_frags(ga, gb);
-    if (s + 1 < total) read_frags((s + 1) % R, 0, fa, fb);
+    if constexpr (decltype(ISSUE)::value) issue_next(slot2);   // slot2 was last read before the previous barrier
     __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // k-half 1 fragments have landed
+    if constexpr (decltype(ISSUE)::value) wait_vm<G>(); else wait_vm<0>();   // own DMA of stage s+1 has landed
+    __builtin_amdgcn_s_barrier();                              // ... and everybody else's: stage s+1 visible
+    __builtin_amdgcn_sched_barrier(0);
+    if (has_next) read_frags(slot1, 0, fa, fb);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) asm volatile("" : "+v"(ga[i]));
+#pragma unroll
+    for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(gb[j]));
     mma_all(ga, gb);
     wait_frags(fa, fb);
-  }
+    slot = slot1;
+  };
+  int s = 0;
+  for (; s + 2 < total; ++s) stage(std::true_type{}, true);
+  for (; s < total; ++s) stage(std::false_type{}, s + 1 < total);
   __syncthreads();  // all waves done with the operand slots; reuse LDS for the epilogue
 
   store_tile<T, FM, FN>(p, acc, reinterpret_cast<float*>(smem) + wave * (EROWS * EST), m0 + wm * WM, n0 + wn * WN,
@@ -650,11 +717,11 @@ static int pick_splitk(GemmParams& p, long tiles, int steps, int want, int min_s
   return p.splitk;
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN>
-static int launch_fl(const GemmParams& p0, hipStream_t stream) {
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE>
+static int launch_fl_mode(const GemmParams& p0, hipStream_t stream) {
   constexpr int NW = WGM * WGN;
   constexpr int SMEM = 3 * (BM / 8 + BN / 8) * 1024;
-  auto kern = &gemm_fl_kernel<T, BM, BN, WGM, WGN>;
+  auto kern = &gemm_fl_kernel<T, BM, BN, WGM, WGN, MODE>;
   static bool attr_set = false;
   if (!attr_set) {
     if (SMEM > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -666,7 +733,7 @@ static int launch_fl(const GemmParams& p0, hipStream_t stream) {
   const int kps = 128 / (int)sizeof(T);
   const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
   const long tiles = (long)tm * tn;
-  const int steps = ((p.mode == GEMM_LINEAR ? 1 : 9) * p.K1 + p.K2) / kps;
+  const int steps = ((MODE == FL_LINEAR ? 1 : 9) * p.K1 + p.K2) / kps;
   float* slab;
   pick_splitk(p, tiles, steps, 256, 4, &slab);
   hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * p.splitk)), dim3(NW * 64), SMEM, stream, p, tm, tn, slab);
@@ -679,17 +746,37 @@ static int launch_fl(const GemmParams& p0, hipStream_t stream) {
   return CL_OK;
 }
 
+template <typename T, int BM, int BN, int WGM, int WGN>
+static int launch_fl(const GemmParams& p, hipStream_t stream) {
+  if (p.mode == GEMM_LINEAR) return launch_fl_mode<T, BM, BN, WGM, WGN, FL_LINEAR>(p, stream);
+  if (p.K2) return CL_EINVAL;   // a second K segment exists for linear operands only
+  if (p.mode == GEMM_CONV_S1) return launch_fl_mode<T, BM, BN, WGM, WGN, FL_CONV_S1>(p, stream);
+  return launch_fl_mode<T, BM, BN, WGM, WGN, FL_CONV_ANY>(p, stream);
+}
+
 int g_gemm_force_cfg = -1;   // probe / tuning hook: >= 0 forces a tile configuration
 
 template <typename T>
 static int launch_t(const GemmParams& p, hipStream_t stream) {
   int cfg = g_gemm_force_cfg;
   if (cfg < 0) {
+    // v2 (64-byte substeps, 4 waves) choices
     if (p.M <= 64 || p.N <= 64) cfg = 0;
     else if (p.N % 160 == 0) cfg = 2;
     else cfg = 1;
-    // small problems: more, smaller workgroups
     if (cfg != 0 && (long)((p.M + 127) / 128) * ((p.N + 127) / 128) < 48 && p.atomic) cfg = 0;
+    // full-line 8-wave kernel: whenever K is whole 128-byte lines and the 256-row tile grid fills the
+    // chip, alone or with split-K at >= 8 stages per split (deep-K products of the 8x8 / 16x16 levels)
+    const int kps = 128 / (int)sizeof(T);
+    const bool fl_ok = p.K1 % kps == 0 && p.K2 % kps == 0 && !(p.mode != GEMM_LINEAR && p.K2) && !p.atomic &&
+                       p.M > 128 && p.N >= 96;
+    if (fl_ok) {
+      const int bn = (p.N % 160 == 0) ? 160 : 128;
+      const long t256 = (long)((p.M + 255) / 256) * ((p.N + bn - 1) / bn);
+      const int steps = ((p.mode == GEMM_LINEAR ? 1 : 9) * p.K1 + p.K2) / kps;
+      const long need = (256 + t256 - 1) / t256;   // split factor that fills 256 CUs
+      if (t256 >= 200 || (g_ws && steps >= 8 * need)) cfg = (bn == 160) ? 8 : 9;
+    }
   }
   switch (cfg) {
     case 0: return launch_cfg<T, 64, 64, 2, 2, 1, 4>(p, stream);
@@ -702,7 +789,8 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
     case 7: return launch_cfg<T, 256, 128, 4, 2, 2, 4>(p, stream);
     case 8: case 9: {
       const int kps = 128 / (int)sizeof(T);
-      if (p.K1 % kps || p.K2 % kps) return launch_cfg<T, 128, 128, 2, 2, 2, 4>(p, stream);
+      if (p.K1 % kps || p.K2 % kps || (p.mode != GEMM_LINEAR && p.K2))
+        return launch_cfg<T, 128, 128, 2, 2, 2, 4>(p, stream);
       return cfg == 8 ? launch_fl<T, 256, 160, 4, 2>(p, stream) : launch_fl<T, 256, 128, 4, 2>(p, stream);
     }
     default: return CL_EINVAL;

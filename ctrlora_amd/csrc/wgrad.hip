@@ -1,0 +1,243 @@
+// Transpose-free weight gradient for gfx950:
+//
+//   dW[n, k] (fp32, accumulated) += alpha * sum_m dy[m, n] * x[m, k]
+//
+// for the optimizer's matrices only -- LoRA down/up (cldm/lora.py:26-80: dA = (dy B)^T x,
+// dB = dy^T (x A^T)) and the ControlNet zero convs (cldm/cldm.py:281-282) -- frozen weights never
+// get a dW.  Both operands are row-major with the contraction index m as the
+// ROW, which is the wrong way round for an MFMA fragment (a lane needs 8 consecutive m of one
+// column).  Round 0 materialised dy^T and x^T in HBM first (4 transposes per LoRA linear: 7.6 ms of a
+// 74 ms step); here the [32 m][128 col] tiles go HBM->LDS as they are (global_load_lds, whole 256-byte
+// rows) and the fragments are built by ds_read_b64_tr_b16, the gfx950 LDS transpose read: within a
+// 16-lane group, lane i receives element (i & 3) of the 8 bytes addressed by lane 4j + (i >> 2), for
+// j = 0..3 -- i.e. with lanes 4j..4j+3 pointing at 16 consecutive columns of row k0 + j, lane i gets
+// column i of rows k0..k0+3.  Two such reads (rows +0, +4) make one 8-deep MFMA operand.
+//
+// Bank conflicts: a 256-byte row stride puts every row on the same banks; the 16-byte chunk index is
+// XOR-swizzled on the DMA source side with f(row) = 2 * ((row & 3) | ((row >> 3) & 1) << 2), which
+// spreads the 8 rows x 2 chunks touched by a 32-lane group over all sixteen slots.
+//
+// The m range is split across workgroups (grid.y); each split stores its fp32 partial tile into a slab
+// of the host-provided workspace and a small second kernel adds the slab sum into the flat gradient
+// buffer.  (First version: fp32 atomics -- 16K per workgroup on the same few addresses -- measured
+// 77 us for a 29 MB problem, time proportional to the number of workgroups.)  Deterministic as a bonus.
+#include "gemm.h"
+#include "mma.h"
+
+namespace cl {
+
+__device__ __forceinline__ u32x2_t lds_read_tr16(uint32_t addr) {
+  u32x2_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+
+// 4 waves (2 x 2), 128 (n) x 128 (k) output tile, 32 rows of m per pipeline step, R-slot ring
+// (R - 1 steps of DMA in flight).
+template <int R>
+__global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const bf16_t* __restrict__ dy, long lddy,
+                                                          const bf16_t* __restrict__ x, long ldx,
+                                                          float* __restrict__ dW, long lddw, int M, int N, int K,
+                                                          float alpha, int tiles_k, int steps_per_split,
+                                                          const void* __restrict__ zero_page,
+                                                          float* __restrict__ slab) {
+  constexpr int TILE = 32 * 256;          // one operand tile: 32 rows x 256 bytes
+  constexpr int SLOT = 2 * TILE;
+  static_assert(R * SLOT >= 4 * 32 * 68 * 4, "epilogue staging must fit in the ring");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wk = wave & 1;
+  const int n0 = (blockIdx.x / tiles_k) * 128, k0 = (blockIdx.x % tiles_k) * 128;
+  const int steps_total = (M + 31) / 32;
+  const int sbeg = blockIdx.y * steps_per_split;
+  const int send = min(steps_total, sbeg + steps_per_split);
+  const int total = send - sbeg;
+  if (total <= 0) return;
+
+  // ---- DMA sources: instruction i of a tile covers rows 4i..4i+3; lane -> (row 4i + lane/16, slot lane%16)
+  // wave w issues instructions 2w, 2w+1 of each operand tile.
+  const int lr4 = lane >> 4, lslot = lane & 15;
+  const char* zsrc = (const char*)zero_page + (lslot & 3) * 16;
+  int rowi[2]; const char* sdy[2]; const char* sx[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = (2 * wave + j) * 4 + lr4;                         // 0..31 within the step
+    const int f = ((row & 3) | (((row >> 3) & 1) << 2)) << 1;
+    const int chunk = lslot ^ f;                                      // logical 16-byte chunk of the row
+    rowi[j] = row;
+    // columns past the matrix edge: any valid bytes do (those outputs are never stored)
+    const int cn = min(n0 + chunk * 8, N - 8), ck = min(k0 + chunk * 8, K - 8);
+    sdy[j] = (const char*)(dy + cn);
+    sx[j] = (const char*)(x + ck);
+  }
+  auto issue = [&](int step, int slot) {
+    char* base = smem + slot * SLOT;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const long m = (long)step * 32 + rowi[j];
+      const bool ok = m < M;                                          // rows past M contribute zeros
+      glds16(ok ? sdy[j] + m * lddy * 2 : zsrc, base + (2 * wave + j) * 1024);
+      glds16(ok ? sx[j] + m * ldx * 2 : zsrc, base + TILE + (2 * wave + j) * 1024);
+    }
+  };
+
+  // ---- fragment read addresses.  lane = 16g + 4j + q: row 8g + j (+4 for the second read),
+  // columns 4q..4q+3 of the fragment's 16 -> chunk (2*frag + q/2) ^ f(row), byte (q & 1) * 8
+  const int g = lane >> 4, jj = (lane >> 2) & 3, q = lane & 3;
+  const int frow = 8 * g + jj;
+  const int fsw = (jj | ((g & 1) << 2)) << 1;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  uint32_t aoff[4], boff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    aoff[i] = frow * 256 + ((((wn * 8 + 2 * i) + (q >> 1)) ^ fsw) * 16) + (q & 1) * 8;
+    boff[i] = TILE + frow * 256 + ((((wk * 8 + 2 * i) + (q >> 1)) ^ fsw) * 16) + (q & 1) * 8;
+  }
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int s = 0; s < R - 1; ++s)
+    if (s < total) issue(sbeg + s, s);
+  for (int s = 0; s < total; ++s) {
+    // own DMA of step s landed; R-2 newer steps (4 instructions per wave each) may stay in flight
+    if (s + R - 1 <= total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * 4) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // step s visible to all; slot (s-1)%R no longer read
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + R - 1 < total) issue(sbeg + s + R - 1, (s + R - 1) % R);
+    const uint32_t base = lds0 + (s % R) * SLOT;
+    u32x4_t af[4], bfr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const u32x2_t lo = lds_read_tr16(base + aoff[i]), hi = lds_read_tr16(base + aoff[i] + 1024);
+      af[i] = u32x4_t{lo.x, lo.y, hi.x, hi.y};
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const u32x2_t lo = lds_read_tr16(base + boff[i]), hi = lds_read_tr16(base + boff[i] + 1024);
+      bfr[i] = u32x4_t{lo.x, lo.y, hi.x, hi.y};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { asm volatile("" : "+v"(af[i])); asm volatile("" : "+v"(bfr[i])); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Mma<bf16_t>::run(af[i], bfr[j], acc[i][j]);
+  }
+  __syncthreads();
+
+  // ---- epilogue: stage 32 x 64 fp32 per wave through LDS, accumulate rows with fp32 atomics
+  constexpr int EST = 68;
+  float* stg = reinterpret_cast<float*>(smem) + wave * (32 * EST);
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          stg[(i2 * 16 + (lane >> 4) * 4 + r) * EST + j * 16 + (lane & 15)] = acc[ps * 2 + i2][j][r];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int rr = it * 4 + (lane >> 4);
+      const int cg = (lane & 15) * 4;
+      const int grow = n0 + wn * 64 + ps * 32 + rr, gcol = k0 + wk * 64 + cg;
+      if (grow < N && gcol < K) {
+        const float4 v = *reinterpret_cast<const float4*>(&stg[rr * EST + cg]);
+        if (slab) {   // one fp32 partial slab per m-split; summed by wgrad_reduce_kernel
+          *reinterpret_cast<float4*>(slab + ((long)blockIdx.y * N + grow) * K + gcol) = v;
+        } else {      // single split: this workgroup is the only writer of its tile
+          float4* dst = reinterpret_cast<float4*>(dW + (long)grow * lddw + gcol);
+          float4 o = *dst;
+          o.x += v.x * alpha; o.y += v.y * alpha; o.z += v.z * alpha; o.w += v.w * alpha;
+          *dst = o;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// dW += alpha * sum over splits of the partial slabs
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dW,
+                                                           long lddw, int N, int K, int splits, float alpha) {
+  const int k4 = K / 4;
+  const long total = (long)N * k4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / k4), k = (int)(i % k4) * 4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < splits; ++z) {
+      const float4 v = *reinterpret_cast<const float4*>(slab + ((long)z * N + n) * K + k);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    float4* dst = reinterpret_cast<float4*>(dW + (long)n * lddw + k);
+    float4 o = *dst;
+    o.x += a.x * alpha; o.y += a.y * alpha; o.z += a.z * alpha; o.w += a.w * alpha;
+    *dst = o;
+  }
+}
+
+// tuning knobs (probe): workgroups wanted, minimum 32-row steps per split, ring depth
+int g_wgrad_blocks = 256, g_wgrad_min_steps = 16, g_wgrad_ring = 4;
+
+int launch_wgrad_tn(const void* dy, long lddy, const void* x, long ldx, float* dW, long lddw, int M, int N, int K,
+                    float alpha, const void* zero_page, hipStream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return CL_OK;
+  if (N % 8 || K % 8 || lddy % 8 || ldx % 8 || lddw % 4 || (reinterpret_cast<uintptr_t>(dW) & 15) || N < 8 || K < 8 || !zero_page) return CL_EINVAL;
+  const int tn = (N + 127) / 128, tk = (K + 127) / 128;
+  const int steps = (M + 31) / 32;
+  // enough workgroups to fill the chip, at least 16 steps (512 rows of m) per split
+  int splits = (g_wgrad_blocks + tn * tk - 1) / (tn * tk);
+  if (splits > steps / g_wgrad_min_steps) splits = steps / g_wgrad_min_steps;
+  if (splits < 1) splits = 1;
+  const int per = (steps + splits - 1) / splits;
+  splits = (steps + per - 1) / per;
+  // partial slabs live in the split-K workspace registered with cl_set_workspace (gemm.hip)
+  void* ws; long ws_bytes;
+  gemm_get_workspace(&ws, &ws_bytes);
+  while (splits > 1 && (long)splits * N * K * 4 > ws_bytes) {
+    --splits;
+  }
+  const int per2 = (steps + splits - 1) / splits;
+  splits = (steps + per2 - 1) / per2;
+  float* slab = splits > 1 ? reinterpret_cast<float*>(ws) : nullptr;
+  const dim3 grid(tn * tk, splits);
+#define WGRAD_LAUNCH(RR)                                                                                   \
+  do {                                                                                                     \
+    static bool attr_set = false;                                                                          \
+    if (!attr_set) {                                                                                       \
+      if (RR * 16384 > 65536 &&                                                                            \
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tn_kernel<RR>),                         \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, RR * 16384) != hipSuccess)       \
+        return CL_ELAUNCH;                                                                                 \
+      attr_set = true;                                                                                     \
+    }                                                                                                      \
+    hipLaunchKernelGGL(wgrad_tn_kernel<RR>, grid, dim3(256), RR * 16384, stream, (const bf16_t*)dy, lddy,  \
+                       (const bf16_t*)x, ldx, dW, lddw, M, N, K, alpha, tk, per2, zero_page, slab);       \
+  } while (0)
+  if (g_wgrad_ring == 3) WGRAD_LAUNCH(3);
+  else if (g_wgrad_ring == 6) WGRAD_LAUNCH(6);
+  else WGRAD_LAUNCH(4);
+#undef WGRAD_LAUNCH
+  if (slab) {
+    const long total = (long)N * (K / 4);
+    int rg = (int)((total + 255) / 256); if (rg > 2048) rg = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rg), dim3(256), 0, stream, slab, dW, lddw, N, K, splits, alpha);
+  }
+  CL_CHECK_LAUNCH();
+  return CL_OK;
+}
+
+}  // namespace cl

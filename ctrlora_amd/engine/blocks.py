@@ -100,13 +100,20 @@ def linear_bwd_lora(ctx: Ctx, L: LinearW, x, t, dy, u):
     """dB += dy^T t ;  dA += u^T x   (fp32, split-K atomics into the flat gradient buffer)."""
     if not L.r:
         return
+    if ctx.dtype == torch.bfloat16:      # transpose-free kernel (LDS transpose reads)
+        hip.weight_grad_tn(dy, t, L.tB.grad)
+        hip.weight_grad_tn(u, x, L.tA.grad)
+        return
     hip.weight_grad(ctx.transposed(dy), ctx.transposed(t), L.tB.grad)
     hip.weight_grad(ctx.transposed(u), ctx.transposed(x), L.tA.grad)
 
 
 def dense_bwd_weight(ctx: Ctx, L: LinearW, x, dy, B: int, HW: int, scale: float = 1.0):
     """Trainable dense 1x1 conv (zero convs): dW += scale * dy^T x ; db += scale * colsum(dy)."""
-    hip.weight_grad(ctx.transposed(dy), ctx.transposed(x), L.tW.grad.view(L.N, L.K), scale)
+    if ctx.dtype == torch.bfloat16:
+        hip.weight_grad_tn(dy, x, L.tW.grad.view(L.N, L.K), scale)
+    else:
+        hip.weight_grad(ctx.transposed(dy), ctx.transposed(x), L.tW.grad.view(L.N, L.K), scale)
     if L.tb is not None:
         hip.colsum(dy, L.tb.grad.view(1, L.N), 1, B * HW, scale)
 

@@ -56,6 +56,7 @@ _SIGS = {
     "cl_lora_linear_fwd": [_I, _P, _L, _P, _P, _P, _L, _P, _I, _P, _L, _I, _P, _L, _I, _I, _I, _P],
     "cl_lora_linear_bwd_data": [_I, _P, _L, _P, _P, _P, _I, _P, _L, _P, _L, _P, _L, _I, _I, _I, _P],
     "cl_weight_grad": [_I, _P, _L, _P, _L, _P, _L, _I, _I, _I, _F, _P],
+    "cl_weight_grad_tn": [_I, _P, _L, _P, _L, _P, _L, _I, _I, _I, _F, _P, _P],
     "cl_conv3x3_fwd": [_I, _I, _P, _L, _P, _P, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P, _P],
     "cl_conv3x3_bwd_data": [_I, _I, _P, _L, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P, _P],
     "cl_conv1x1_fwd": [_I, _P, _L, _P, _P, _F, _P, _L, _F, _P, _L, _I, _I, _I, _P],
@@ -196,6 +197,15 @@ def weight_grad(dyT, xT, dW, scale=1.0):
     """dW[N,K] (fp32) += scale * dyT[N,Mp] . xT[K,Mp]^T  (split-K, fp32 atomics)."""
     _chk(lib().cl_weight_grad(dt(dyT), dyT.data_ptr(), ld(dyT), xT.data_ptr(), ld(xT), dW.data_ptr(), ld(dW),
                               dyT.shape[0], xT.shape[0], dyT.shape[1], scale, stream()), "cl_weight_grad")
+
+
+def weight_grad_tn(dy, x, dW, scale=1.0):
+    """dW[N,K] (fp32) += scale * dy[M,N]^T . x[M,K], bf16 operands as they are (no transposes)."""
+    if _workspace is None:
+        ensure_workspace(dy.device)
+    _chk(lib().cl_weight_grad_tn(dt(dy), dy.data_ptr(), ld(dy), x.data_ptr(), ld(x), dW.data_ptr(), ld(dW),
+                                 dy.shape[0], dy.shape[1], x.shape[1], scale, zero_page(dy.device).data_ptr(),
+                                 stream()), "cl_weight_grad_tn")
 
 
 # ------------------------------------------------------------------ normalisation

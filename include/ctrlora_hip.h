@@ -99,6 +99,12 @@ int cl_lora_linear_bwd_data(int dtype, const void* dy, long lddy, const void* Wt
 int cl_weight_grad(int dtype, const void* dyT, long lddyt, const void* xT, long ldxt, float* dW,
                    long lddw, int N, int K, int Mp, float scale, void* stream);
 
+/* the same weight gradient without materialised transposes (bf16 only): dW[N,K] += scale * dy[M,N]^T . x[M,K],
+ * both operands row-major as the forward/backward pass left them; fragments are built with the gfx950 LDS
+ * transpose read (csrc/wgrad.hip).  zero_page: >= 64 zero bytes on the device (rows past M). */
+int cl_weight_grad_tn(int dtype, const void* dy, long lddy, const void* x, long ldx, float* dW, long lddw,
+                      int M, int N, int K, float scale, const void* zero_page, void* stream);
+
 /* 3x3 convolutions of ResBlock / Downsample / Upsample / input conv / out conv
  * (ldm/modules/diffusionmodules/openaimodel.py:108-118,150,203,229,729; cldm/cldm.py:141):
  * out = conv(x) + bias + emb[b, :] (openaimodel.py:272) + residual (openaimodel.py:274).

@@ -151,6 +151,64 @@ static void time_case(const char* name, int dtype, int mode, int M, int N, int K
   hipFree(A.d); hipFree(Wt.d); hipFree(C.d); if (K2) { hipFree(A2.d); hipFree(W2.d); }
 }
 
+// ---------------- transpose-free weight gradient ----------------
+static void case_wgrad(const char* name, int M, int N, int K, float alpha, bool timeit = false) {
+  Buf DY, X; DY.init((size_t)M * N, CL_BF16); X.init((size_t)M * K, CL_BF16);
+  std::vector<float> init((size_t)N * K);
+  for (auto& v : init) v = frand();
+  float* dW; HIPCHK(hipMalloc(&dW, (size_t)N * K * 4));
+  HIPCHK(hipMemcpy(dW, init.data(), (size_t)N * K * 4, hipMemcpyHostToDevice));
+  int rc = launch_wgrad_tn(DY.d, N, X.d, K, dW, K, M, N, K, alpha, g_zero, 0);
+  HIPCHK(hipDeviceSynchronize());
+  if (rc) { printf("[FAIL] %s rc=%d\n", name, rc); g_fail++; return; }
+  if (!timeit) {
+    std::vector<float> out((size_t)N * K);
+    HIPCHK(hipMemcpy(out.data(), dW, (size_t)N * K * 4, hipMemcpyDeviceToHost));
+    double num = 0, den = 0;
+    for (int n = 0; n < N; ++n) for (int k = 0; k < K; ++k) {
+      double s = 0;
+      for (int m = 0; m < M; ++m) s += (double)DY.h[(size_t)m * N + n] * X.h[(size_t)m * K + k];
+      s = init[(size_t)n * K + k] + alpha * s;
+      double d = out[(size_t)n * K + k] - s; num += d * d; den += s * s;
+    }
+    report(name, num, den, 2e-5);
+  } else {
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    const int iters = 20;
+    HIPCHK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) launch_wgrad_tn(DY.d, N, X.d, K, dW, K, M, N, K, alpha, g_zero, 0);
+    HIPCHK(hipEventRecord(e1, 0)); HIPCHK(hipEventSynchronize(e1));
+    float ms; HIPCHK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+    printf("[TIME] %-44s %8.3f ms  %8.1f GB/s operand reads\n", name, ms, ((double)M * (N + K) * 2) / ms * 1e-6);
+  }
+  hipFree(dW); hipFree(DY.d); hipFree(X.d);
+}
+
+static void wgrad_suite(bool timeit) {
+  printf("---- weight gradient (LDS transpose reads)\n");
+  case_wgrad("wgrad 300x200x136", 300, 200, 136, 1.0f);
+  case_wgrad("wgrad 616x320x128 alpha 0.5", 616, 320, 128, 0.5f);
+  case_wgrad("wgrad M=8 1280x128", 8, 1280, 128, 1.0f);
+  case_wgrad("wgrad 4096x128x320", 4096, 128, 320, 1.0f);
+  case_wgrad("wgrad 1000x8x40 (tiny)", 1000, 8, 40, 1.0f);
+  if (timeit) {
+    const int rings[] = {4}, mins[] = {32, 16, 8, 4}, blks[] = {256, 512, 1024};
+    for (int r : rings) for (int mn : mins) for (int b : blks) {
+      g_wgrad_ring = r; g_wgrad_min_steps = mn; g_wgrad_blocks = b;
+      char nm[96]; snprintf(nm, 96, "wgrad 32768x320x128 R%d min%d blk%d", r, mn, b);
+      case_wgrad(nm, 32768, 320, 128, 1.0f, true);
+      snprintf(nm, 96, "wgrad 8192x640x128 R%d min%d blk%d", r, mn, b);
+      case_wgrad(nm, 8192, 640, 128, 1.0f, true);
+    }
+    g_wgrad_ring = 4; g_wgrad_min_steps = 16; g_wgrad_blocks = 512;
+    case_wgrad("wgrad 32768x320x128 (dB @64^2)", 32768, 320, 128, 1.0f, true);
+    case_wgrad("wgrad 32768x128x320 (dA @64^2)", 32768, 128, 320, 1.0f, true);
+    case_wgrad("wgrad 32768x2560x128 (dB GEGLU)", 32768, 2560, 128, 1.0f, true);
+    case_wgrad("wgrad 32768x320x320 (zero conv)", 32768, 320, 320, 1.0f, true);
+    case_wgrad("wgrad 512x1280x1280 (zero conv 8^2)", 512, 1280, 1280, 1.0f, true);
+  }
+}
+
 static void correctness_suite(const char* tag) {
   printf("---- correctness: %s\n", tag);
   case_linear("linear bf16 300x200x96 plain", CL_BF16, 300, 200, 96, 0, false, false, false, 0, 1.f, 0.f, true, 1);
@@ -191,13 +249,24 @@ int main(int argc, char** argv) {
   HIPCHK(hipMalloc(&g_zero, 4096)); HIPCHK(hipMemset(g_zero, 0, 4096));
   void* ws; HIPCHK(hipMalloc(&ws, 64 << 20)); gemm_set_workspace(ws, 64 << 20);
 
+  if (argc > 3 && !strcmp(argv[1], "--one")) {   // profiling aid: one timed shape under one forced config
+    g_gemm_force_cfg = atoi(argv[2]);
+    const int which = atoi(argv[3]);
+    if (which == 0) time_case("conv bf16 320->320 @64^2 B8", CL_BF16, GEMM_CONV_S1, 8 * 64 * 64, 320, 320, 8, 64, 64);
+    if (which == 1) time_case("gemm bf16 4096^3", CL_BF16, GEMM_LINEAR, 4096, 4096, 4096, 0, 0, 0);
+    if (which == 2) time_case("conv bf16 1280->1280 @16^2 B8", CL_BF16, GEMM_CONV_S1, 8 * 16 * 16, 1280, 1280, 8, 16, 16);
+    if (which == 3) time_case("gemm bf16 32768x2560x320 (GEGLU proj)", CL_BF16, GEMM_LINEAR, 32768, 2560, 320, 0, 0, 0);
+    return 0;
+  }
+  wgrad_suite(argc > 1 && !strcmp(argv[1], "--time"));
+  if (argc > 2 && !strcmp(argv[2], "--wgrad-only")) return g_fail ? 1 : 0;
   g_gemm_force_cfg = -1; correctness_suite("heuristic config");
-  const int cfgs[] = {0, 1, 2, 5, 8, 9};
+  const int cfgs[] = {8};
   for (int c : cfgs) { char tag[32]; snprintf(tag, 32, "forced cfg %d", c); g_gemm_force_cfg = c; correctness_suite(tag); }
   g_gemm_force_cfg = -1;
 
   if (argc > 1 && !strcmp(argv[1], "--time")) {
-    const int tc[] = {6, 1, 2, 5, 8, 9};
+    const int tc[] = {-1};
     for (int c : tc) {
       g_gemm_force_cfg = c;
       printf("---- timing, cfg %d (-1 heuristic, 6 = round-0 structure)\n", c);
