@@ -326,6 +326,15 @@ static int dispatch_bwd(const AttnBwdArgs& a, hipStream_t st) {
   }
 }
 
+int attn_delta(const AttnBwdArgs& a, hipStream_t st) {
+  const long total = (long)a.B * a.H * a.N;
+  int dgrid = (int)((total + 255) / 256); if (dgrid > 2048) dgrid = 2048;
+  hipLaunchKernelGGL((attn_delta_kernel<bf16_t>), dim3(dgrid), dim3(256), 0, st, (const bf16_t*)a.O, a.ldo,
+                     (const bf16_t*)a.dO, a.lddo, a.Delta, a.lse_stride, a.B, a.H, a.N, a.DH);
+  CL_CHECK_LAUNCH();
+  return CL_OK;
+}
+
 int attn_bwd(const AttnBwdArgs& a, int dtype, hipStream_t st) {
   const int eb = dtype == CL_BF16 ? 2 : 4;
   if ((a.ldq * eb) % 16 || (a.ldk * eb) % 16 || (a.ldv * eb) % 16 || (a.lddo * eb) % 16 || (a.ldo * eb) % 16)

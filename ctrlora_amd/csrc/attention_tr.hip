@@ -1,0 +1,561 @@
+// bf16 fused attention for gfx950 without materialised transposes.
+//
+// CrossAttention.forward (ldm/modules/attention.py:163-194) and its data gradient, flash style
+// (fp32 scores / softmax as the reference forces at :171-179, log-sum-exp saved for the backward).
+// The round-0 kernels (attention_fwd.hip / attention_bwd.hip, still used for the fp32 parity mode)
+// needed V^T, Q^T, dO^T and K^T copies in HBM for the second MFMA of every stage, because an MFMA
+// operand wants the contraction index contiguous.  Here every tile goes HBM->LDS row-major exactly
+// as the projections left it (global_load_lds), and the "transposed" operands are built by
+// ds_read_b64_tr_b16: within a 16-lane group, lane i receives element (i & 3) of the 8 bytes addressed
+// by lane 4j + (i >> 2), j = 0..3.  With lanes 4j..4j+3 pointing at 16 consecutive head-dim columns of
+// key/query row r0 + j, lane i gets column i of rows r0..r0+3, i.e. one half of an A-operand
+// fragment whose contraction index runs over keys/queries.  So each tile is read twice from LDS
+// (row-wise with ds_read_b128 for Q.K^T-type products, column-wise with the transpose read for
+// P.V-type products) and only once from HBM.
+//
+// k-index bookkeeping: the B operand of the second product comes straight out of the first product's
+// accumulators (C layout: lane = column, rows 4g+r), so a 32-deep contraction step made of two
+// 16-row fragments f0, f1 gives lane group g the rows {16 f0 + 4g + r} U {16 f1 + 4g + r}; the
+// transpose reads fetch exactly those rows (row 4g + j of each fragment), any consistent
+// permutation of the contraction index being valid for an MFMA.
+//
+// Backward: dK/dV kernel = 64*KF keys per workgroup (KF key fragments per wave, so every LDS
+// fragment feeds KF MFMAs), loop over 64-query tiles {Q, dO, lse, delta} double buffered;
+// dQ kernel = 64*QF queries per workgroup, loop over 64-key tiles {K, V}.  log-sum-exp and delta
+// ride in the tile (LDS broadcast reads) instead of per-fragment global loads.
+#include "attn_common.h"
+
+namespace cl {
+
+namespace {
+
+template <int DH> struct Geo {
+  static constexpr int CPR = DH / 8;             // 16-byte chunks per row
+  static constexpr int KSTEPS = (CPR + 3) / 4;   // 32-deep MFMA steps over the head dim
+  static constexpr int DN = (DH + 15) / 16;      // 16-wide output fragments over the head dim
+  static constexpr int ROWB = DH * 2;            // bytes per tile row
+  static constexpr int TILE = 64 * ROWB;         // a 64-row operand tile
+  static constexpr int TI = 64 * CPR / 64;       // DMA instructions per tile (= CPR)
+};
+
+template <int IMM> __device__ __forceinline__ u32x2_t tr_read(uint32_t addr) {
+  u32x2_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM) : "memory");
+  return v;
+}
+// one 8-deep A-operand fragment = transpose reads of rows r0+4g+j and r0+16+4g+j (r0 = 32 * STEP)
+template <int ROWB, int STEP> __device__ __forceinline__ u32x4_t tr_frag(uint32_t addr) {
+  const u32x2_t lo = tr_read<STEP * 32 * ROWB>(addr), hi = tr_read<STEP * 32 * ROWB + 16 * ROWB>(addr);
+  return u32x4_t{lo.x, lo.y, hi.x, hi.y};
+}
+
+// 64-row tile, rows `row0 + r` of a [rows, ld] bf16 matrix (head slice already applied to `base`),
+// rows clamped to nrows-1; wave w issues instructions w, w+4, ...
+template <int DH>
+__device__ __forceinline__ void stage_tile(const char* base, long ld_bytes, int row0, int nrows, char* dst, int wave,
+                                           int lane) {
+  using G = Geo<DH>;
+  for (int ii = wave; ii < G::TI; ii += 4) {
+    const int c = ii * 64 + lane;
+    const int r = c / G::CPR, cc = c - r * G::CPR;
+    const int rr = min(row0 + r, nrows - 1);
+    glds16(base + (long)rr * ld_bytes + cc * 16, dst + ii * 1024);
+  }
+}
+
+}  // namespace
+
+// =============================================================================== forward
+template <int DH, int QW>
+__global__ __launch_bounds__(256) void attn_fwd_tr_kernel(AttnFwdArgs p, const void* __restrict__ V, long ldv) {
+  using G = Geo<DH>;
+  constexpr int CPR = G::CPR, KSTEPS = G::KSTEPS, DN = G::DN, ROWB = G::ROWB, TILE = G::TILE;
+  constexpr int STAGE = 2 * TILE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages + 64 bytes of slack
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, lq = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * (64 * QW) + wave * (16 * QW);
+  const float sl2 = p.scale * 1.4426950408889634f;
+
+  u32x4_t qf[QW][KSTEPS];
+#pragma unroll
+  for (int f = 0; f < QW; ++f) {
+    const int row = min(q0 + f * 16 + lq, p.N - 1);
+    const char* qp = (const char*)p.Q + (((long)b * p.N + row) * p.ldq + (long)h * DH) * 2;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int c = 4 * ks + g;
+      qf[f][ks] = (c < CPR) ? *reinterpret_cast<const u32x4_t*>(qp + c * 16) : u32x4_t{0u, 0u, 0u, 0u};
+    }
+  }
+  const char* kbase = (const char*)p.K + ((long)b * p.Nkv * p.ldk + (long)h * DH) * 2;
+  const char* vbase = (const char*)V + ((long)b * p.Nkv * ldv + (long)h * DH) * 2;
+
+  f32x4_t ot[DN][QW];
+#pragma unroll
+  for (int i = 0; i < DN; ++i)
+#pragma unroll
+    for (int f = 0; f < QW; ++f) ot[i][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_run[QW], l_run[QW];
+#pragma unroll
+  for (int f = 0; f < QW; ++f) { m_run[f] = -1e30f; l_run[f] = 0.f; }
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const uint32_t krow = lq * ROWB + g * 16;                                    // b128: row lq, chunk g (+4 ks)
+  const uint32_t troff = (4 * g + ((lane >> 2) & 3)) * ROWB + (lane & 3) * 8;  // transpose read: row 4g+j, cols 4q
+  const int ntiles = (p.Nkv + 63) / 64;
+  stage_tile<DH>(kbase, p.ldk * 2, 0, p.Nkv, smem, wave, lane);
+  stage_tile<DH>(vbase, ldv * 2, 0, p.Nkv, smem + TILE, wave, lane);
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < ntiles) {
+      stage_tile<DH>(kbase, p.ldk * 2, (t + 1) * 64, p.Nkv, smem + (buf ^ 1) * STAGE, wave, lane);
+      stage_tile<DH>(vbase, ldv * 2, (t + 1) * 64, p.Nkv, smem + (buf ^ 1) * STAGE + TILE, wave, lane);
+    }
+    const uint32_t kt = lds0 + buf * STAGE, vt = kt + TILE;
+
+    // ---- S^T = K . Q^T   (rows = keys 16 kf + 4g + r, col = query lq)
+    f32x4_t st[4][QW];
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf) {
+      u32x4_t ka[KSTEPS];
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks)
+        ka[ks] = (4 * ks + g < CPR) ? lds_read_b128(kt + krow + kf * 16 * ROWB + ks * 64) : u32x4_t{0u, 0u, 0u, 0u};
+      lds_wait();
+#pragma unroll
+      for (int f = 0; f < QW; ++f) {
+        st[kf][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) Mma<bf16_t>::run(ka[ks], qf[f][ks], st[kf][f]);
+      }
+    }
+    // ---- online softmax: lane owns query lq of each q fragment
+    const int kv0 = t * 64;
+    const bool tail = kv0 + 64 > p.Nkv;
+#pragma unroll
+    for (int f = 0; f < QW; ++f) {
+      float mx = -1e30f;
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float s = st[kf][f][r] * sl2;
+          if (tail && kv0 + kf * 16 + 4 * g + r >= p.Nkv) s = -INFINITY;
+          st[kf][f][r] = s;
+          mx = fmaxf(mx, s);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[f], mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);
+      m_run[f] = m_new;
+      float ls = 0.f;
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(st[kf][f][r] - m_new);
+          st[kf][f][r] = e;
+          ls += e;
+        }
+      l_run[f] = l_run[f] * alpha + ls;
+#pragma unroll
+      for (int i = 0; i < DN; ++i) ot[i][f] *= alpha;
+    }
+    // ---- O^T += V^T . P^T   (A = V^T via transpose reads of the row-major V tile)
+    u32x4_t pb[2][QW];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int f = 0; f < QW; ++f) {
+        f32x4_t tmp[2] = {st[2 * s][f], st[2 * s + 1][f]};
+        pb[s][f] = PFrag<bf16_t>::make(tmp);
+      }
+#pragma unroll
+    for (int i = 0; i < DN; ++i) {
+      u32x4_t va[2];
+      va[0] = tr_frag<ROWB, 0>(vt + troff + i * 32);
+      va[1] = tr_frag<ROWB, 1>(vt + troff + i * 32);
+      lds_wait();
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int f = 0; f < QW; ++f) Mma<bf16_t>::run(va[s], pb[s][f], ot[i][f]);
+    }
+  }
+
+  // ---- epilogue: normalise, store O rows, log-sum-exp
+#pragma unroll
+  for (int f = 0; f < QW; ++f) {
+    float l = l_run[f];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    const int row = q0 + f * 16 + lq;
+    if (row < p.N) {
+      bf16_t* op = reinterpret_cast<bf16_t*>(p.O) + ((long)b * p.N + row) * p.ldo + (long)h * DH;
+#pragma unroll
+      for (int i = 0; i < DN; ++i) {
+        const int d0 = i * 16 + 4 * g;
+        if (d0 < DH) {
+          float v[4] = {ot[i][f][0] * inv, ot[i][f][1] * inv, ot[i][f][2] * inv, ot[i][f][3] * inv};
+          store4(op + d0, v);
+        }
+      }
+      if (p.LSE && g == 0) p.LSE[((long)b * p.H + h) * p.lse_stride + row] = m_run[f] + __builtin_amdgcn_logf(l);
+    }
+  }
+}
+
+// =============================================================================== dK / dV
+template <int DH, int KF>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_tr_kernel(AttnBwdArgs p) {
+  using G = Geo<DH>;
+  constexpr int CPR = G::CPR, KSTEPS = G::KSTEPS, DN = G::DN, ROWB = G::ROWB, TILE = G::TILE, TI = G::TI;
+  constexpr int STAGE = 2 * TILE + 512;     // Q tile, dO tile, lse[64], delta[64]
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, lq = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int kv_w = blockIdx.x * (64 * KF) + wave * (16 * KF);
+  const float sl2 = p.scale * 1.4426950408889634f;
+
+  // K and V fragments (B operands: col = key lq, k = d chunk) stay in registers
+  u32x4_t kb[KF][KSTEPS], vb[KF][KSTEPS];
+#pragma unroll
+  for (int kf = 0; kf < KF; ++kf) {
+    const int kr = min(kv_w + kf * 16 + lq, p.Nkv - 1);
+    const char* kp = (const char*)p.K + (((long)b * p.Nkv + kr) * p.ldk + (long)h * DH) * 2;
+    const char* vp = (const char*)p.V + (((long)b * p.Nkv + kr) * p.ldv + (long)h * DH) * 2;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int c = 4 * ks + g;
+      kb[kf][ks] = (c < CPR) ? *reinterpret_cast<const u32x4_t*>(kp + c * 16) : u32x4_t{0u, 0u, 0u, 0u};
+      vb[kf][ks] = (c < CPR) ? *reinterpret_cast<const u32x4_t*>(vp + c * 16) : u32x4_t{0u, 0u, 0u, 0u};
+    }
+  }
+  const char* qbase = (const char*)p.Q + ((long)b * p.N * p.ldq + (long)h * DH) * 2;
+  const char* dobase = (const char*)p.dO + ((long)b * p.N * p.lddo + (long)h * DH) * 2;
+  const float* lse = p.LSE + ((long)b * p.H + h) * p.lse_stride;
+  const float* dlt = p.Delta + ((long)b * p.H + h) * p.lse_stride;
+
+  f32x4_t dvt[KF][DN], dkt[KF][DN];
+#pragma unroll
+  for (int kf = 0; kf < KF; ++kf)
+#pragma unroll
+    for (int i = 0; i < DN; ++i) { dvt[kf][i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dkt[kf][i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+
+  auto issue = [&](int t, int buf) {
+    char* base = smem + buf * STAGE;
+    stage_tile<DH>(qbase, p.ldq * 2, t * 64, p.N, base, wave, lane);
+    stage_tile<DH>(dobase, p.lddo * 2, t * 64, p.N, base + TILE, wave, lane);
+    if (wave == (TI & 3) && lane < 32) {   // lse (lanes 0-15) and delta (16-31), 64 floats each; lse_stride % 64 == 0
+      const float* src = lane < 16 ? lse + t * 64 + lane * 4 : dlt + t * 64 + (lane - 16) * 4;
+      glds16(src, base + 2 * TILE);
+    }
+  };
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const uint32_t rrow = lq * ROWB + g * 16;
+  const uint32_t troff = (4 * g + ((lane >> 2) & 3)) * ROWB + (lane & 3) * 8;
+  const int ntiles = (p.N + 63) / 64;
+  issue(0, 0);
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < ntiles) issue(t + 1, buf ^ 1);
+    const uint32_t aQ = lds0 + buf * STAGE, adO = aQ + TILE, aL = adO + TILE;
+    const int q0 = t * 64;
+
+    // ---- S = Q K^T, dP = dO V^T  (rows = queries 16 qf + 4g + r, col = key lq)
+    f32x4_t ps[KF][4], ds[KF][4];
+#pragma unroll
+    for (int qf = 0; qf < 4; ++qf) {
+      u32x4_t qa[KSTEPS], da[KSTEPS];
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        const bool in = 4 * ks + g < CPR;
+        qa[ks] = in ? lds_read_b128(aQ + rrow + qf * 16 * ROWB + ks * 64) : u32x4_t{0u, 0u, 0u, 0u};
+        da[ks] = in ? lds_read_b128(adO + rrow + qf * 16 * ROWB + ks * 64) : u32x4_t{0u, 0u, 0u, 0u};
+      }
+      const u32x4_t l4 = lds_read_b128(aL + (qf * 16 + 4 * g) * 4);
+      const u32x4_t d4 = lds_read_b128(aL + 256 + (qf * 16 + 4 * g) * 4);
+      lds_wait();
+      const float lv[4] = {__uint_as_float(l4.x), __uint_as_float(l4.y), __uint_as_float(l4.z), __uint_as_float(l4.w)};
+      const float dv[4] = {__uint_as_float(d4.x), __uint_as_float(d4.y), __uint_as_float(d4.z), __uint_as_float(d4.w)};
+      const int qrow = q0 + qf * 16 + 4 * g;
+#pragma unroll
+      for (int kf = 0; kf < KF; ++kf) {
+        f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) { Mma<bf16_t>::run(qa[ks], kb[kf][ks], s); Mma<bf16_t>::run(da[ks], vb[kf][ks], dp); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = qrow + r < p.N;
+          const float pr = ok ? __builtin_amdgcn_exp2f(s[r] * sl2 - lv[r]) : 0.f;
+          ps[kf][qf][r] = pr;
+          ds[kf][qf][r] = ok ? pr * (dp[r] - dv[r]) * p.scale : 0.f;
+        }
+      }
+    }
+    // ---- dV^T += dO^T . P ;  dK^T += Q^T . dS   (A operands by transpose reads of the same tiles)
+    u32x4_t pb[KF][2], sb[KF][2];
+#pragma unroll
+    for (int kf = 0; kf < KF; ++kf)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) { pb[kf][s] = PFrag<bf16_t>::make(&ps[kf][2 * s]); sb[kf][s] = PFrag<bf16_t>::make(&ds[kf][2 * s]); }
+#pragma unroll
+    for (int i = 0; i < DN; ++i) {
+      u32x4_t oa[2], qa[2];
+      oa[0] = tr_frag<ROWB, 0>(adO + troff + i * 32); oa[1] = tr_frag<ROWB, 1>(adO + troff + i * 32);
+      qa[0] = tr_frag<ROWB, 0>(aQ + troff + i * 32); qa[1] = tr_frag<ROWB, 1>(aQ + troff + i * 32);
+      lds_wait();
+#pragma unroll
+      for (int kf = 0; kf < KF; ++kf)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { Mma<bf16_t>::run(oa[s], pb[kf][s], dvt[kf][i]); Mma<bf16_t>::run(qa[s], sb[kf][s], dkt[kf][i]); }
+    }
+  }
+  // ---- store dK / dV rows (4 consecutive d per lane)
+#pragma unroll
+  for (int kf = 0; kf < KF; ++kf) {
+    const int kr = kv_w + kf * 16 + lq;
+    if (kr < p.Nkv) {
+      bf16_t* dkp = reinterpret_cast<bf16_t*>(p.dK) + ((long)b * p.Nkv + kr) * p.lddk + (long)h * DH;
+      bf16_t* dvp = reinterpret_cast<bf16_t*>(p.dV) + ((long)b * p.Nkv + kr) * p.lddv + (long)h * DH;
+#pragma unroll
+      for (int i = 0; i < DN; ++i) {
+        const int d0 = i * 16 + 4 * g;
+        if (d0 < DH) {
+          float a[4] = {dkt[kf][i][0], dkt[kf][i][1], dkt[kf][i][2], dkt[kf][i][3]};
+          float c[4] = {dvt[kf][i][0], dvt[kf][i][1], dvt[kf][i][2], dvt[kf][i][3]};
+          store4(dkp + d0, a);
+          store4(dvp + d0, c);
+        }
+      }
+    }
+  }
+}
+
+// =============================================================================== dQ
+template <int DH, int QF>
+__global__ __launch_bounds__(256) void attn_bwd_dq_tr_kernel(AttnBwdArgs p) {
+  using G = Geo<DH>;
+  constexpr int CPR = G::CPR, KSTEPS = G::KSTEPS, DN = G::DN, ROWB = G::ROWB, TILE = G::TILE;
+  constexpr int STAGE = 2 * TILE;           // K tile, V tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, lq = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q_w = blockIdx.x * (64 * QF) + wave * (16 * QF);
+  const float sl2 = p.scale * 1.4426950408889634f;
+
+  u32x4_t qb[QF][KSTEPS], ob[QF][KSTEPS];
+  float lse_q[QF], dlt_q[QF];
+#pragma unroll
+  for (int f = 0; f < QF; ++f) {
+    const int qr = min(q_w + f * 16 + lq, p.N - 1);
+    const char* qp = (const char*)p.Q + (((long)b * p.N + qr) * p.ldq + (long)h * DH) * 2;
+    const char* op = (const char*)p.dO + (((long)b * p.N + qr) * p.lddo + (long)h * DH) * 2;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int c = 4 * ks + g;
+      qb[f][ks] = (c < CPR) ? *reinterpret_cast<const u32x4_t*>(qp + c * 16) : u32x4_t{0u, 0u, 0u, 0u};
+      ob[f][ks] = (c < CPR) ? *reinterpret_cast<const u32x4_t*>(op + c * 16) : u32x4_t{0u, 0u, 0u, 0u};
+    }
+    lse_q[f] = p.LSE[((long)b * p.H + h) * p.lse_stride + qr];
+    dlt_q[f] = p.Delta[((long)b * p.H + h) * p.lse_stride + qr];
+  }
+  const char* kbase = (const char*)p.K + ((long)b * p.Nkv * p.ldk + (long)h * DH) * 2;
+  const char* vbase = (const char*)p.V + ((long)b * p.Nkv * p.ldv + (long)h * DH) * 2;
+
+  f32x4_t dqt[QF][DN];
+#pragma unroll
+  for (int f = 0; f < QF; ++f)
+#pragma unroll
+    for (int i = 0; i < DN; ++i) dqt[f][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const uint32_t rrow = lq * ROWB + g * 16;
+  const uint32_t troff = (4 * g + ((lane >> 2) & 3)) * ROWB + (lane & 3) * 8;
+  const int ntiles = (p.Nkv + 63) / 64;
+  stage_tile<DH>(kbase, p.ldk * 2, 0, p.Nkv, smem, wave, lane);
+  stage_tile<DH>(vbase, p.ldv * 2, 0, p.Nkv, smem + TILE, wave, lane);
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < ntiles) {
+      stage_tile<DH>(kbase, p.ldk * 2, (t + 1) * 64, p.Nkv, smem + (buf ^ 1) * STAGE, wave, lane);
+      stage_tile<DH>(vbase, p.ldv * 2, (t + 1) * 64, p.Nkv, smem + (buf ^ 1) * STAGE + TILE, wave, lane);
+    }
+    const uint32_t aK = lds0 + buf * STAGE, aV = aK + TILE;
+    const int kv0 = t * 64;
+
+    // ---- S^T = K Q^T, dP^T = V dO^T  (rows = keys 16 kf + 4g + r, col = query lq)
+    f32x4_t dst[QF][4];
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf) {
+      u32x4_t ka[KSTEPS], va[KSTEPS];
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        const bool in = 4 * ks + g < CPR;
+        ka[ks] = in ? lds_read_b128(aK + rrow + kf * 16 * ROWB + ks * 64) : u32x4_t{0u, 0u, 0u, 0u};
+        va[ks] = in ? lds_read_b128(aV + rrow + kf * 16 * ROWB + ks * 64) : u32x4_t{0u, 0u, 0u, 0u};
+      }
+      lds_wait();
+#pragma unroll
+      for (int f = 0; f < QF; ++f) {
+        f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) { Mma<bf16_t>::run(ka[ks], qb[f][ks], s); Mma<bf16_t>::run(va[ks], ob[f][ks], dp); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = kv0 + kf * 16 + 4 * g + r < p.Nkv;
+          const float pr = ok ? __builtin_amdgcn_exp2f(s[r] * sl2 - lse_q[f]) : 0.f;
+          dst[f][kf][r] = ok ? pr * (dp[r] - dlt_q[f]) * p.scale : 0.f;
+        }
+      }
+    }
+    // ---- dQ^T += K^T . dS^T   (A = K^T by transpose reads of the K tile)
+    u32x4_t sb[QF][2];
+#pragma unroll
+    for (int f = 0; f < QF; ++f)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) sb[f][s] = PFrag<bf16_t>::make(&dst[f][2 * s]);
+#pragma unroll
+    for (int i = 0; i < DN; ++i) {
+      u32x4_t ka[2];
+      ka[0] = tr_frag<ROWB, 0>(aK + troff + i * 32); ka[1] = tr_frag<ROWB, 1>(aK + troff + i * 32);
+      lds_wait();
+#pragma unroll
+      for (int f = 0; f < QF; ++f)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) Mma<bf16_t>::run(ka[s], sb[f][s], dqt[f][i]);
+    }
+  }
+#pragma unroll
+  for (int f = 0; f < QF; ++f) {
+    const int qrow = q_w + f * 16 + lq;
+    if (qrow < p.N) {
+      bf16_t* dqp = reinterpret_cast<bf16_t*>(p.dQ) + ((long)b * p.N + qrow) * p.lddq + (long)h * DH;
+#pragma unroll
+      for (int i = 0; i < DN; ++i) {
+        const int d0 = i * 16 + 4 * g;
+        if (d0 < DH) {
+          float a[4] = {dqt[f][i][0], dqt[f][i][1], dqt[f][i][2], dqt[f][i][3]};
+          store4(dqp + d0, a);
+        }
+      }
+    }
+  }
+}
+
+// =============================================================================== host side
+template <typename K>
+static int set_lds(K kern, int bytes) {
+  if (bytes > 65536 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+    return CL_ELAUNCH;
+  return CL_OK;
+}
+
+template <int DH>
+static int launch_fwd_tr(const AttnFwdArgs& a, const void* V, long ldv, hipStream_t st) {
+  constexpr int LDS = 2 * 2 * Geo<DH>::TILE + 64 + 16 * Geo<DH>::ROWB;
+  constexpr int QW = DH <= 80 ? 2 : 1;
+  static bool done = false;
+  if (!done) {
+    if (set_lds(&attn_fwd_tr_kernel<DH, 2>, LDS) || set_lds(&attn_fwd_tr_kernel<DH, 1>, LDS)) return CL_ELAUNCH;
+    done = true;
+  }
+  const long blocks128 = (long)((a.N + 127) / 128) * a.H * a.B;
+  if (QW == 2 && blocks128 >= 512) {
+    dim3 grid((a.N + 127) / 128, a.H, a.B);
+    hipLaunchKernelGGL((attn_fwd_tr_kernel<DH, 2>), grid, dim3(256), LDS, st, a, V, ldv);
+  } else {
+    dim3 grid((a.N + 63) / 64, a.H, a.B);
+    hipLaunchKernelGGL((attn_fwd_tr_kernel<DH, 1>), grid, dim3(256), LDS, st, a, V, ldv);
+  }
+  CL_CHECK_LAUNCH();
+  return CL_OK;
+}
+
+int attn_fwd_tr(const AttnFwdArgs& a, const void* V, long ldv, hipStream_t st) {
+  if ((a.ldq * 2) % 16 || (a.ldk * 2) % 16 || (ldv * 2) % 16 || (a.ldo * 2) % 16 || a.Nkv < 1 || a.N < 1) return CL_EINVAL;
+  switch (a.DH) {
+    case 8: return launch_fwd_tr<8>(a, V, ldv, st);
+    case 16: return launch_fwd_tr<16>(a, V, ldv, st);
+    case 32: return launch_fwd_tr<32>(a, V, ldv, st);
+    case 40: return launch_fwd_tr<40>(a, V, ldv, st);
+    case 80: return launch_fwd_tr<80>(a, V, ldv, st);
+    case 160: return launch_fwd_tr<160>(a, V, ldv, st);
+    default: return CL_EINVAL;
+  }
+}
+
+template <int DH>
+static int launch_bwd_tr(const AttnBwdArgs& a, hipStream_t st) {
+  constexpr int KF = DH <= 80 ? 2 : 1;
+  constexpr int LDS_DKV = 2 * (2 * Geo<DH>::TILE + 512) + 64 + 16 * Geo<DH>::ROWB;
+  constexpr int LDS_DQ = 2 * 2 * Geo<DH>::TILE + 64 + 16 * Geo<DH>::ROWB;
+  static bool done = false;
+  if (!done) {
+    if (set_lds(&attn_bwd_dkv_tr_kernel<DH, KF>, LDS_DKV) || set_lds(&attn_bwd_dkv_tr_kernel<DH, 1>, LDS_DKV) ||
+        set_lds(&attn_bwd_dq_tr_kernel<DH, KF>, LDS_DQ) || set_lds(&attn_bwd_dq_tr_kernel<DH, 1>, LDS_DQ))
+      return CL_ELAUNCH;
+    done = true;
+  }
+  int rc = attn_delta(a, st);
+  if (rc) return rc;
+  if (a.dK) {
+    // two key fragments per wave only when that still leaves enough workgroups to fill the chip
+    const long blocks2 = (long)((a.Nkv + 64 * KF - 1) / (64 * KF)) * a.H * a.B;
+    if (KF == 2 && blocks2 >= 512) {
+      dim3 grid((a.Nkv + 127) / 128, a.H, a.B);
+      hipLaunchKernelGGL((attn_bwd_dkv_tr_kernel<DH, KF>), grid, dim3(256), LDS_DKV, st, a);
+    } else {
+      dim3 grid((a.Nkv + 63) / 64, a.H, a.B);
+      hipLaunchKernelGGL((attn_bwd_dkv_tr_kernel<DH, 1>), grid, dim3(256), LDS_DKV, st, a);
+    }
+  }
+  const long qblocks2 = (long)((a.N + 64 * KF - 1) / (64 * KF)) * a.H * a.B;
+  if (KF == 2 && qblocks2 >= 512) {
+    dim3 grid((a.N + 127) / 128, a.H, a.B);
+    hipLaunchKernelGGL((attn_bwd_dq_tr_kernel<DH, KF>), grid, dim3(256), LDS_DQ, st, a);
+  } else {
+    dim3 grid((a.N + 63) / 64, a.H, a.B);
+    hipLaunchKernelGGL((attn_bwd_dq_tr_kernel<DH, 1>), grid, dim3(256), LDS_DQ, st, a);
+  }
+  CL_CHECK_LAUNCH();
+  return CL_OK;
+}
+
+int attn_bwd_tr(const AttnBwdArgs& a, hipStream_t st) {
+  if ((a.ldq * 2) % 16 || (a.ldk * 2) % 16 || (a.ldv * 2) % 16 || (a.lddo * 2) % 16 || (a.ldo * 2) % 16) return CL_EINVAL;
+  if ((a.lddq * 2) % 16 || a.lse_stride % 64 || a.lse_stride < a.N) return CL_EINVAL;
+  if ((a.dK == nullptr) != (a.dV == nullptr)) return CL_EINVAL;
+  if (a.dK && ((a.lddk * 2) % 16 || (a.lddv * 2) % 16)) return CL_EINVAL;
+  switch (a.DH) {
+    case 8: return launch_bwd_tr<8>(a, st);
+    case 16: return launch_bwd_tr<16>(a, st);
+    case 32: return launch_bwd_tr<32>(a, st);
+    case 40: return launch_bwd_tr<40>(a, st);
+    case 80: return launch_bwd_tr<80>(a, st);
+    case 160: return launch_bwd_tr<160>(a, st);
+    default: return CL_EINVAL;
+  }
+}
+
+}  // namespace cl

@@ -190,6 +190,26 @@ int cl_attention_bwd(int dtype, const void* Q, long ldq, const void* K, long ldk
   return attn_bwd(a, dtype, S(stream));
 }
 
+int cl_attention_fwd_v2(int dtype, const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, void* O,
+                        long ldo, float* LSE, int lse_stride, int B, int H, int N, int Nkv, int dh, float scale,
+                        void* stream) {
+  if (dtype != CL_BF16) return CL_EINVAL;
+  AttnFwdArgs a{}; a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.O = O; a.ldo = ldo;
+  a.LSE = LSE; a.lse_stride = lse_stride; a.B = B; a.H = H; a.N = N; a.Nkv = Nkv; a.DH = dh; a.scale = scale;
+  return attn_fwd_tr(a, V, ldv, S(stream));
+}
+
+int cl_attention_bwd_v2(int dtype, const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv,
+                        const void* O, long ldo, const void* dO, long lddo, const float* LSE, float* Delta,
+                        int lse_stride, void* dQ, long lddq, void* dK, long lddk, void* dV, long lddv, int B, int H,
+                        int N, int Nkv, int dh, float scale, void* stream) {
+  if (dtype != CL_BF16) return CL_EINVAL;
+  AttnBwdArgs a{}; a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo;
+  a.dO = dO; a.lddo = lddo; a.LSE = LSE; a.Delta = Delta; a.lse_stride = lse_stride; a.dQ = dQ; a.lddq = lddq;
+  a.dK = dK; a.lddk = lddk; a.dV = dV; a.lddv = lddv; a.B = B; a.H = H; a.N = N; a.Nkv = Nkv; a.DH = dh; a.scale = scale;
+  return attn_bwd_tr(a, S(stream));
+}
+
 int cl_geglu_fwd(int dtype, const void* h, long ldh, void* out, long ldo, long M, int F, void* stream) { return geglu_fwd(dtype, h, ldh, out, ldo, M, F, S(stream)); }
 int cl_geglu_bwd(int dtype, const void* h, long ldh, const void* dout, long lddo, void* dh, long lddh, long M, int F, void* stream) { return geglu_bwd(dtype, h, ldh, dout, lddo, dh, lddh, M, F, S(stream)); }
 int cl_silu_fwd(int dtype, const void* x, void* y, long n, void* stream) { return silu_fwd(dtype, x, y, n, S(stream)); }

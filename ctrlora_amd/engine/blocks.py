@@ -295,13 +295,16 @@ class AttnE:
                 k, v, tk, tv = kv_cache
             else:
                 k, v, tk, tv = self.project_context(ctx, c)
-        kpad = rup(Nkv, 64)
-        vt = torch.empty((B, inner, kpad), dtype=ctx.dtype, device=ctx.device)
-        hip.transpose(v, vt, B, Nkv, inner, kpad, ldi=v.stride(0))
         a = ctx.new(B * N, inner)
         lse = torch.empty((B, H, rup(N, 64)), dtype=torch.float32, device=ctx.device) if ctx.record else None
-        hip.attention_fwd(q, k, vt, a, lse, B, H, N, Nkv, self.dh, self.scale)
-        del vt
+        if ctx.dtype == torch.bfloat16:       # transpose-free kernels (LDS transpose reads)
+            hip.attention_fwd_v2(q, k, v, a, lse, B, H, N, Nkv, self.dh, self.scale)
+        else:
+            kpad = rup(Nkv, 64)
+            vt = torch.empty((B, inner, kpad), dtype=ctx.dtype, device=ctx.device)
+            hip.transpose(v, vt, B, Nkv, inner, kpad, ldi=v.stride(0))
+            hip.attention_fwd(q, k, vt, a, lse, B, H, N, Nkv, self.dh, self.scale)
+            del vt
         out, to_ = linear_fwd(ctx, self.o, a, residual=residual)
         saved = (xn, c, q, k, v, a, lse, tq, tk, tv, to_) if ctx.record else None
         return out, saved
@@ -313,13 +316,6 @@ class AttnE:
         inner, H = self.inner, self.heads
         da, uo = linear_bwd_data(ctx, self.o, dout)
         linear_bwd_lora(ctx, self.o, a, to_, dout, uo)
-        npad, kpad = rup(N, 64), rup(Nkv, 64)
-        qt = torch.empty((B, inner, npad), dtype=ctx.dtype, device=ctx.device)
-        dot = torch.empty((B, inner, npad), dtype=ctx.dtype, device=ctx.device)
-        kt = torch.empty((B, inner, kpad), dtype=ctx.dtype, device=ctx.device)
-        hip.transpose(q, qt, B, N, inner, npad, ldi=q.stride(0))
-        hip.transpose(da, dot, B, N, inner, npad, ldi=da.stride(0))
-        hip.transpose(k, kt, B, Nkv, inner, kpad, ldi=k.stride(0))
         delta = torch.empty_like(lse)
         want_kv = self.is_self or self.need_kv_grad
         if self.is_self and self.fused_qkv is not None:
@@ -329,8 +325,18 @@ class AttnE:
             dq = ctx.new(B * N, inner)
             dk = ctx.new(B * Nkv, inner) if want_kv else None
             dv = ctx.new(B * Nkv, inner) if want_kv else None
-        hip.attention_bwd(q, k, v, a, da, qt, dot, kt, lse, delta, dq, dk, dv, B, H, N, Nkv, self.dh, self.scale)
-        del qt, dot, kt
+        if ctx.dtype == torch.bfloat16:
+            hip.attention_bwd_v2(q, k, v, a, da, lse, delta, dq, dk, dv, B, H, N, Nkv, self.dh, self.scale)
+        else:
+            npad, kpad = rup(N, 64), rup(Nkv, 64)
+            qt = torch.empty((B, inner, npad), dtype=ctx.dtype, device=ctx.device)
+            dot = torch.empty((B, inner, npad), dtype=ctx.dtype, device=ctx.device)
+            kt = torch.empty((B, inner, kpad), dtype=ctx.dtype, device=ctx.device)
+            hip.transpose(q, qt, B, N, inner, npad, ldi=q.stride(0))
+            hip.transpose(da, dot, B, N, inner, npad, ldi=da.stride(0))
+            hip.transpose(k, kt, B, Nkv, inner, kpad, ldi=k.stride(0))
+            hip.attention_bwd(q, k, v, a, da, qt, dot, kt, lse, delta, dq, dk, dv, B, H, N, Nkv, self.dh, self.scale)
+            del qt, dot, kt
         if self.is_self:
             if self.fused_qkv is not None:
                 dxn, _ = linear_bwd_data(ctx, self.fused_qkv, dqkv, accum=accum_xn)

@@ -68,6 +68,9 @@ _SIGS = {
     "cl_attention_fwd": [_I, _P, _L, _P, _L, _P, _I, _P, _L, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "cl_attention_bwd": [_I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _I, _P, _I, _P, _P, _I, _P, _L, _P, _L,
                          _P, _L, _I, _I, _I, _I, _I, _F, _P],
+    "cl_attention_fwd_v2": [_I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+    "cl_attention_bwd_v2": [_I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _I, _P, _L, _P, _L, _P, _L,
+                            _I, _I, _I, _I, _I, _F, _P],
     "cl_geglu_fwd": [_I, _P, _L, _P, _L, _L, _I, _P],
     "cl_geglu_bwd": [_I, _P, _L, _P, _L, _P, _L, _L, _I, _P],
     "cl_silu_fwd": [_I, _P, _P, _L, _P],
@@ -258,6 +261,21 @@ def attention_bwd(q, k, v, o, do, qt, dot, kt, lse, delta, dq, dk, dv, B, H, N, 
                                 kt.data_ptr(), kt.shape[-1], lse.data_ptr(), delta.data_ptr(), lse.shape[-1],
                                 dq.data_ptr(), ld(dq), ptr(dk), ld(dk), ptr(dv), ld(dv), B, H, N, Nkv, dh, scale,
                                 stream()), "cl_attention_bwd")
+
+
+def attention_fwd_v2(q, k, v, o, lse, B, H, N, Nkv, dh, scale):
+    """bf16, transpose-free: v is [B*Nkv, >=H*dh] like k."""
+    _chk(lib().cl_attention_fwd_v2(dt(q), q.data_ptr(), ld(q), k.data_ptr(), ld(k), v.data_ptr(), ld(v), o.data_ptr(),
+                                   ld(o), ptr(lse), 0 if lse is None else lse.shape[-1], B, H, N, Nkv, dh, scale,
+                                   stream()), "cl_attention_fwd_v2")
+    return o
+
+
+def attention_bwd_v2(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, N, Nkv, dh, scale):
+    _chk(lib().cl_attention_bwd_v2(dt(q), q.data_ptr(), ld(q), k.data_ptr(), ld(k), v.data_ptr(), ld(v), o.data_ptr(),
+                                   ld(o), do.data_ptr(), ld(do), lse.data_ptr(), delta.data_ptr(), lse.shape[-1],
+                                   dq.data_ptr(), ld(dq), ptr(dk), ld(dk), ptr(dv), ld(dv), B, H, N, Nkv, dh, scale,
+                                   stream()), "cl_attention_bwd_v2")
 
 
 # ------------------------------------------------------------------ elementwise / layout

@@ -155,6 +155,17 @@ int cl_attention_bwd(int dtype, const void* Q, long ldq, const void* K, long ldk
                      float* Delta, int lse_stride, void* dQ, long lddq, void* dK, long lddk, void* dV,
                      long lddv, int B, int H, int N, int Nkv, int dh, float scale, void* stream);
 
+/* bf16 variants without any materialised transposes (csrc/attention_tr.hip): every tile is staged
+ * row-major as the projections wrote it and the P.V-type operands are built with the gfx950 LDS
+ * transpose read.  V is [B*Nkv, ldv] like K.  fp32 parity mode keeps the entry points above. */
+int cl_attention_fwd_v2(int dtype, const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv,
+                        void* O, long ldo, float* LSE, int lse_stride, int B, int H, int N, int Nkv, int dh,
+                        float scale, void* stream);
+int cl_attention_bwd_v2(int dtype, const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv,
+                        const void* O, long ldo, const void* dO, long lddo, const float* LSE, float* Delta,
+                        int lse_stride, void* dQ, long lddq, void* dK, long lddk, void* dV, long lddv,
+                        int B, int H, int N, int Nkv, int dh, float scale, void* stream);
+
 /* ---- elementwise / layout ------------------------------------------------------------ */
 int cl_geglu_fwd(int dtype, const void* h, long ldh, void* out, long ldo, long M, int F, void* stream); /* attention.py:55-56 */
 int cl_geglu_bwd(int dtype, const void* h, long ldh, const void* dout, long lddo, void* dh, long lddh, long M, int F, void* stream);

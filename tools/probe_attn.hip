@@ -17,6 +17,7 @@ static float frand() { rng_state = rng_state * 1664525u + 1013904223u; return ((
 static uint16_t h_f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
 static float h_bf2f(uint16_t v) { uint32_t u = ((uint32_t)v) << 16; float f; memcpy(&f, &u, 4); return f; }
 static int g_fail = 0;
+static bool g_tr = false;   // --tr: transpose-free bf16 kernel (attention_tr.hip)
 
 struct Buf {
   std::vector<float> h; void* d = nullptr; size_t n = 0; int dtype = 0;
@@ -46,7 +47,8 @@ static void run_case(const char* name, int dtype, int B, int H, int N, int Nkv, 
   if (dtype == CL_F32 && rc == 0) {}  // f32->f32 path
   AttnFwdArgs a{}; a.Q = Q.d; a.ldq = ldq; a.K = K.d; a.ldk = ldk; a.Vt = Vt.d; a.nkv_pad = pad; a.O = O.d; a.ldo = inner;
   a.LSE = dlse; a.lse_stride = N; a.B = B; a.H = H; a.N = N; a.Nkv = Nkv; a.DH = DH; a.scale = 1.0f / std::sqrt((float)DH);
-  if (!rc) rc = attn_fwd(a, dtype, 0);
+  const bool tr = g_tr && dtype == CL_BF16;
+  if (!rc) rc = tr ? attn_fwd_tr(a, V.d, ldv, 0) : attn_fwd(a, dtype, 0);
   HIPCHK(hipDeviceSynchronize());
   if (rc) { printf("[FAIL] %s rc=%d\n", name, rc); g_fail++; return; }
   O.download(); HIPCHK(hipMemcpy(lse.data(), dlse, lse.size() * 4, hipMemcpyDeviceToHost));
@@ -78,9 +80,9 @@ static void run_case(const char* name, int dtype, int B, int H, int N, int Nkv, 
   if (!ok) g_fail++;
   if (timeit) {
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) attn_fwd(a, dtype, 0);
+    for (int i = 0; i < 3; ++i) { if (tr) attn_fwd_tr(a, V.d, ldv, 0); else attn_fwd(a, dtype, 0); }
     HIPCHK(hipEventRecord(e0, 0));
-    for (int i = 0; i < 20; ++i) attn_fwd(a, dtype, 0);
+    for (int i = 0; i < 20; ++i) { if (tr) attn_fwd_tr(a, V.d, ldv, 0); else attn_fwd(a, dtype, 0); }
     HIPCHK(hipEventRecord(e1, 0)); HIPCHK(hipEventSynchronize(e1));
     float ms; HIPCHK(hipEventElapsedTime(&ms, e0, e1)); ms /= 20;
     printf("[TIME] %-46s %8.3f ms  %8.1f TFLOP/s\n", name, ms, 4.0 * B * H * (double)N * Nkv * DH / ms * 1e-9);
@@ -90,6 +92,8 @@ static void run_case(const char* name, int dtype, int B, int H, int N, int Nkv, 
 
 int main(int argc, char** argv) {
   const bool timeit = argc > 1 && !strcmp(argv[1], "--time");
+  g_tr = argc > 2 && !strcmp(argv[2], "--tr");
+  printf("kernels: %s\n", g_tr ? "transpose-free (tr)" : "round-0");
   run_case("bf16 d40 N200 self", CL_BF16, 2, 3, 200, 200, 40, 96, false);
   run_case("bf16 d40 N130 cross 77", CL_BF16, 2, 8, 130, 77, 40, 96, false);
   run_case("bf16 d80 N256 self", CL_BF16, 2, 8, 256, 256, 80, 96, false);

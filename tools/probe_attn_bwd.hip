@@ -16,6 +16,7 @@ static float frand() { rng_state = rng_state * 1664525u + 1013904223u; return ((
 static uint16_t h_f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
 static float h_bf2f(uint16_t v) { uint32_t u = ((uint32_t)v) << 16; float f; memcpy(&f, &u, 4); return f; }
 static int g_fail = 0;
+static bool g_tr = false;   // --tr: transpose-free bf16 kernels (attention_tr.hip)
 
 struct Buf {
   std::vector<float> h; void* d = nullptr; size_t n = 0; int dtype = 0;
@@ -57,12 +58,13 @@ static void run_case(const char* name, int dtype, int B, int H, int N, int Nkv, 
   const float scale = 1.0f / std::sqrt((float)DH);
   AttnFwdArgs f{}; f.Q = Q.d; f.ldq = inner; f.K = K.d; f.ldk = inner; f.Vt = Vt.d; f.nkv_pad = kpad; f.O = O.d; f.ldo = inner;
   f.LSE = lse; f.lse_stride = npad; f.B = B; f.H = H; f.N = N; f.Nkv = Nkv; f.DH = DH; f.scale = scale;
-  rc |= attn_fwd(f, dtype, 0);
+  const bool tr = g_tr && dtype == CL_BF16;
+  rc |= tr ? attn_fwd_tr(f, V.d, inner, 0) : attn_fwd(f, dtype, 0);
   AttnBwdArgs a{}; a.Q = Q.d; a.ldq = inner; a.K = K.d; a.ldk = inner; a.V = V.d; a.ldv = inner; a.O = O.d; a.ldo = inner;
   a.dO = dO.d; a.lddo = inner; a.Qt = Qt.d; a.dOt = dOt.d; a.n_pad = npad; a.Kt = Kt.d; a.nkv_pad = kpad; a.LSE = lse; a.Delta = delta;
   a.lse_stride = npad; a.dQ = dQ.d; a.lddq = inner; a.dK = want_dkv ? dK.d : nullptr; a.lddk = inner; a.dV = want_dkv ? dV.d : nullptr; a.lddv = inner;
   a.B = B; a.H = H; a.N = N; a.Nkv = Nkv; a.DH = DH; a.scale = scale;
-  rc |= attn_bwd(a, dtype, 0);
+  rc |= tr ? attn_bwd_tr(a, 0) : attn_bwd(a, dtype, 0);
   HIPCHK(hipDeviceSynchronize());
   if (rc) { printf("[FAIL] %s rc=%d\n", name, rc); g_fail++; return; }
   if ((long)B * H * N * Nkv <= 4000000L) {
@@ -101,9 +103,9 @@ static void run_case(const char* name, int dtype, int B, int H, int N, int Nkv, 
   }
   if (timeit) {
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    for (int i = 0; i < 2; ++i) attn_bwd(a, dtype, 0);
+    for (int i = 0; i < 2; ++i) { if (tr) attn_bwd_tr(a, 0); else attn_bwd(a, dtype, 0); }
     HIPCHK(hipEventRecord(e0, 0));
-    for (int i = 0; i < 10; ++i) attn_bwd(a, dtype, 0);
+    for (int i = 0; i < 10; ++i) { if (tr) attn_bwd_tr(a, 0); else attn_bwd(a, dtype, 0); }
     HIPCHK(hipEventRecord(e1, 0)); HIPCHK(hipEventSynchronize(e1));
     float ms; HIPCHK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
     printf("[TIME] %-40s %8.3f ms  %8.1f TFLOP/s (10 N Nkv d flops)\n", name, ms, (want_dkv ? 10.0 : 6.0) * B * H * (double)N * Nkv * DH / ms * 1e-9);
@@ -115,6 +117,8 @@ static void run_case(const char* name, int dtype, int B, int H, int N, int Nkv, 
 
 int main(int argc, char** argv) {
   const bool timeit = argc > 1 && !strcmp(argv[1], "--time");
+  g_tr = argc > 2 && !strcmp(argv[2], "--tr");
+  printf("kernels: %s\n", g_tr ? "transpose-free (tr)" : "round-0");
   run_case("bf16 d40 N200 self", CL_BF16, 2, 3, 200, 200, 40, true, false);
   run_case("bf16 d40 N130 cross 77", CL_BF16, 2, 4, 130, 77, 40, true, false);
   run_case("bf16 d40 N130 cross 77 (dQ only)", CL_BF16, 2, 4, 130, 77, 40, false, false);
