@@ -221,6 +221,7 @@ int cl_tok_to_nchw(int dtype, const void* in, long ldi, float* out, int B, int C
 int cl_colsum(int dtype, const void* in, long ldi, float* out, long ldo, int B, int HW, int C, float scale, void* stream) { return colsum(dtype, in, ldi, out, ldo, B, HW, C, scale, S(stream)); }
 int cl_pool2x2(int dtype, const void* in, long ldi, void* out, long ldo, int B, int H, int W, int C, int accumulate, void* stream) { return pool2x2(dtype, in, ldi, out, ldo, B, H, W, C, accumulate, S(stream)); }
 int cl_pack2d(int dtype, const float* in, long ldi, void* out, long ldo, long R, int C, int Cpad, void* stream) { return pack2d(dtype, in, ldi, out, ldo, R, C, Cpad, S(stream)); }
+int cl_repack(int dtype, const float* flat, const long* desc, const int* tile_prefix, int ndesc, int total_tiles, void* stream) { return repack(dtype, flat, desc, tile_prefix, ndesc, total_tiles, S(stream)); }
 int cl_timestep_embedding(int dtype, const long* t, const float* freqs, void* out, long ldo, int B, int half, void* stream) { return timestep_embed(dtype, t, freqs, out, ldo, B, half, S(stream)); }
 int cl_qsample(const float* z, const float* noise, const long* t, const float* sqrt_ac, const float* sqrt_1mac, float* out, int B, long per_sample, void* stream) { return qsample(z, noise, t, sqrt_ac, sqrt_1mac, out, B, per_sample, S(stream)); }
 int cl_mse_loss(const float* eps, const float* target, float* d_eps, float* loss, long n, float gscale, void* stream) { return mse_loss(eps, target, d_eps, loss, n, gscale, S(stream)); }

@@ -23,6 +23,8 @@ int adamw(float* p, const float* g, float* m, float* v, long n, float lr, float 
           float wd, int step, float gscale, hipStream_t st);
 int pool2x2(int dtype, const void* in, long ldi, void* out, long ldo, int B, int H, int W, int C, int accumulate, hipStream_t st);
 int colsum(int dtype, const void* in, long ldi, float* out, long ldo, int B, int HW, int C, float scale, hipStream_t st);
+int repack(int dtype, const float* flat, const long* desc, const int* tile_prefix, int ndesc, int total_tiles,
+           hipStream_t st);
 int pack2d(int dtype, const float* in, long ldi, void* out, long ldo, long R, int C, int Cpad, hipStream_t st);
 
 }  // namespace cl

@@ -422,4 +422,54 @@ int pack2d(int dtype, const float* in, long ldi, void* out, long ldo, long R, in
   CL_CHECK_LAUNCH(); return CL_OK;
 }
 
+// ------------------------------------------------------------------ fused re-pack of the trainables
+// After every optimizer step the engine needs its storage-dtype copies of the trainable matrices
+// (LoRA down/up, zero convs) in both orientations (W for the forward NT product, W^T for the data
+// gradient).  Round 0 issued one pack + one transpose launch per matrix (~500 launches / 2.6 ms per
+// step); this is ONE launch over a device-resident descriptor table: workgroup -> (matrix, 32x32 tile)
+// by binary search in the tile prefix, fp32 tile in, straight and transposed tiles out.
+//   desc[i] = {src offset (floats) in the flat master, rows << 32 | cols, dst pointer, dst^T pointer (or 0)}
+template <typename T>
+__global__ __launch_bounds__(256) void repack_kernel(const float* __restrict__ flat, const long* __restrict__ desc,
+                                                     const int* __restrict__ tile_prefix, int ndesc) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = ndesc - 1;
+  const int blk = blockIdx.x;
+  while (lo < hi) {                       // first matrix whose prefix end exceeds blk
+    const int mid = (lo + hi) >> 1;
+    if (tile_prefix[mid + 1] > blk) hi = mid; else lo = mid + 1;
+  }
+  const long* d = desc + (long)lo * 4;
+  const long src = d[0];
+  const int R = (int)(d[1] >> 32), C = (int)(d[1] & 0xffffffff);
+  T* dst = reinterpret_cast<T*>(d[2]);
+  T* dstT = reinterpret_cast<T*>(d[3]);
+  const int t = blk - tile_prefix[lo];
+  const int tc = (C + 31) / 32;
+  const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    const float v = (r < R && c < C) ? flat[src + (long)r * C + c] : 0.f;
+    tile[ty + 8 * i][tx] = v;
+    if (dst && r < R && c < C) dst[(long)r * C + c] = from_f<T>(v);
+  }
+  if (!dstT) return;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (r < R && c < C) dstT[(long)c * R + r] = from_f<T>(tile[tx][ty + 8 * i]);
+  }
+}
+
+int repack(int dtype, const float* flat, const long* desc, const int* tile_prefix, int ndesc, int total_tiles,
+           hipStream_t st) {
+  if (ndesc <= 0 || total_tiles <= 0) return CL_OK;
+  if (dtype == CL_BF16) hipLaunchKernelGGL((repack_kernel<bf16_t>), dim3(total_tiles), dim3(256), 0, st, flat, desc, tile_prefix, ndesc);
+  else hipLaunchKernelGGL((repack_kernel<float>), dim3(total_tiles), dim3(256), 0, st, flat, desc, tile_prefix, ndesc);
+  CL_CHECK_LAUNCH(); return CL_OK;
+}
+
 }  // namespace cl

@@ -379,11 +379,11 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_kernel(GemmParams p, i
 // validity mask computed once, and a wave-uniform (scalar) tap offset updated when the tap changes.
 enum { FL_LINEAR = 0, FL_CONV_S1 = 1, FL_CONV_ANY = 2 };
 
-template <typename T, int BM, int BN, int WGM, int WGN, int MODE>
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int R>
 __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p, int tiles_m, int tiles_n,
                                                                  float* __restrict__ slab) {
   constexpr int NW = WGM * WGN;
-  constexpr int R = 3;
+  static_assert(R == 2 || R == 3, "ring depth");
   constexpr int KPS = 128 / (int)sizeof(T);  // elements per stage row
   constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 16, FN = WN / 16;
   constexpr int AI = BM / 8, BI = BN / 8;    // DMA instructions (8 rows x 128 B) per stage
@@ -590,15 +590,16 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p
   // block and the scheduler can slot the scalar/vector ALU work into the MFMA issue gaps.
   int slot = 0;
   auto stage = [&](auto ISSUE, bool has_next) {
+    constexpr bool issue = decltype(ISSUE)::value;
     const int slot1 = (slot == R - 1) ? 0 : slot + 1;
     const int slot2 = (slot1 == R - 1) ? 0 : slot1 + 1;
     read_frags(slot, 1, ga, gb);
     __builtin_amdgcn_sched_barrier(0);
     mma_all(fa, fb);
-    if constexpr (decltype(ISSUE)::value) issue_next(slot2);   // slot2 was last read before the previous barrier
+    if constexpr (issue && R == 3) issue_next(slot2);          // slot2 was last read before the previous barrier
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // k-half 1 fragments have landed
-    if constexpr (decltype(ISSUE)::value) wait_vm<G>(); else wait_vm<0>();   // own DMA of stage s+1 has landed
+    if constexpr (issue && R == 3) wait_vm<G>(); else wait_vm<0>();   // own DMA of stage s+1 has landed
     __builtin_amdgcn_s_barrier();                              // ... and everybody else's: stage s+1 visible
     __builtin_amdgcn_sched_barrier(0);
     if (has_next) read_frags(slot1, 0, fa, fb);
@@ -608,6 +609,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p
 #pragma unroll
     for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(gb[j]));
     mma_all(ga, gb);
+    // two-slot ring: stage s has been read completely by every wave (barrier above), refill its slot
+    if constexpr (issue && R == 2) issue_next(slot);
     wait_frags(fa, fb);
     slot = slot1;
   };
@@ -717,11 +720,11 @@ static int pick_splitk(GemmParams& p, long tiles, int steps, int want, int min_s
   return p.splitk;
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int MODE>
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int R>
 static int launch_fl_mode(const GemmParams& p0, hipStream_t stream) {
   constexpr int NW = WGM * WGN;
-  constexpr int SMEM = 3 * (BM / 8 + BN / 8) * 1024;
-  auto kern = &gemm_fl_kernel<T, BM, BN, WGM, WGN, MODE>;
+  constexpr int SMEM = R * (BM / 8 + BN / 8) * 1024;
+  auto kern = &gemm_fl_kernel<T, BM, BN, WGM, WGN, MODE, R>;
   static bool attr_set = false;
   if (!attr_set) {
     if (SMEM > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -735,7 +738,7 @@ static int launch_fl_mode(const GemmParams& p0, hipStream_t stream) {
   const long tiles = (long)tm * tn;
   const int steps = ((MODE == FL_LINEAR ? 1 : 9) * p.K1 + p.K2) / kps;
   float* slab;
-  pick_splitk(p, tiles, steps, 256, 4, &slab);
+  pick_splitk(p, tiles, steps, R == 3 ? 256 : 512, 4, &slab);
   hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * p.splitk)), dim3(NW * 64), SMEM, stream, p, tm, tn, slab);
   if (slab) {
     const long total = (long)p.M * (p.N / 8);
@@ -746,12 +749,12 @@ static int launch_fl_mode(const GemmParams& p0, hipStream_t stream) {
   return CL_OK;
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN>
+template <typename T, int BM, int BN, int WGM, int WGN, int R>
 static int launch_fl(const GemmParams& p, hipStream_t stream) {
-  if (p.mode == GEMM_LINEAR) return launch_fl_mode<T, BM, BN, WGM, WGN, FL_LINEAR>(p, stream);
+  if (p.mode == GEMM_LINEAR) return launch_fl_mode<T, BM, BN, WGM, WGN, FL_LINEAR, R>(p, stream);
   if (p.K2) return CL_EINVAL;   // a second K segment exists for linear operands only
-  if (p.mode == GEMM_CONV_S1) return launch_fl_mode<T, BM, BN, WGM, WGN, FL_CONV_S1>(p, stream);
-  return launch_fl_mode<T, BM, BN, WGM, WGN, FL_CONV_ANY>(p, stream);
+  if (p.mode == GEMM_CONV_S1) return launch_fl_mode<T, BM, BN, WGM, WGN, FL_CONV_S1, R>(p, stream);
+  return launch_fl_mode<T, BM, BN, WGM, WGN, FL_CONV_ANY, R>(p, stream);
 }
 
 int g_gemm_force_cfg = -1;   // probe / tuning hook: >= 0 forces a tile configuration
@@ -791,7 +794,13 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
       const int kps = 128 / (int)sizeof(T);
       if (p.K1 % kps || p.K2 % kps || (p.mode != GEMM_LINEAR && p.K2))
         return launch_cfg<T, 128, 128, 2, 2, 2, 4>(p, stream);
-      return cfg == 8 ? launch_fl<T, 256, 160, 4, 2>(p, stream) : launch_fl<T, 256, 128, 4, 2>(p, stream);
+      return cfg == 8 ? launch_fl<T, 256, 160, 4, 2, 3>(p, stream) : launch_fl<T, 256, 128, 4, 2, 3>(p, stream);
+    }
+    case 10: case 11: {   // 128-row tiles, 4 waves, 2-slot ring: two workgroups per CU (small-K / mid-size products)
+      const int kps = 128 / (int)sizeof(T);
+      if (p.K1 % kps || p.K2 % kps || (p.mode != GEMM_LINEAR && p.K2))
+        return launch_cfg<T, 128, 128, 2, 2, 2, 4>(p, stream);
+      return cfg == 10 ? launch_fl<T, 128, 160, 2, 2, 2>(p, stream) : launch_fl<T, 128, 128, 2, 2, 2>(p, stream);
     }
     default: return CL_EINVAL;
   }

@@ -81,31 +81,45 @@ __global__ void gn_partial_kernel(const T* __restrict__ x, long ldx, int HW, int
   }
 }
 
+// block-wide sum of two doubles (256 threads = 4 waves); result valid in every thread
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* red /*[8]*/) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { red[wave] = a; red[4 + wave] = b; }
+  __syncthreads();
+  a = red[0] + red[1] + red[2] + red[3];
+  b = red[4] + red[5] + red[6] + red[7];
+}
+
 // per-(b,group) mean/rstd and per-(b,channel) scale/shift
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nchunk, int HW, int C, int G,
-                                   float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ stats /*[B][G][2]*/, float* __restrict__ coef /*[B][C][2]*/) {
-  // one wave per (sample, group): lanes sweep the group's (chunk, channel) partials, coalesced
-  const int g = blockIdx.x, b = blockIdx.y, cg = C / G, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int nchunk, int HW, int C,
+                                                          int G, float eps, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          float* __restrict__ stats /*[B][G][2]*/,
+                                                          float* __restrict__ coef /*[B][C][2]*/) {
+  // one workgroup per (sample, group): 256 threads sweep the group's (chunk, channel) partials, coalesced
+  __shared__ double red[8];
+  const int g = blockIdx.x, b = blockIdx.y, cg = C / G, tid = threadIdx.x;
   double s = 0, q = 0;
   const int total = nchunk * cg;
-  for (int i = lane; i < total; i += 64) {
+  for (int i = tid; i < total; i += 256) {
     const int k = i / cg, c = g * cg + (i - k * cg);
     const float2 p = *reinterpret_cast<const float2*>(partial + (((long)b * nchunk + k) * C + c) * 2);
     s += p.x; q += p.y;
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+  block_sum2(s, q, red);
   const double n = (double)HW * cg;
   const double mean = s / n;
   double var = q / n - mean * mean;
   if (var < 0) var = 0;
   const double rstd = 1.0 / sqrt(var + (double)eps);
-  if (lane == 0) {
+  if (tid == 0) {
     stats[((long)b * G + g) * 2] = (float)mean;
     stats[((long)b * G + g) * 2 + 1] = (float)rstd;
   }
-  for (int c = g * cg + lane; c < (g + 1) * cg; c += 64) {
+  for (int c = g * cg + tid; c < (g + 1) * cg; c += 256) {
     const double sc = rstd * (double)gamma[c];
     coef[((long)b * C + c) * 2] = (float)sc;
     coef[((long)b * C + c) * 2 + 1] = (float)((double)beta[c] - mean * sc);
@@ -146,7 +160,7 @@ static int gn_fwd_t(const GnArgs& a, hipStream_t st) {
   dim3 grid(g.nchunk, a.B);
   hipLaunchKernelGGL((gn_partial_kernel<T>), grid, dim3(g.threads), g.threads * 64, st,
                      (const T*)a.x, a.ldx, a.HW, a.C, g.VX, g.PY, g.ppc, g.nchunk, partial);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.G, a.B), dim3(64), 0, st,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.G, a.B), dim3(256), 0, st,
                      partial, g.nchunk, a.HW, a.C, a.G, a.eps, a.gamma, a.beta, a.stats, coef);
   if (a.silu)
     hipLaunchKernelGGL((gn_apply_kernel<T, true>), grid, dim3(g.threads), 0, st,
@@ -216,29 +230,46 @@ __global__ void gn_bwd_partial_kernel(const T* __restrict__ x, long ldx, const T
   }
 }
 
-// per (b): channel sums -> group sums -> apply coefficients; optional dgamma/dbeta accumulation
-__global__ void gn_bwd_finalize_kernel(const float* __restrict__ partial, int nchunk, int HW, int C, int G,
-                                       const float* __restrict__ gamma, const float* __restrict__ stats,
-                                       float* __restrict__ bcoef /*[B][C][4]: k1,k2,k3,_*/,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  // one wave per (sample, group); lane = channel within the group (two rounds when cg > 64)
-  const int g = blockIdx.x, b = blockIdx.y, cg = C / G, lane = threadIdx.x;
+// per (b, group): channel sums -> group sums -> apply coefficients; optional dgamma/dbeta accumulation
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ partial, int nchunk, int HW,
+                                                              int C, int G, const float* __restrict__ gamma,
+                                                              const float* __restrict__ stats,
+                                                              float* __restrict__ bcoef /*[B][C][4]: k1,k2,k3,_*/,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  // one workgroup per (sample, group).  Thread t owns channel t % CL of the group and the chunks
+  // k = t / CL, t / CL + 256 / CL, ...  (CL = channels rounded up to a power of two <= 256); per-channel
+  // totals are combined through LDS so that dgamma / dbeta need one atomic per channel.
+  __shared__ double red[8];
+  __shared__ double chs[256], chq[256];
+  const int g = blockIdx.x, b = blockIdx.y, cg = C / G, tid = threadIdx.x;
+  int CL = 1;
+  while (CL < cg && CL < 256) CL <<= 1;
+  const int KL = 256 / CL;                         // chunk lanes per channel
+  const int cl = tid % CL, kl = tid / CL;
   double s1 = 0, s2 = 0;
-  for (int c = g * cg + lane; c < (g + 1) * cg; c += 64) {
+  for (int c0 = 0; c0 < cg; c0 += CL) {            // one round unless cg > 256
+    const int c = g * cg + c0 + cl;
     double s = 0, q = 0;
-    for (int k = 0; k < nchunk; ++k) {
-      const float2 p = *reinterpret_cast<const float2*>(partial + (((long)b * nchunk + k) * C + c) * 2);
-      s += p.x; q += p.y;
+    if (c0 + cl < cg) {
+      for (int k = kl; k < nchunk; k += KL) {
+        const float2 p = *reinterpret_cast<const float2*>(partial + (((long)b * nchunk + k) * C + c) * 2);
+        s += p.x; q += p.y;
+      }
     }
-    if (dgamma) { atomicAdd(dgamma + c, (float)q); atomicAdd(dbeta + c, (float)s); }
-    s1 += gamma[c] * s; s2 += gamma[c] * q;
+    __syncthreads();
+    chs[tid] = s; chq[tid] = q;
+    __syncthreads();
+    if (kl == 0 && c0 + cl < cg) {
+      for (int k = 1; k < KL; ++k) { s += chs[k * CL + cl]; q += chq[k * CL + cl]; }
+      if (dgamma) { atomicAdd(dgamma + c, (float)q); atomicAdd(dbeta + c, (float)s); }
+      s1 += (double)gamma[c] * s; s2 += (double)gamma[c] * q;
+    }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+  block_sum2(s1, s2, red);
   const double n = (double)HW * cg;
   const double rstd = stats[((long)b * G + g) * 2 + 1];
   const float k2 = (float)(rstd * s1 / n), k3 = (float)(rstd * s2 / n);
-  for (int c = g * cg + lane; c < (g + 1) * cg; c += 64) {
+  for (int c = g * cg + tid; c < (g + 1) * cg; c += 256) {
     float* o = bcoef + ((long)b * C + c) * 4;
     o[0] = (float)(rstd * gamma[c]); o[1] = k2; o[2] = k3; o[3] = 0.f;
   }
@@ -294,7 +325,7 @@ static int gn_bwd_t(const GnBwdArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((gn_bwd_partial_kernel<T, S>), grid, dim3(g.threads), g.threads * 64, st, (const T*)a.x,   \
                      a.ldx, (const T*)a.dy, a.lddy, a.HW, a.C, a.G, g.VX, g.PY, g.ppc, g.nchunk, a.gamma,       \
                      a.beta, a.stats, partial);                                                                \
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(a.G, a.B), dim3(64), 0, st,                                    \
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(a.G, a.B), dim3(256), 0, st,                                    \
                      partial, g.nchunk, a.HW, a.C, a.G, a.gamma, a.stats, bcoef, a.dgamma, a.dbeta);            \
   hipLaunchKernelGGL((gn_bwd_apply_kernel<T, S>), grid, dim3(g.threads), 0, st, (const T*)a.x, a.ldx,           \
                      (const T*)a.dy, a.lddy, (const T*)a.accum, a.ldacc, (T*)a.dx, a.lddx, a.HW, a.C, a.G,      \

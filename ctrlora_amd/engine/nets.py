@@ -323,10 +323,33 @@ class ControlNetE:
         self.repack()
 
     def repack(self):
-        for L in self._b.linears:
-            L.repack()
-        for n in self._b.norms:
-            n.repack()
+        """Refresh the packed (storage dtype, both orientations) copies of every trainable matrix from the
+        flat fp32 masters: ONE kernel over a device-resident descriptor table (built on first use)."""
+        tab = self.__dict__.get("_repack_tab")
+        if tab is None:
+            rows, prefix = [], [0]
+
+            def add(t, R, C, dst, dstT):
+                rows.append([t.offset, (R << 32) | C, 0 if dst is None else dst.data_ptr(),
+                             0 if dstT is None else dstT.data_ptr()])
+                prefix.append(prefix[-1] + ((R + 31) // 32) * ((C + 31) // 32))
+
+            for L in self._b.linears:
+                if L.tA is not None:
+                    add(L.tA, L.r, L.K, L.A, L.At)
+                    add(L.tB, L.N, L.r, L.B, L.Bt)
+                if L.tW is not None:
+                    add(L.tW, L.N, L.K, L.W, L.Wt)
+                    if L.tb is not None:
+                        L.bias = L.tb.master
+            for n in self._b.norms:
+                n.repack()      # views of the masters: nothing to copy
+            tab = (torch.tensor(rows, dtype=torch.int64, device=self.device),
+                   torch.tensor(prefix, dtype=torch.int32, device=self.device), len(rows), prefix[-1])
+            self.__dict__["_repack_tab"] = tab
+        desc, prefix, n, tiles = tab
+        if n:
+            hip.repack(self.dtype, self.tr.flat, desc, prefix, n, tiles)
 
     def fwd(self, ctx: Ctx, hint_tok, t, c, B, H, W, sinks, scales, weight=1.0, kv=None):
         """sinks[k] = (out_view, residual_view or None); out = (zero_conv_k(h_k)) * scale_k * weight + residual."""

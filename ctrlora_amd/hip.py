@@ -82,6 +82,7 @@ _SIGS = {
     "cl_colsum": [_I, _P, _L, _P, _L, _I, _I, _I, _F, _P],
     "cl_pool2x2": [_I, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P],
     "cl_pack2d": [_I, _P, _L, _P, _L, _L, _I, _I, _P],
+    "cl_repack": [_I, _P, _P, _P, _I, _I, _P],
     "cl_timestep_embedding": [_I, _P, _P, _P, _L, _I, _I, _P],
     "cl_qsample": [_P, _P, _P, _P, _P, _P, _I, _L, _P],
     "cl_mse_loss": [_P, _P, _P, _P, _L, _F, _P],
@@ -200,6 +201,11 @@ def weight_grad(dyT, xT, dW, scale=1.0):
     """dW[N,K] (fp32) += scale * dyT[N,Mp] . xT[K,Mp]^T  (split-K, fp32 atomics)."""
     _chk(lib().cl_weight_grad(dt(dyT), dyT.data_ptr(), ld(dyT), xT.data_ptr(), ld(xT), dW.data_ptr(), ld(dW),
                               dyT.shape[0], xT.shape[0], dyT.shape[1], scale, stream()), "cl_weight_grad")
+
+
+def repack(dtype, flat, desc, tile_prefix, ndesc, total_tiles):
+    _chk(lib().cl_repack(dt_of(dtype), flat.data_ptr(), desc.data_ptr(), tile_prefix.data_ptr(), ndesc, total_tiles,
+                         stream()), "cl_repack")
 
 
 def weight_grad_tn(dy, x, dW, scale=1.0):

@@ -179,6 +179,12 @@ int cl_tok_to_nchw(int dtype, const void* in, long ldi, float* out, int B, int C
 int cl_colsum(int dtype, const void* in, long ldi, float* out, long ldo, int B, int HW, int C, float scale, void* stream);
 int cl_pool2x2(int dtype, const void* in, long ldi, void* out, long ldo, int B, int H, int W, int C, int accumulate, void* stream);
 int cl_pack2d(int dtype, const float* in, long ldi, void* out, long ldo, long R, int C, int Cpad, void* stream);
+/* One-launch refresh of the engine's storage-dtype copies of all trainable matrices from the flat fp32
+ * master buffer after an optimizer step.  desc = device table of 4 longs per matrix {src offset in floats,
+ * rows << 32 | cols, dst [rows][cols] or 0, dst^T [cols][rows] or 0}; tile_prefix[i] = number of 32x32
+ * tiles before matrix i (ndesc + 1 entries). */
+int cl_repack(int dtype, const float* flat, const long* desc, const int* tile_prefix, int ndesc,
+              int total_tiles, void* stream);
 /* timestep_embedding (util.py:154-174); freqs = the fp32 table exp(-ln(1e4) * arange(half)/half) */
 int cl_timestep_embedding(int dtype, const long* t, const float* freqs, void* out, long ldo, int B, int half, void* stream);
 

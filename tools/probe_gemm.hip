@@ -261,12 +261,12 @@ int main(int argc, char** argv) {
   wgrad_suite(argc > 1 && !strcmp(argv[1], "--time"));
   if (argc > 2 && !strcmp(argv[2], "--wgrad-only")) return g_fail ? 1 : 0;
   g_gemm_force_cfg = -1; correctness_suite("heuristic config");
-  const int cfgs[] = {8};
+  const int cfgs[] = {8, 10, 11};
   for (int c : cfgs) { char tag[32]; snprintf(tag, 32, "forced cfg %d", c); g_gemm_force_cfg = c; correctness_suite(tag); }
   g_gemm_force_cfg = -1;
 
   if (argc > 1 && !strcmp(argv[1], "--time")) {
-    const int tc[] = {-1};
+    const int tc[] = {-1, 2, 8, 10, 9, 11};
     for (int c : tc) {
       g_gemm_force_cfg = c;
       printf("---- timing, cfg %d (-1 heuristic, 6 = round-0 structure)\n", c);
@@ -278,6 +278,10 @@ int main(int argc, char** argv) {
       time_case("gemm bf16 32768x320x1280 (FF out)", CL_BF16, GEMM_LINEAR, 32768, 320, 1280, 0, 0, 0);
       time_case("gemm bf16 8192x640x640", CL_BF16, GEMM_LINEAR, 8192, 640, 640, 0, 0, 0);
       time_case("gemm bf16 2048x1280x1280", CL_BF16, GEMM_LINEAR, 2048, 1280, 1280, 0, 0, 0);
+      time_case("gemm bf16 2048x128x1280 (LoRA down 16^2)", CL_BF16, GEMM_LINEAR, 2048, 128, 1280, 0, 0, 0);
+      time_case("gemm bf16 8192x128x640 (LoRA down 32^2)", CL_BF16, GEMM_LINEAR, 8192, 128, 640, 0, 0, 0);
+      time_case("gemm bf16 512x1280x1280", CL_BF16, GEMM_LINEAR, 512, 1280, 1280, 0, 0, 0);
+      time_case("gemm bf16 2048x3840x1280 (qkv 16^2)", CL_BF16, GEMM_LINEAR, 2048, 3840, 1280, 0, 0, 0);
       time_case("gemm bf16 8192x5120x640 (GEGLU proj 32^2)", CL_BF16, GEMM_LINEAR, 8192, 5120, 640, 0, 0, 0);
       time_case("gemm bf16 8192x640x2560 (FF out 32^2)", CL_BF16, GEMM_LINEAR, 8192, 640, 2560, 0, 0, 0);
       time_case("conv bf16 320->320 @64^2 B8", CL_BF16, GEMM_CONV_S1, 8 * 64 * 64, 320, 320, 8, 64, 64);
