@@ -159,6 +159,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ddim", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--tiny", action="store_true", help="debug: narrow model")
     args = ap.parse_args()
 
@@ -184,8 +185,18 @@ def main():
     n_in = 4
     data = synth(B, H, model.control_model.context_dim, device, 1234 + rank, n_in)
 
+    graphed = None
+    if not args.no_graph:
+        # the whole step (zero_grad, forward, hand-written backward, AdamW, re-pack) as hipGraph replays;
+        # with N > 1 ranks the gradient all-reduce runs between two graphs (ctrlora_amd/train.py)
+        from ctrlora_amd.train import GraphedTrainStep
+        graphed = GraphedTrainStep(model, opt, data["z"][0], data["ctx"][0], data["hint"][0], data["t"][0],
+                                   data["noise"][0])
+
     def step(i):
         j = i % n_in
+        if graphed is not None:
+            return graphed(data["z"][j], data["ctx"][j], data["hint"][j], data["t"][j], data["noise"][j])
         opt.zero_grad()
         cond = {"c_crossattn": [data["ctx"][j]], "c_concat": [data["hint"][j]]}
         loss, _ = model.p_losses(data["z"][j], cond, data["t"][j], noise=data["noise"][j])
@@ -224,7 +235,8 @@ def main():
             "config": {"workload": f"ctrlora_finetune_sd15_rank{args.rank_lora}.yaml, canny-style latent hint, "
                                    f"512x512 (latent 64x64), per-GPU batch {B}, {args.dtype} storage / fp32 accumulate, "
                                    "synthetic latents + random-init weights, LoRA+zero-conv+norm trainables, fused AdamW",
-                       "global_batch": world * B, "parallelism": f"dp{world}", "lora_rank": args.rank_lora},
+                       "global_batch": world * B, "parallelism": f"dp{world}", "lora_rank": args.rank_lora,
+                       "launch": "eager" if args.no_graph else "hipGraph replay"},
             "loss": round(final_loss, 5),
         }
         achieved = tf_img * ips / world          # per-GPU TFLOP/s

@@ -45,6 +45,9 @@ class DDIMSampler(object):
         self.ddpm_num_timesteps = model.num_timesteps
         self.schedule = schedule
         self.batch_cfg = True
+        # capture one denoise step (both CFG passes + the fused update) as a hipGraph and replay it for the
+        # rest of the loop; set False to run every step eagerly
+        self.use_graph = True
 
     def register_buffer(self, name, attr):
         if isinstance(attr, torch.Tensor) and attr.device != self.model.device:
@@ -111,6 +114,10 @@ class DDIMSampler(object):
         intermediates = {"x_inter": [img], "pred_x0": [img]}
         time_range = np.flip(timesteps)
         total_steps = timesteps.shape[0]
+        if (self.use_graph and img.is_cuda and mask is None and ucg_schedule is None and total_steps >= 4
+                and noise_dropout == 0. and callable(getattr(self.model, "engine", None))):
+            return self._sampling_graphed(cond, img, timesteps, callback, img_callback, log_every_t, temperature,
+                                          unconditional_guidance_scale, unconditional_conditioning, intermediates)
         eng = getattr(self.model, "engine", None)
         if callable(eng):
             # text context is constant over the loop: project K/V of every cross-attention once
@@ -142,6 +149,74 @@ class DDIMSampler(object):
                 self.model.engine().cache_context_kv = False
                 self.model.engine().reset_context_cache()
         return img, intermediates
+
+    @torch.no_grad()
+    def _sampling_graphed(self, cond, img, timesteps, callback, img_callback, log_every_t, temperature, cfg_scale,
+                          uncond, intermediates):
+        """The S-step loop of ddim_sampling (:157-178) with the loop state on the DEVICE: a cursor i counts
+        iterations, `cl_ddim_set_t` derives ts = ddim_timesteps[S-1-i] and `cl_ddim_step_dev` the table row, so
+        one step = both CFG passes through the engine + the fused update is a fixed kernel sequence.  Iteration 0
+        runs eagerly (fills the context K/V cache, sizes every buffer), iteration 1 is captured, the rest replay."""
+        from ctrlora_amd import hip
+        model, device = self.model, img.device
+        S, b = int(timesteps.shape[0]), img.shape[0]
+        x = img.float().contiguous().clone()
+        pred_x0 = torch.empty_like(x)
+        ts = torch.zeros(b, dtype=torch.long, device=device)
+        cursor = torch.zeros(1, dtype=torch.int32, device=device)
+        table = torch.as_tensor(np.ascontiguousarray(timesteps).astype(np.int64)).to(device)
+        use_cfg = not (uncond is None or cfg_scale == 1.)
+        both = _cat_conds(cond, uncond) if (use_cfg and self.batch_cfg) else None
+        any_sigma = bool((self.coef_table[:, 2] != 0).any())
+
+        def body():
+            hip.ddim_set_t(table, cursor, S, ts)
+            e_u = None
+            if not use_cfg:
+                e_c = model.apply_model(x, ts, cond)
+            elif both is not None:
+                e = model.apply_model(torch.cat([x, x], 0), torch.cat([ts, ts], 0), both)
+                e_c, e_u = e[:b], e[b:]
+            else:
+                e_c = model.apply_model(x, ts, cond)
+                e_u = model.apply_model(x, ts, uncond)
+            # the reference draws the sigma*noise term every step (:227); with eta = 0 every sigma is zero and
+            # the draw cannot change the sample, so it is skipped (only the global RNG position differs)
+            noise = noise_like(x.shape, device, False) * temperature if any_sigma else None
+            hip.ddim_step_dev(x, e_c.float().contiguous(), None if e_u is None else e_u.float().contiguous(), noise,
+                              self.coef_table, cursor, S, float(cfg_scale), x, pred_x0)
+            hip.tick(cursor)
+
+        eng = model.engine()
+        eng.cache_context_kv = True
+        eng.reset_context_cache()
+        graph = None
+        try:
+            for i in range(S):
+                index = S - i - 1
+                if i == 0:
+                    body()
+                elif i == 1:
+                    torch.cuda.synchronize()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        body()
+                    graph.replay()      # capture does not execute
+                else:
+                    graph.replay()
+                if callback:
+                    callback(i)
+                if img_callback:
+                    img_callback(pred_x0, i)
+                if index % log_every_t == 0 or index == S - 1:
+                    intermediates["x_inter"].append(x.clone())
+                    intermediates["pred_x0"].append(pred_x0.clone())
+        finally:
+            eng.cache_context_kv = False
+            eng.reset_context_cache()
+        out = x.clone()
+        del graph
+        return out, intermediates
 
     @torch.no_grad()
     def p_sample_ddim(self, x, c, t, index, repeat_noise=False, use_original_steps=False, quantize_denoised=False,

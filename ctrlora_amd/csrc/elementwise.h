@@ -19,6 +19,11 @@ int qsample(const float* z, const float* noise, const long* t, const float* sqrt
 int mse_loss(const float* eps, const float* target, float* d_eps, float* loss, long n, float gscale, hipStream_t st);
 int ddim_step(const float* x, const float* e_c, const float* e_u, const float* noise, const float* coef, int index,
               float scale, float* x_prev, float* pred_x0, long n, hipStream_t st);
+int tick(int* counter, hipStream_t st);
+int adamw_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, int* step, hipStream_t st);
+int ddim_set_t(const long* table, const int* cursor, int S, long* ts, int n, hipStream_t st);
+int ddim_step_dev(const float* x, const float* e_c, const float* e_u, const float* noise, const float* coef,
+                  const int* cursor, int S, float scale, float* x_prev, float* pred_x0, long n, hipStream_t st);
 int adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
           float wd, int step, float gscale, hipStream_t st);
 int pool2x2(int dtype, const void* in, long ldi, void* out, long ldo, int B, int H, int W, int C, int accumulate, hipStream_t st);

@@ -233,6 +233,54 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 
+// ---------------------------------------------------------------- device-resident step state (hipGraph replay)
+// A captured graph replays the SAME kernel arguments, so anything that changes from step to step must
+// live in device memory: the optimizer step count / hyper-parameters and the DDIM loop cursor.
+__global__ void tick_kernel(int* c) { *c += 1; }
+
+// hyper = {lr, beta1, beta2, eps, weight_decay, grad_scale}; *step was already incremented for this step
+__global__ void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                 float* __restrict__ v, long n, const float* __restrict__ hyper,
+                                 const int* __restrict__ step) {
+  const float lr = hyper[0], beta1 = hyper[1], beta2 = hyper[2], eps = hyper[3], wd = hyper[4], gscale = hyper[5];
+  const float st = (float)*step;
+  const float bc1 = 1.0f - powf(beta1, st), bc2_sqrt = sqrtf(1.0f - powf(beta2, st));
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gscale;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= (lr / bc1) * mi / denom;
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+
+// DDIM loop with a device cursor i = 0..S-1 (ddim_hacked.py:157-160): index = S-1-i, ts = ddim_timesteps[index]
+__global__ void ddim_set_t_kernel(const long* __restrict__ table, const int* __restrict__ cursor, int S,
+                                  long* __restrict__ ts, int n) {
+  const int index = max(0, S - 1 - *cursor);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) ts[i] = table[index];
+}
+__global__ void ddim_step_dev_kernel(const float* __restrict__ x, const float* __restrict__ e_c,
+                                     const float* __restrict__ e_u, const float* __restrict__ noise,
+                                     const float* __restrict__ coef, const int* __restrict__ cursor, int S,
+                                     float scale, float* __restrict__ x_prev, float* __restrict__ pred_x0, long n) {
+  const int index = max(0, S - 1 - *cursor);
+  const float a_t = coef[index * 4 + 0], a_prev = coef[index * 4 + 1];
+  const float sigma = coef[index * 4 + 2], s1m = coef[index * 4 + 3];
+  const float sqrt_at = sqrtf(a_t), sqrt_ap = sqrtf(a_prev), dir = sqrtf(1.0f - a_prev - sigma * sigma);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float e = e_c[i];
+    if (e_u) { const float u = e_u[i]; e = u + scale * (e - u); }
+    const float p0 = (x[i] - s1m * e) / sqrt_at;
+    float xp = sqrt_ap * p0 + dir * e;
+    if (noise) xp += sigma * noise[i];
+    x_prev[i] = xp;            // x_prev may alias x (element-wise)
+    if (pred_x0) pred_x0[i] = p0;
+  }
+}
+
 // ---------------------------------------------------------------- 2x2 sum pool (data-gradient of nearest x2)
 // in [B, 2H, 2W, C] (ldi) -> out [B, H, W, C] (ldo), out (+)= sum of the 2x2 block
 template <typename T>
@@ -394,6 +442,24 @@ int adamw(float* p, const float* g, float* m, float* v, long n, float lr, float 
   const float bc1 = 1.0f - powf(beta1, (float)step);
   const float bc2 = 1.0f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n)), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, wd, bc1, sqrtf(bc2), gscale);
+  CL_CHECK_LAUNCH(); return CL_OK;
+}
+int tick(int* counter, hipStream_t st) {
+  hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(1), 0, st, counter);
+  CL_CHECK_LAUNCH(); return CL_OK;
+}
+int adamw_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, int* step, hipStream_t st) {
+  hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(1), 0, st, step);
+  hipLaunchKernelGGL(adamw_dev_kernel, dim3(ew_grid(n)), dim3(256), 0, st, p, g, m, v, n, hyper, step);
+  CL_CHECK_LAUNCH(); return CL_OK;
+}
+int ddim_set_t(const long* table, const int* cursor, int S, long* ts, int n, hipStream_t st) {
+  hipLaunchKernelGGL(ddim_set_t_kernel, dim3(1), dim3(256), 0, st, table, cursor, S, ts, n);
+  CL_CHECK_LAUNCH(); return CL_OK;
+}
+int ddim_step_dev(const float* x, const float* e_c, const float* e_u, const float* noise, const float* coef,
+                  const int* cursor, int S, float scale, float* x_prev, float* pred_x0, long n, hipStream_t st) {
+  hipLaunchKernelGGL(ddim_step_dev_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, e_c, e_u, noise, coef, cursor, S, scale, x_prev, pred_x0, n);
   CL_CHECK_LAUNCH(); return CL_OK;
 }
 int pool2x2(int dtype, const void* in, long ldi, void* out, long ldo, int B, int H, int W, int C, int accumulate, hipStream_t st) {

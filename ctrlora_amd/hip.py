@@ -87,6 +87,10 @@ _SIGS = {
     "cl_qsample": [_P, _P, _P, _P, _P, _P, _I, _L, _P],
     "cl_mse_loss": [_P, _P, _P, _P, _L, _F, _P],
     "cl_ddim_step": [_P, _P, _P, _P, _P, _I, _F, _P, _P, _L, _P],
+    "cl_tick": [_P, _P],
+    "cl_adamw_dev": [_P, _P, _P, _P, _L, _P, _P, _P],
+    "cl_ddim_set_t": [_P, _P, _I, _P, _I, _P],
+    "cl_ddim_step_dev": [_P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _L, _P],
     "cl_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
 }
 EXPORTED = tuple(_SIGS.keys())
@@ -387,3 +391,25 @@ def ddim_step(x, e_c, e_u, noise, coef, index, scale, x_prev, pred_x0=None):
 def adamw(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
     _chk(lib().cl_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
                         weight_decay, step, grad_scale, stream()), "cl_adamw")
+
+
+def tick(counter):
+    _chk(lib().cl_tick(counter.data_ptr(), stream()), "cl_tick")
+
+
+def adamw_dev(p, g, m, v, hyper, step):
+    """AdamW with device-resident hyper-parameters {lr, b1, b2, eps, wd, grad_scale} and step counter
+    (hipGraph-replayable: nothing step-dependent is a kernel argument)."""
+    _chk(lib().cl_adamw_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), hyper.data_ptr(),
+                            step.data_ptr(), stream()), "cl_adamw_dev")
+
+
+def ddim_set_t(table, cursor, S, ts):
+    _chk(lib().cl_ddim_set_t(table.data_ptr(), cursor.data_ptr(), S, ts.data_ptr(), ts.numel(), stream()), "cl_ddim_set_t")
+    return ts
+
+
+def ddim_step_dev(x, e_c, e_u, noise, coef, cursor, S, scale, x_prev, pred_x0=None):
+    _chk(lib().cl_ddim_step_dev(x.data_ptr(), e_c.data_ptr(), ptr(e_u), ptr(noise), coef.data_ptr(), cursor.data_ptr(),
+                                S, scale, x_prev.data_ptr(), ptr(pred_x0), x.numel(), stream()), "cl_ddim_step_dev")
+    return x_prev

@@ -69,28 +69,49 @@ class MSELossFn(torch.autograd.Function):
 
 class FusedAdamW(torch.optim.Optimizer):
     """AdamW over the engine's flat buffers.  `params` are the bound nn.Parameters (kept in param_groups
-    for scheduler / checkpoint compatibility); the arithmetic is one HIP kernel per ControlNet bank."""
+    for scheduler / checkpoint compatibility); the arithmetic is one HIP kernel per ControlNet bank.
+
+    Step count and hyper-parameters live in DEVICE memory (cl_adamw_dev), so that `step()` can be captured
+    in a hipGraph and replayed: a learning-rate schedule only has to refresh the 6-float `hyper` tensor
+    (`sync_hyper()`, done automatically outside capture)."""
 
     def __init__(self, params, executors, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
                  grad_scale: float = 1.0):
         super().__init__(list(params), dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.executors = list(executors)
         self.grad_scale = grad_scale
-        self._step = 0
+        dev = self.executors[0].tr.flat.device
+        self._step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._hyper = torch.zeros(6, dtype=torch.float32, device=dev)
+        self._hyper_host = None
         self._m = [torch.zeros_like(ex.tr.flat) for ex in self.executors]
         self._v = [torch.zeros_like(ex.tr.flat) for ex in self.executors]
         self.pre_step_hook = None     # e.g. DP: wait for the gradient all-reduce
+        self.sync_hyper()
+
+    @property
+    def _step(self) -> int:
+        return int(self._step_dev.item())
+
+    def sync_hyper(self):
+        """Push {lr, betas, eps, weight_decay, grad_scale} to the device if they changed (host -> device copy:
+        call it OUTSIDE graph capture / between replays)."""
+        g = self.param_groups[0]
+        cur = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+               float(self.grad_scale))
+        if cur != self._hyper_host:
+            self._hyper.copy_(torch.tensor(cur, dtype=torch.float32))
+            self._hyper_host = cur
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         if self.pre_step_hook is not None:
             self.pre_step_hook()
-        self._step += 1
-        g = self.param_groups[0]
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_hyper()
         for ex, m, v in zip(self.executors, self._m, self._v):
-            hip.adamw(ex.tr.flat, ex.tr.flat_grad, m, v, g["lr"], self._step, g["betas"][0], g["betas"][1], g["eps"],
-                      g["weight_decay"], self.grad_scale)
+            hip.adamw_dev(ex.tr.flat, ex.tr.flat_grad, m, v, self._hyper, self._step_dev)
             ex.repack()
         return loss
 
@@ -104,8 +125,82 @@ class FusedAdamW(torch.optim.Optimizer):
                     param_groups=[{k: v for k, v in g.items() if k != "params"} for g in self.param_groups])
 
     def load_state_dict(self, sd):
-        self._step = sd["step"]
+        self._step_dev.fill_(int(sd["step"]))
         for dst, src in zip(self._m, sd["m"]):
             dst.copy_(src)
         for dst, src in zip(self._v, sd["v"]):
             dst.copy_(src)
+
+
+class GraphedTrainStep:
+    """One optimizer step of LoRA fine-tuning as hipGraph replays.
+
+    The eager step is ~2800 kernel launches driven from Python through ctypes; at < 50 ms per step the host
+    becomes the bottleneck.  Everything in the step has static shapes and no host dependence (the optimizer's
+    step counter and hyper-parameters are device-resident), so it is captured once and replayed:
+
+        graph A : zero_grad -> p_losses forward -> hand-written backward      (all ranks, no collectives)
+        eager   : all-reduce of the flat LoRA gradient buffer over RCCL        (world_size > 1 only)
+        graph B : fused AdamW + re-pack of the trainables
+
+    With one rank, A and B are a single graph.  Inputs are copied into static buffers before each replay.
+    `model` is a ControlFinetuneLDM-like module (p_losses / dp / control_model), `opt` its FusedAdamW.
+    """
+
+    def __init__(self, model, opt, z, cond_txt, hint, t, noise, warmup: int = 2):
+        import torch.distributed as dist
+        self.model, self.opt = model, opt
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.dist = dist
+        self.s_z, self.s_ctx, self.s_hint = z.clone(), cond_txt.clone(), hint.clone()
+        self.s_t, self.s_noise = t.clone(), noise.clone()
+        self.loss = None
+        dp = model.dp
+        if dp is not None:
+            dp.enabled = False          # no collectives inside the captured region
+
+        def fwd_bwd():
+            opt.zero_grad()
+            cond = {"c_crossattn": [self.s_ctx], "c_concat": [self.s_hint]}
+            loss, _ = model.p_losses(self.s_z, cond, self.s_t, noise=self.s_noise)
+            loss.backward()
+            return loss.detach()
+
+        def reduce_grads():
+            if self.world > 1:
+                for ex in opt.executors:
+                    dist.all_reduce(ex.tr.flat_grad, op=dist.ReduceOp.SUM)
+
+        hook, opt.pre_step_hook = opt.pre_step_hook, None
+        self._hook = hook
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                fwd_bwd(); reduce_grads(); opt.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.g_a = torch.cuda.CUDAGraph()
+        if self.world == 1:
+            with torch.cuda.graph(self.g_a):
+                self.loss = fwd_bwd()
+                opt.step()
+            self.g_b = None
+        else:
+            with torch.cuda.graph(self.g_a):
+                self.loss = fwd_bwd()
+            self.g_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_b, pool=self.g_a.pool()):
+                opt.step()
+        self._reduce = reduce_grads
+        self.warmup_steps = warmup
+
+    def __call__(self, z, cond_txt, hint, t, noise):
+        self.s_z.copy_(z); self.s_ctx.copy_(cond_txt); self.s_hint.copy_(hint)
+        self.s_t.copy_(t); self.s_noise.copy_(noise)
+        self.opt.sync_hyper()
+        self.g_a.replay()
+        if self.g_b is not None:
+            self._reduce()
+            self.g_b.replay()
+        return self.loss

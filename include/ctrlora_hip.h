@@ -202,6 +202,18 @@ int cl_ddim_step(const float* x, const float* e_c, const float* e_u, const float
 int cl_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
              float eps, float weight_decay, int step, float grad_scale, void* stream);
 
+/* ---- device-resident step state: what a captured hipGraph needs --------------------------
+ * A replayed graph re-issues the same kernel arguments, so per-step scalars live in device memory.
+ * cl_tick: *counter += 1.  cl_adamw_dev: AdamW with hyper = device {lr, beta1, beta2, eps, weight_decay,
+ * grad_scale} and a device step counter (incremented first, as torch does).  cl_ddim_set_t / cl_ddim_step_dev:
+ * the DDIM loop body with a device cursor i (iteration number): index = S-1-i, ts[:] = ddim_timesteps[index]
+ * (cldm/ddim_hacked.py:157-160,203-231); x_prev may alias x. */
+int cl_tick(int* counter, void* stream);
+int cl_adamw_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, int* step, void* stream);
+int cl_ddim_set_t(const long* table, const int* cursor, int S, long* ts, int n, void* stream);
+int cl_ddim_step_dev(const float* x, const float* e_c, const float* e_u, const float* noise, const float* coef,
+                     const int* cursor, int S, float scale, float* x_prev, float* pred_x0, long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

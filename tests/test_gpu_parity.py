@@ -308,6 +308,45 @@ def test_api_training_step_and_ddim_through_the_drop_in_classes():
     assert rel_l2(samples, ref) < 5e-4
 
 
+def test_graphed_train_step_matches_eager_steps():
+    """hipGraph replay of the whole optimizer step (ctrlora_amd.train.GraphedTrainStep: device-resident AdamW
+    step counter / hyper-parameters) gives the same trajectory as eager launches."""
+    _need_gpu()
+    import bench
+    from ctrlora_amd.train import GraphedTrainStep
+    from oracle import arch
+    cfg = arch.TINY
+    inp = _inputs(cfg, 2, 16, 8)
+    cu = lambda v: v.cuda()
+
+    def make():
+        m = bench.build_model("ctrlora_finetune_sd15_rank128.yaml", 0, tiny=True).cuda().train()
+        m.set_engine_dtype(torch.float32)
+        m.learning_rate = 1e-3
+        return m, m.configure_optimizers()
+
+    ma, oa = make()
+    cond = {"c_crossattn": [cu(inp["ctx"])], "c_concat": [cu(inp["hint_z"])]}
+    losses = []
+    for _ in range(4):
+        oa.zero_grad()
+        loss, _ = ma.p_losses(cu(inp["z"]), cond, cu(inp["t"]), noise=cu(inp["noise"]))
+        loss.backward()
+        oa.step()
+        losses.append(float(loss))
+    mb, ob = make()
+    g = GraphedTrainStep(mb, ob, cu(inp["z"]), cu(inp["ctx"]), cu(inp["hint_z"]), cu(inp["t"]), cu(inp["noise"]),
+                         warmup=2)                                  # steps 1-2 run eagerly inside
+    l3 = float(g(cu(inp["z"]), cu(inp["ctx"]), cu(inp["hint_z"]), cu(inp["t"]), cu(inp["noise"])))
+    l4 = float(g(cu(inp["z"]), cu(inp["ctx"]), cu(inp["hint_z"]), cu(inp["t"]), cu(inp["noise"])))
+    assert ob._step == 4
+    assert abs(l3 - losses[2]) < 1e-4 * abs(losses[2]) and abs(l4 - losses[3]) < 1e-4 * abs(losses[3])
+    assert losses[3] != losses[2]
+    pa, pb = dict(ma.control_model.named_parameters()), dict(mb.control_model.named_parameters())
+    k = "zero_convs.3.0.weight"
+    assert rel_l2(pb[k].detach(), pa[k].detach().cpu()) < 1e-4
+
+
 def test_lora_modules_standalone_on_gpu():
     _need_gpu()
     from cldm.lora import LoRACompatibleLinear, LoRALinearLayer
