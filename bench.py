@@ -190,8 +190,16 @@ def main():
         # the whole step (zero_grad, forward, hand-written backward, AdamW, re-pack) as hipGraph replays;
         # with N > 1 ranks the gradient all-reduce runs between two graphs (ctrlora_amd/train.py)
         from ctrlora_amd.train import GraphedTrainStep
-        graphed = GraphedTrainStep(model, opt, data["z"][0], data["ctx"][0], data["hint"][0], data["t"][0],
-                                   data["noise"][0])
+        try:
+            graphed = GraphedTrainStep(model, opt, data["z"][0], data["ctx"][0], data["hint"][0], data["t"][0],
+                                       data["noise"][0])
+        except Exception as e:   # capture is an optimisation: never lose the measurement to it
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches",
+                  file=sys.stderr)
+            graphed, args.no_graph = None, True
+            if model.dp is not None:
+                model.dp.enabled = True
+                opt.pre_step_hook = model.dp.wait
 
     def step(i):
         j = i % n_in
