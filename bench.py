@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ddim", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--ddim-only", action="store_true", help="profiling aid: run only the DDIM leg")
     ap.add_argument("--tiny", action="store_true", help="debug: narrow model")
     args = ap.parse_args()
 
@@ -173,6 +174,9 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    if args.ddim_only:
+        print(json.dumps(ddim_bench(device, dtype, tiny=args.tiny)))
+        return
 
     model = build_model(f"ctrlora_finetune_sd15_rank{args.rank_lora}.yaml", 0, tiny=args.tiny).to(device).train()
     model.set_engine_dtype(dtype)

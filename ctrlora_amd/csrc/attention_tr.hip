@@ -23,6 +23,7 @@
 // fragment feeds KF MFMAs), loop over 64-query tiles {Q, dO, lse, delta} double buffered;
 // dQ kernel = 64*QF queries per workgroup, loop over 64-key tiles {K, V}.  log-sum-exp and delta
 // ride in the tile (LDS broadcast reads) instead of per-fragment global loads.
+#include <type_traits>
 #include "attn_common.h"
 
 namespace cl {
@@ -49,25 +50,50 @@ template <int ROWB, int STEP> __device__ __forceinline__ u32x4_t tr_frag(uint32_
   return u32x4_t{lo.x, lo.y, hi.x, hi.y};
 }
 
-// 64-row tile, rows `row0 + r` of a [rows, ld] bf16 matrix (head slice already applied to `base`),
-// rows clamped to nrows-1; wave w issues instructions w, w+4, ...
-template <int DH>
-__device__ __forceinline__ void stage_tile(const char* base, long ld_bytes, int row0, int nrows, char* dst, int wave,
-                                           int lane) {
-  using G = Geo<DH>;
-  for (int ii = wave; ii < G::TI; ii += 4) {
-    const int c = ii * 64 + lane;
-    const int r = c / G::CPR, cc = c - r * G::CPR;
-    const int rr = min(row0 + r, nrows - 1);
-    glds16(base + (long)rr * ld_bytes + cc * 16, dst + ii * 1024);
+// Staging of 64-row tiles of a [rows, ld] bf16 matrix (head slice already applied to `base`); wave w issues
+// DMA instructions w, w+4, ...  PMC showed the forward VALU-bound (SQ_ACTIVE_INST_VALU ~ 90 % of the kernel)
+// with ~30 % of the vector instructions spent on per-tile DMA address generation (divide by chunks-per-row,
+// clamp, 64-bit multiply), so the per-lane (row, chunk) decomposition is done ONCE and a full tile costs one
+// 64-bit add per instruction; only the ragged last tile clamps rows.
+template <int DH> struct TileDma {
+  static constexpr int TI = Geo<DH>::TI, NJ = (TI + 3) / 4, CPR = Geo<DH>::CPR;
+  int r[NJ], cc16[NJ];
+  __device__ __forceinline__ void init(int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = (wave + 4 * j) * 64 + lane;
+      r[j] = c / CPR;
+      cc16[j] = (c - r[j] * CPR) * 16;
+    }
   }
-}
+  __device__ __forceinline__ void offsets(long ld_bytes, int (&off)[NJ]) const {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) off[j] = r[j] * (int)ld_bytes + cc16[j];
+  }
+  __device__ __forceinline__ void issue(const char* base, long ld_bytes, const int (&off)[NJ], int row0, int nrows,
+                                        char* dst, int wave) const {
+    const char* tb = base + (long)row0 * ld_bytes;      // wave-uniform
+    if (row0 + 64 <= nrows) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        if (wave + 4 * j < TI) glds16(tb + off[j], dst + (wave + 4 * j) * 1024);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        if (wave + 4 * j < TI) {
+          const int rr = min(row0 + r[j], nrows - 1);
+          glds16(base + (long)rr * ld_bytes + cc16[j], dst + (wave + 4 * j) * 1024);
+        }
+    }
+  }
+};
 
 }  // namespace
 
 // =============================================================================== forward
-template <int DH, int QW>
-__global__ __launch_bounds__(256) void attn_fwd_tr_kernel(AttnFwdArgs p, const void* __restrict__ V, long ldv) {
+// TAIL: Nkv is not a multiple of 64 (cross-attention's 77 keys): only that instantiation carries key masking
+template <int DH, int QW, bool TAIL>
+__global__ __launch_bounds__(256, 2) void attn_fwd_tr_kernel(AttnFwdArgs p, const void* __restrict__ V, long ldv) {
   using G = Geo<DH>;
   constexpr int CPR = G::CPR, KSTEPS = G::KSTEPS, DN = G::DN, ROWB = G::ROWB, TILE = G::TILE;
   constexpr int STAGE = 2 * TILE;
@@ -101,25 +127,30 @@ __global__ __launch_bounds__(256) void attn_fwd_tr_kernel(AttnFwdArgs p, const v
     for (int f = 0; f < QW; ++f) ot[i][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   float m_run[QW], l_run[QW];
 #pragma unroll
-  for (int f = 0; f < QW; ++f) { m_run[f] = -1e30f; l_run[f] = 0.f; }
+  for (int f = 0; f < QW; ++f) { m_run[f] = -1e30f; l_run[f] = 0.f; }   // finite: exp2(m_run - m_new) must not see inf - inf
 
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
   const uint32_t krow = lq * ROWB + g * 16;                                    // b128: row lq, chunk g (+4 ks)
   const uint32_t troff = (4 * g + ((lane >> 2) & 3)) * ROWB + (lane & 3) * 8;  // transpose read: row 4g+j, cols 4q
   const int ntiles = (p.Nkv + 63) / 64;
-  stage_tile<DH>(kbase, p.ldk * 2, 0, p.Nkv, smem, wave, lane);
-  stage_tile<DH>(vbase, ldv * 2, 0, p.Nkv, smem + TILE, wave, lane);
+  TileDma<DH> dma; dma.init(wave, lane);
+  int koff[TileDma<DH>::NJ], voff[TileDma<DH>::NJ];
+  dma.offsets(p.ldk * 2, koff); dma.offsets(ldv * 2, voff);
+  dma.issue(kbase, p.ldk * 2, koff, 0, p.Nkv, smem, wave);
+  dma.issue(vbase, ldv * 2, voff, 0, p.Nkv, smem + TILE, wave);
   for (int t = 0; t < ntiles; ++t) {
     const int buf = t & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t + 1 < ntiles) {
-      stage_tile<DH>(kbase, p.ldk * 2, (t + 1) * 64, p.Nkv, smem + (buf ^ 1) * STAGE, wave, lane);
-      stage_tile<DH>(vbase, ldv * 2, (t + 1) * 64, p.Nkv, smem + (buf ^ 1) * STAGE + TILE, wave, lane);
+      dma.issue(kbase, p.ldk * 2, koff, (t + 1) * 64, p.Nkv, smem + (buf ^ 1) * STAGE, wave);
+      dma.issue(vbase, ldv * 2, voff, (t + 1) * 64, p.Nkv, smem + (buf ^ 1) * STAGE + TILE, wave);
     }
     const uint32_t kt = lds0 + buf * STAGE, vt = kt + TILE;
 
     // ---- S^T = K . Q^T   (rows = keys 16 kf + 4g + r, col = query lq)
+    // (software-pipelining the LDS reads one fragment ahead was measured: no gain -- the kernel is VALU-bound
+    // and the other resident waves already cover LDS latency -- and it cost an occupancy step in registers)
     f32x4_t st[4][QW];
 #pragma unroll
     for (int kf = 0; kf < 4; ++kf) {
@@ -135,38 +166,37 @@ __global__ __launch_bounds__(256) void attn_fwd_tr_kernel(AttnFwdArgs p, const v
         for (int ks = 0; ks < KSTEPS; ++ks) Mma<bf16_t>::run(ka[ks], qf[f][ks], st[kf][f]);
       }
     }
-    // ---- online softmax: lane owns query lq of each q fragment
+    // ---- online softmax: lane owns query lq of each q fragment; max on the raw scores, one fma + exp2 each
     const int kv0 = t * 64;
-    const bool tail = kv0 + 64 > p.Nkv;
+    {
 #pragma unroll
-    for (int f = 0; f < QW; ++f) {
-      float mx = -1e30f;
+      for (int f = 0; f < QW; ++f) {
+        float mx = -INFINITY;
 #pragma unroll
-      for (int kf = 0; kf < 4; ++kf)
+        for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float s = st[kf][f][r] * sl2;
-          if (tail && kv0 + kf * 16 + 4 * g + r >= p.Nkv) s = -INFINITY;
-          st[kf][f][r] = s;
-          mx = fmaxf(mx, s);
-        }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run[f], mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);
-      m_run[f] = m_new;
-      float ls = 0.f;
+          for (int r = 0; r < 4; ++r) {
+            if constexpr (TAIL) { if (kv0 + kf * 16 + 4 * g + r >= p.Nkv) st[kf][f][r] = -INFINITY; }
+            mx = fmaxf(mx, st[kf][f][r]);
+          }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run[f], mx * sl2);      // sl2 > 0
+        const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);
+        m_run[f] = m_new;
+        float ls = 0.f;
 #pragma unroll
-      for (int kf = 0; kf < 4; ++kf)
+        for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(st[kf][f][r] - m_new);
-          st[kf][f][r] = e;
-          ls += e;
-        }
-      l_run[f] = l_run[f] * alpha + ls;
+          for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kf][f][r], sl2, -m_new));
+            st[kf][f][r] = e;
+            ls += e;
+          }
+        l_run[f] = l_run[f] * alpha + ls;
 #pragma unroll
-      for (int i = 0; i < DN; ++i) ot[i][f] *= alpha;
+        for (int i = 0; i < DN; ++i) ot[i][f] *= alpha;
+      }
     }
     // ---- O^T += V^T . P^T   (A = V^T via transpose reads of the row-major V tile)
     u32x4_t pb[2][QW];
@@ -214,8 +244,9 @@ __global__ __launch_bounds__(256) void attn_fwd_tr_kernel(AttnFwdArgs p, const v
 }
 
 // =============================================================================== dK / dV
-template <int DH, int KF>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_tr_kernel(AttnBwdArgs p) {
+// TAIL: N is not a multiple of 64 (query masking)
+template <int DH, int KF, bool TAIL>
+__global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_tr_kernel(AttnBwdArgs p) {
   using G = Geo<DH>;
   constexpr int CPR = G::CPR, KSTEPS = G::KSTEPS, DN = G::DN, ROWB = G::ROWB, TILE = G::TILE, TI = G::TI;
   constexpr int STAGE = 2 * TILE + 512;     // Q tile, dO tile, lse[64], delta[64]
@@ -253,10 +284,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_tr_kernel(AttnBwdArgs p) {
 #pragma unroll
     for (int i = 0; i < DN; ++i) { dvt[kf][i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dkt[kf][i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 
+  TileDma<DH> dma; dma.init(wave, lane);
+  int qoff[TileDma<DH>::NJ], dooff[TileDma<DH>::NJ];
+  dma.offsets(p.ldq * 2, qoff); dma.offsets(p.lddo * 2, dooff);
   auto issue = [&](int t, int buf) {
     char* base = smem + buf * STAGE;
-    stage_tile<DH>(qbase, p.ldq * 2, t * 64, p.N, base, wave, lane);
-    stage_tile<DH>(dobase, p.lddo * 2, t * 64, p.N, base + TILE, wave, lane);
+    dma.issue(qbase, p.ldq * 2, qoff, t * 64, p.N, base, wave);
+    dma.issue(dobase, p.lddo * 2, dooff, t * 64, p.N, base + TILE, wave);
     if (wave == (TI & 3) && lane < 32) {   // lse (lanes 0-15) and delta (16-31), 64 floats each; lse_stride % 64 == 0
       const float* src = lane < 16 ? lse + t * 64 + lane * 4 : dlt + t * 64 + (lane - 16) * 4;
       glds16(src, base + 2 * TILE);
@@ -278,32 +312,35 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_tr_kernel(AttnBwdArgs p) {
 
     // ---- S = Q K^T, dP = dO V^T  (rows = queries 16 qf + 4g + r, col = key lq)
     f32x4_t ps[KF][4], ds[KF][4];
+    {
 #pragma unroll
-    for (int qf = 0; qf < 4; ++qf) {
-      u32x4_t qa[KSTEPS], da[KSTEPS];
+      for (int qf = 0; qf < 4; ++qf) {
+        u32x4_t qa[KSTEPS], da[KSTEPS];
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
-        const bool in = 4 * ks + g < CPR;
-        qa[ks] = in ? lds_read_b128(aQ + rrow + qf * 16 * ROWB + ks * 64) : u32x4_t{0u, 0u, 0u, 0u};
-        da[ks] = in ? lds_read_b128(adO + rrow + qf * 16 * ROWB + ks * 64) : u32x4_t{0u, 0u, 0u, 0u};
-      }
-      const u32x4_t l4 = lds_read_b128(aL + (qf * 16 + 4 * g) * 4);
-      const u32x4_t d4 = lds_read_b128(aL + 256 + (qf * 16 + 4 * g) * 4);
-      lds_wait();
-      const float lv[4] = {__uint_as_float(l4.x), __uint_as_float(l4.y), __uint_as_float(l4.z), __uint_as_float(l4.w)};
-      const float dv[4] = {__uint_as_float(d4.x), __uint_as_float(d4.y), __uint_as_float(d4.z), __uint_as_float(d4.w)};
-      const int qrow = q0 + qf * 16 + 4 * g;
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          const bool in = 4 * ks + g < CPR;
+          qa[ks] = in ? lds_read_b128(aQ + rrow + qf * 16 * ROWB + ks * 64) : u32x4_t{0u, 0u, 0u, 0u};
+          da[ks] = in ? lds_read_b128(adO + rrow + qf * 16 * ROWB + ks * 64) : u32x4_t{0u, 0u, 0u, 0u};
+        }
+        const u32x4_t l4 = lds_read_b128(aL + (qf * 16 + 4 * g) * 4);
+        const u32x4_t d4 = lds_read_b128(aL + 256 + (qf * 16 + 4 * g) * 4);
+        lds_wait();
+        const float lv[4] = {__uint_as_float(l4.x), __uint_as_float(l4.y), __uint_as_float(l4.z), __uint_as_float(l4.w)};
+        const float dv[4] = {__uint_as_float(d4.x), __uint_as_float(d4.y), __uint_as_float(d4.z), __uint_as_float(d4.w)};
+        const int qrow = q0 + qf * 16 + 4 * g;
 #pragma unroll
-      for (int kf = 0; kf < KF; ++kf) {
-        f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        for (int kf = 0; kf < KF; ++kf) {
+          f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) { Mma<bf16_t>::run(qa[ks], kb[kf][ks], s); Mma<bf16_t>::run(da[ks], vb[kf][ks], dp); }
+          for (int ks = 0; ks < KSTEPS; ++ks) { Mma<bf16_t>::run(qa[ks], kb[kf][ks], sc); Mma<bf16_t>::run(da[ks], vb[kf][ks], dp); }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool ok = qrow + r < p.N;
-          const float pr = ok ? __builtin_amdgcn_exp2f(s[r] * sl2 - lv[r]) : 0.f;
-          ps[kf][qf][r] = pr;
-          ds[kf][qf][r] = ok ? pr * (dp[r] - dv[r]) * p.scale : 0.f;
+          for (int r = 0; r < 4; ++r) {
+            float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], sl2, -lv[r]));
+            float dsv = pr * (dp[r] - dv[r]) * p.scale;
+            if constexpr (TAIL) { if (qrow + r >= p.N) { pr = 0.f; dsv = 0.f; } }   // lse / delta pads may hold NaN
+            ps[kf][qf][r] = pr;
+            ds[kf][qf][r] = dsv;
+          }
         }
       }
     }
@@ -312,17 +349,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_tr_kernel(AttnBwdArgs p) {
 #pragma unroll
     for (int kf = 0; kf < KF; ++kf)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) { pb[kf][s] = PFrag<bf16_t>::make(&ps[kf][2 * s]); sb[kf][s] = PFrag<bf16_t>::make(&ds[kf][2 * s]); }
+      for (int s2 = 0; s2 < 2; ++s2) { pb[kf][s2] = PFrag<bf16_t>::make(&ps[kf][2 * s2]); sb[kf][s2] = PFrag<bf16_t>::make(&ds[kf][2 * s2]); }
 #pragma unroll
     for (int i = 0; i < DN; ++i) {
-      u32x4_t oa[2], qa[2];
+      u32x4_t oa[2], qt[2];
       oa[0] = tr_frag<ROWB, 0>(adO + troff + i * 32); oa[1] = tr_frag<ROWB, 1>(adO + troff + i * 32);
-      qa[0] = tr_frag<ROWB, 0>(aQ + troff + i * 32); qa[1] = tr_frag<ROWB, 1>(aQ + troff + i * 32);
+      qt[0] = tr_frag<ROWB, 0>(aQ + troff + i * 32); qt[1] = tr_frag<ROWB, 1>(aQ + troff + i * 32);
       lds_wait();
 #pragma unroll
       for (int kf = 0; kf < KF; ++kf)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) { Mma<bf16_t>::run(oa[s], pb[kf][s], dvt[kf][i]); Mma<bf16_t>::run(qa[s], sb[kf][s], dkt[kf][i]); }
+        for (int s2 = 0; s2 < 2; ++s2) { Mma<bf16_t>::run(oa[s2], pb[kf][s2], dvt[kf][i]); Mma<bf16_t>::run(qt[s2], sb[kf][s2], dkt[kf][i]); }
     }
   }
   // ---- store dK / dV rows (4 consecutive d per lane)
@@ -347,8 +384,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_tr_kernel(AttnBwdArgs p) {
 }
 
 // =============================================================================== dQ
-template <int DH, int QF>
-__global__ __launch_bounds__(256) void attn_bwd_dq_tr_kernel(AttnBwdArgs p) {
+// TAIL: Nkv is not a multiple of 64 (key masking)
+template <int DH, int QF, bool TAIL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_tr_kernel(AttnBwdArgs p) {
   using G = Geo<DH>;
   constexpr int CPR = G::CPR, KSTEPS = G::KSTEPS, DN = G::DN, ROWB = G::ROWB, TILE = G::TILE;
   constexpr int STAGE = 2 * TILE;           // K tile, V tile
@@ -390,41 +428,46 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_tr_kernel(AttnBwdArgs p) {
   const uint32_t rrow = lq * ROWB + g * 16;
   const uint32_t troff = (4 * g + ((lane >> 2) & 3)) * ROWB + (lane & 3) * 8;
   const int ntiles = (p.Nkv + 63) / 64;
-  stage_tile<DH>(kbase, p.ldk * 2, 0, p.Nkv, smem, wave, lane);
-  stage_tile<DH>(vbase, p.ldv * 2, 0, p.Nkv, smem + TILE, wave, lane);
+  TileDma<DH> dma; dma.init(wave, lane);
+  int koff[TileDma<DH>::NJ], voff[TileDma<DH>::NJ];
+  dma.offsets(p.ldk * 2, koff); dma.offsets(p.ldv * 2, voff);
+  dma.issue(kbase, p.ldk * 2, koff, 0, p.Nkv, smem, wave);
+  dma.issue(vbase, p.ldv * 2, voff, 0, p.Nkv, smem + TILE, wave);
   for (int t = 0; t < ntiles; ++t) {
     const int buf = t & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t + 1 < ntiles) {
-      stage_tile<DH>(kbase, p.ldk * 2, (t + 1) * 64, p.Nkv, smem + (buf ^ 1) * STAGE, wave, lane);
-      stage_tile<DH>(vbase, p.ldv * 2, (t + 1) * 64, p.Nkv, smem + (buf ^ 1) * STAGE + TILE, wave, lane);
+      dma.issue(kbase, p.ldk * 2, koff, (t + 1) * 64, p.Nkv, smem + (buf ^ 1) * STAGE, wave);
+      dma.issue(vbase, p.ldv * 2, voff, (t + 1) * 64, p.Nkv, smem + (buf ^ 1) * STAGE + TILE, wave);
     }
     const uint32_t aK = lds0 + buf * STAGE, aV = aK + TILE;
     const int kv0 = t * 64;
 
     // ---- S^T = K Q^T, dP^T = V dO^T  (rows = keys 16 kf + 4g + r, col = query lq)
     f32x4_t dst[QF][4];
+    {
 #pragma unroll
-    for (int kf = 0; kf < 4; ++kf) {
-      u32x4_t ka[KSTEPS], va[KSTEPS];
+      for (int kf = 0; kf < 4; ++kf) {
+        u32x4_t ka[KSTEPS], va[KSTEPS];
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
-        const bool in = 4 * ks + g < CPR;
-        ka[ks] = in ? lds_read_b128(aK + rrow + kf * 16 * ROWB + ks * 64) : u32x4_t{0u, 0u, 0u, 0u};
-        va[ks] = in ? lds_read_b128(aV + rrow + kf * 16 * ROWB + ks * 64) : u32x4_t{0u, 0u, 0u, 0u};
-      }
-      lds_wait();
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          const bool in = 4 * ks + g < CPR;
+          ka[ks] = in ? lds_read_b128(aK + rrow + kf * 16 * ROWB + ks * 64) : u32x4_t{0u, 0u, 0u, 0u};
+          va[ks] = in ? lds_read_b128(aV + rrow + kf * 16 * ROWB + ks * 64) : u32x4_t{0u, 0u, 0u, 0u};
+        }
+        lds_wait();
 #pragma unroll
-      for (int f = 0; f < QF; ++f) {
-        f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        for (int f = 0; f < QF; ++f) {
+          f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) { Mma<bf16_t>::run(ka[ks], qb[f][ks], s); Mma<bf16_t>::run(va[ks], ob[f][ks], dp); }
+          for (int ks = 0; ks < KSTEPS; ++ks) { Mma<bf16_t>::run(ka[ks], qb[f][ks], sc); Mma<bf16_t>::run(va[ks], ob[f][ks], dp); }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool ok = kv0 + kf * 16 + 4 * g + r < p.Nkv;
-          const float pr = ok ? __builtin_amdgcn_exp2f(s[r] * sl2 - lse_q[f]) : 0.f;
-          dst[f][kf][r] = ok ? pr * (dp[r] - dlt_q[f]) * p.scale : 0.f;
+          for (int r = 0; r < 4; ++r) {
+            float dsv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], sl2, -lse_q[f])) * (dp[r] - dlt_q[f]) * p.scale;
+            if constexpr (TAIL) { if (kv0 + kf * 16 + 4 * g + r >= p.Nkv) dsv = 0.f; }
+            dst[f][kf][r] = dsv;
+          }
         }
       }
     }
@@ -433,16 +476,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_tr_kernel(AttnBwdArgs p) {
 #pragma unroll
     for (int f = 0; f < QF; ++f)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) sb[f][s] = PFrag<bf16_t>::make(&dst[f][2 * s]);
+      for (int s2 = 0; s2 < 2; ++s2) sb[f][s2] = PFrag<bf16_t>::make(&dst[f][2 * s2]);
 #pragma unroll
     for (int i = 0; i < DN; ++i) {
-      u32x4_t ka[2];
-      ka[0] = tr_frag<ROWB, 0>(aK + troff + i * 32); ka[1] = tr_frag<ROWB, 1>(aK + troff + i * 32);
+      u32x4_t kc[2];
+      kc[0] = tr_frag<ROWB, 0>(aK + troff + i * 32); kc[1] = tr_frag<ROWB, 1>(aK + troff + i * 32);
       lds_wait();
 #pragma unroll
       for (int f = 0; f < QF; ++f)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) Mma<bf16_t>::run(ka[s], sb[f][s], dqt[f][i]);
+        for (int s2 = 0; s2 < 2; ++s2) Mma<bf16_t>::run(kc[s2], sb[f][s2], dqt[f][i]);
     }
   }
 #pragma unroll
@@ -471,49 +514,54 @@ static int set_lds(K kern, int bytes) {
   return CL_OK;
 }
 
-template <int DH>
+template <int DH, bool TAIL>
 static int launch_fwd_tr(const AttnFwdArgs& a, const void* V, long ldv, hipStream_t st) {
   constexpr int LDS = 2 * 2 * Geo<DH>::TILE + 64 + 16 * Geo<DH>::ROWB;
   constexpr int QW = DH <= 80 ? 2 : 1;
   static bool done = false;
   if (!done) {
-    if (set_lds(&attn_fwd_tr_kernel<DH, 2>, LDS) || set_lds(&attn_fwd_tr_kernel<DH, 1>, LDS)) return CL_ELAUNCH;
+    if (set_lds(&attn_fwd_tr_kernel<DH, QW, TAIL>, LDS) || set_lds(&attn_fwd_tr_kernel<DH, 1, TAIL>, LDS)) return CL_ELAUNCH;
     done = true;
   }
   const long blocks128 = (long)((a.N + 127) / 128) * a.H * a.B;
   if (QW == 2 && blocks128 >= 512) {
     dim3 grid((a.N + 127) / 128, a.H, a.B);
-    hipLaunchKernelGGL((attn_fwd_tr_kernel<DH, 2>), grid, dim3(256), LDS, st, a, V, ldv);
+    hipLaunchKernelGGL((attn_fwd_tr_kernel<DH, QW, TAIL>), grid, dim3(256), LDS, st, a, V, ldv);
   } else {
     dim3 grid((a.N + 63) / 64, a.H, a.B);
-    hipLaunchKernelGGL((attn_fwd_tr_kernel<DH, 1>), grid, dim3(256), LDS, st, a, V, ldv);
+    hipLaunchKernelGGL((attn_fwd_tr_kernel<DH, 1, TAIL>), grid, dim3(256), LDS, st, a, V, ldv);
   }
   CL_CHECK_LAUNCH();
   return CL_OK;
 }
 
+template <int DH>
+static int launch_fwd_tr_t(const AttnFwdArgs& a, const void* V, long ldv, hipStream_t st) {
+  return (a.Nkv % 64) ? launch_fwd_tr<DH, true>(a, V, ldv, st) : launch_fwd_tr<DH, false>(a, V, ldv, st);
+}
+
 int attn_fwd_tr(const AttnFwdArgs& a, const void* V, long ldv, hipStream_t st) {
   if ((a.ldq * 2) % 16 || (a.ldk * 2) % 16 || (ldv * 2) % 16 || (a.ldo * 2) % 16 || a.Nkv < 1 || a.N < 1) return CL_EINVAL;
   switch (a.DH) {
-    case 8: return launch_fwd_tr<8>(a, V, ldv, st);
-    case 16: return launch_fwd_tr<16>(a, V, ldv, st);
-    case 32: return launch_fwd_tr<32>(a, V, ldv, st);
-    case 40: return launch_fwd_tr<40>(a, V, ldv, st);
-    case 80: return launch_fwd_tr<80>(a, V, ldv, st);
-    case 160: return launch_fwd_tr<160>(a, V, ldv, st);
+    case 8: return launch_fwd_tr_t<8>(a, V, ldv, st);
+    case 16: return launch_fwd_tr_t<16>(a, V, ldv, st);
+    case 32: return launch_fwd_tr_t<32>(a, V, ldv, st);
+    case 40: return launch_fwd_tr_t<40>(a, V, ldv, st);
+    case 80: return launch_fwd_tr_t<80>(a, V, ldv, st);
+    case 160: return launch_fwd_tr_t<160>(a, V, ldv, st);
     default: return CL_EINVAL;
   }
 }
 
-template <int DH>
+template <int DH, bool TQ, bool TK>
 static int launch_bwd_tr(const AttnBwdArgs& a, hipStream_t st) {
-  constexpr int KF = DH <= 80 ? 2 : 1;
+  constexpr int KF = DH <= 40 ? 2 : 1;     // key / query fragments per wave (register budget: <= 256 VGPRs)
   constexpr int LDS_DKV = 2 * (2 * Geo<DH>::TILE + 512) + 64 + 16 * Geo<DH>::ROWB;
   constexpr int LDS_DQ = 2 * 2 * Geo<DH>::TILE + 64 + 16 * Geo<DH>::ROWB;
   static bool done = false;
   if (!done) {
-    if (set_lds(&attn_bwd_dkv_tr_kernel<DH, KF>, LDS_DKV) || set_lds(&attn_bwd_dkv_tr_kernel<DH, 1>, LDS_DKV) ||
-        set_lds(&attn_bwd_dq_tr_kernel<DH, KF>, LDS_DQ) || set_lds(&attn_bwd_dq_tr_kernel<DH, 1>, LDS_DQ))
+    if (set_lds(&attn_bwd_dkv_tr_kernel<DH, KF, TQ>, LDS_DKV) || set_lds(&attn_bwd_dkv_tr_kernel<DH, 1, TQ>, LDS_DKV) ||
+        set_lds(&attn_bwd_dq_tr_kernel<DH, KF, TK>, LDS_DQ) || set_lds(&attn_bwd_dq_tr_kernel<DH, 1, TK>, LDS_DQ))
       return CL_ELAUNCH;
     done = true;
   }
@@ -524,22 +572,29 @@ static int launch_bwd_tr(const AttnBwdArgs& a, hipStream_t st) {
     const long blocks2 = (long)((a.Nkv + 64 * KF - 1) / (64 * KF)) * a.H * a.B;
     if (KF == 2 && blocks2 >= 512) {
       dim3 grid((a.Nkv + 127) / 128, a.H, a.B);
-      hipLaunchKernelGGL((attn_bwd_dkv_tr_kernel<DH, KF>), grid, dim3(256), LDS_DKV, st, a);
+      hipLaunchKernelGGL((attn_bwd_dkv_tr_kernel<DH, KF, TQ>), grid, dim3(256), LDS_DKV, st, a);
     } else {
       dim3 grid((a.Nkv + 63) / 64, a.H, a.B);
-      hipLaunchKernelGGL((attn_bwd_dkv_tr_kernel<DH, 1>), grid, dim3(256), LDS_DKV, st, a);
+      hipLaunchKernelGGL((attn_bwd_dkv_tr_kernel<DH, 1, TQ>), grid, dim3(256), LDS_DKV, st, a);
     }
   }
   const long qblocks2 = (long)((a.N + 64 * KF - 1) / (64 * KF)) * a.H * a.B;
   if (KF == 2 && qblocks2 >= 512) {
     dim3 grid((a.N + 127) / 128, a.H, a.B);
-    hipLaunchKernelGGL((attn_bwd_dq_tr_kernel<DH, KF>), grid, dim3(256), LDS_DQ, st, a);
+    hipLaunchKernelGGL((attn_bwd_dq_tr_kernel<DH, KF, TK>), grid, dim3(256), LDS_DQ, st, a);
   } else {
     dim3 grid((a.N + 63) / 64, a.H, a.B);
-    hipLaunchKernelGGL((attn_bwd_dq_tr_kernel<DH, 1>), grid, dim3(256), LDS_DQ, st, a);
+    hipLaunchKernelGGL((attn_bwd_dq_tr_kernel<DH, 1, TK>), grid, dim3(256), LDS_DQ, st, a);
   }
   CL_CHECK_LAUNCH();
   return CL_OK;
+}
+
+template <int DH>
+static int launch_bwd_tr_t(const AttnBwdArgs& a, hipStream_t st) {
+  const bool tq = a.N % 64, tk = a.Nkv % 64;
+  if (tq) return tk ? launch_bwd_tr<DH, true, true>(a, st) : launch_bwd_tr<DH, true, false>(a, st);
+  return tk ? launch_bwd_tr<DH, false, true>(a, st) : launch_bwd_tr<DH, false, false>(a, st);
 }
 
 int attn_bwd_tr(const AttnBwdArgs& a, hipStream_t st) {
@@ -548,12 +603,12 @@ int attn_bwd_tr(const AttnBwdArgs& a, hipStream_t st) {
   if ((a.dK == nullptr) != (a.dV == nullptr)) return CL_EINVAL;
   if (a.dK && ((a.lddk * 2) % 16 || (a.lddv * 2) % 16)) return CL_EINVAL;
   switch (a.DH) {
-    case 8: return launch_bwd_tr<8>(a, st);
-    case 16: return launch_bwd_tr<16>(a, st);
-    case 32: return launch_bwd_tr<32>(a, st);
-    case 40: return launch_bwd_tr<40>(a, st);
-    case 80: return launch_bwd_tr<80>(a, st);
-    case 160: return launch_bwd_tr<160>(a, st);
+    case 8: return launch_bwd_tr_t<8>(a, st);
+    case 16: return launch_bwd_tr_t<16>(a, st);
+    case 32: return launch_bwd_tr_t<32>(a, st);
+    case 40: return launch_bwd_tr_t<40>(a, st);
+    case 80: return launch_bwd_tr_t<80>(a, st);
+    case 160: return launch_bwd_tr_t<160>(a, st);
     default: return CL_EINVAL;
   }
 }
