@@ -101,6 +101,14 @@ int cl_weight_grad_tn(int dtype, const void* dy, long lddy, const void* x, long 
   return launch_wgrad_tn(dy, lddy, x, ldx, dW, lddw, M, N, K, scale, zero_page, S(stream));
 }
 
+int cl_weight_grad_tn_group(int dtype, int n, const cl_wgrad_desc* descs, const void* zero_page, void* stream) {
+  if (dtype != CL_BF16) return CL_EINVAL;
+  if (n <= 0) return CL_OK;
+  if (!descs || n > 4096) return CL_EINVAL;
+  static_assert(sizeof(cl_wgrad_desc) == sizeof(WgradDesc), "descriptor layout");
+  return launch_wgrad_tn_group(reinterpret_cast<const WgradDesc*>(descs), n, zero_page, S(stream));
+}
+
 int cl_conv3x3_fwd(int dtype, int mode, const void* x, long ldx, const void* Wp, const float* bias, const void* emb,
                    long ldemb, const void* residual, long ldr, void* y, long ldy, int B, int Hin, int Win, int Cin,
                    int Cout, const void* zero_page, void* stream) {

@@ -44,6 +44,9 @@ void gemm_get_workspace(void** p, long* bytes);
 // transpose-free weight gradient (wgrad.hip, bf16 only): dW[N,K] += alpha * dy[M,N]^T . x[M,K]
 int launch_wgrad_tn(const void* dy, long lddy, const void* x, long ldx, float* dW, long lddw, int M, int N, int K,
                     float alpha, const void* zero_page, hipStream_t stream);
+// grouped form: many (dy, x, dW) problems in one launch (+ one reduce launch)
+struct WgradDesc { const void* dy; long lddy; const void* x; long ldx; float* dW; long lddw; int M, N, K; float alpha; };
+int launch_wgrad_tn_group(const WgradDesc* probs, int n, const void* zero_page, hipStream_t stream);
 extern int g_wgrad_blocks, g_wgrad_min_steps, g_wgrad_ring;
 extern int g_gemm_force_cfg;   // tuning/probe hook (tile configuration override), -1 = heuristic
 

@@ -32,26 +32,49 @@ __device__ __forceinline__ u32x2_t lds_read_tr16(uint32_t addr) {
   return v;
 }
 
+// Many weight gradients per launch: the LoRA matrices are small (r x K, N x r), so one problem cannot fill
+// 256 CUs without splitting m very finely; instead the engine queues the problems of a transformer block /
+// ResBlock and ONE launch covers them all (descriptor table passed by value in the kernel arguments, so the
+// launch is hipGraph-replayable without any host->device copy).
+struct WgradProb {
+  const bf16_t* dy; const bf16_t* x; float* dW; float* slab;   // slab: this problem's partial-tile region or null
+  long lddy, ldx, lddw;
+  int M, N, K;
+  float alpha;
+  int tiles_k, tiles, per, splits;   // k-tiles per row of tiles, tiles, 32-row steps per split, splits
+  int blk0;                          // first workgroup id of this problem
+  int red0;                          // first reduce-kernel workgroup id of this problem
+};
+constexpr int WGRAD_MAX_PROBS = 24;
+struct WgradGroup { int n; int pad; WgradProb p[WGRAD_MAX_PROBS]; };
+
 // 4 waves (2 x 2), 128 (n) x 128 (k) output tile, 32 rows of m per pipeline step, R-slot ring
 // (R - 1 steps of DMA in flight).
 template <int R>
-__global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const bf16_t* __restrict__ dy, long lddy,
-                                                          const bf16_t* __restrict__ x, long ldx,
-                                                          float* __restrict__ dW, long lddw, int M, int N, int K,
-                                                          float alpha, int tiles_k, int steps_per_split,
-                                                          const void* __restrict__ zero_page,
-                                                          float* __restrict__ slab) {
+__global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const WgradGroup grp, const void* __restrict__ zero_page) {
   constexpr int TILE = 32 * 256;          // one operand tile: 32 rows x 256 bytes
   constexpr int SLOT = 2 * TILE;
   static_assert(R * SLOT >= 4 * 32 * 68 * 4, "epilogue staging must fit in the ring");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
+  // ---- which problem is this workgroup in (wave-uniform scan over the by-value table)
+  int pi = 0;
+  while (pi + 1 < grp.n && (int)blockIdx.x >= grp.p[pi + 1].blk0) ++pi;
+  const WgradProb& P = grp.p[pi];
+  const bf16_t* __restrict__ dy = P.dy; const bf16_t* __restrict__ x = P.x;
+  float* __restrict__ dW = P.dW; float* __restrict__ slab = P.slab;
+  const long lddy = P.lddy, ldx = P.ldx, lddw = P.lddw;
+  const int M = P.M, N = P.N, K = P.K, tiles_k = P.tiles_k, steps_per_split = P.per;
+  const float alpha = P.alpha;
+  const int local = (int)blockIdx.x - P.blk0;
+  const int tile = local % P.tiles, split = local / P.tiles;
+
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 1, wk = wave & 1;
-  const int n0 = (blockIdx.x / tiles_k) * 128, k0 = (blockIdx.x % tiles_k) * 128;
+  const int n0 = (tile / tiles_k) * 128, k0 = (tile % tiles_k) * 128;
   const int steps_total = (M + 31) / 32;
-  const int sbeg = blockIdx.y * steps_per_split;
+  const int sbeg = split * steps_per_split;
   const int send = min(steps_total, sbeg + steps_per_split);
   const int total = send - sbeg;
   if (total <= 0) return;
@@ -157,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const bf16_t* __restri
       if (grow < N && gcol < K) {
         const float4 v = *reinterpret_cast<const float4*>(&stg[rr * EST + cg]);
         if (slab) {   // one fp32 partial slab per m-split; summed by wgrad_reduce_kernel
-          *reinterpret_cast<float4*>(slab + ((long)blockIdx.y * N + grow) * K + gcol) = v;
+          *reinterpret_cast<float4*>(slab + ((long)split * N + grow) * K + gcol) = v;
         } else {      // single split: this workgroup is the only writer of its tile
           float4* dst = reinterpret_cast<float4*>(dW + (long)grow * lddw + gcol);
           float4 o = *dst;
@@ -170,50 +193,33 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const bf16_t* __restri
   }
 }
 
-// dW += alpha * sum over splits of the partial slabs
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dW,
-                                                           long lddw, int N, int K, int splits, float alpha) {
-  const int k4 = K / 4;
+// dW += alpha * sum over splits of the partial slabs (all problems of the group in one launch;
+// one workgroup = 256 float4 of one problem)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradGroup grp) {
+  int pi = 0;
+  while (pi + 1 < grp.n && (int)blockIdx.x >= grp.p[pi + 1].red0) ++pi;
+  const WgradProb& P = grp.p[pi];
+  if (!P.slab) return;
+  const int N = P.N, K = P.K, k4 = K / 4;
   const long total = (long)N * k4;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int n = (int)(i / k4), k = (int)(i % k4) * 4;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int z = 0; z < splits; ++z) {
-      const float4 v = *reinterpret_cast<const float4*>(slab + ((long)z * N + n) * K + k);
-      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-    }
-    float4* dst = reinterpret_cast<float4*>(dW + (long)n * lddw + k);
-    float4 o = *dst;
-    o.x += a.x * alpha; o.y += a.y * alpha; o.z += a.z * alpha; o.w += a.w * alpha;
-    *dst = o;
+  const long i = (long)((int)blockIdx.x - P.red0) * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int n = (int)(i / k4), k = (int)(i % k4) * 4;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int z = 0; z < P.splits; ++z) {
+    const float4 v = *reinterpret_cast<const float4*>(P.slab + ((long)z * N + n) * K + k);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
   }
+  float4* dst = reinterpret_cast<float4*>(P.dW + (long)n * P.lddw + k);
+  float4 o = *dst;
+  o.x += a.x * P.alpha; o.y += a.y * P.alpha; o.z += a.z * P.alpha; o.w += a.w * P.alpha;
+  *dst = o;
 }
 
-// tuning knobs (probe): workgroups wanted, minimum 32-row steps per split, ring depth
-int g_wgrad_blocks = 256, g_wgrad_min_steps = 16, g_wgrad_ring = 4;
+// tuning knobs (probe): workgroups wanted per GROUP, minimum 32-row steps per split, ring depth
+int g_wgrad_blocks = 512, g_wgrad_min_steps = 8, g_wgrad_ring = 4;
 
-int launch_wgrad_tn(const void* dy, long lddy, const void* x, long ldx, float* dW, long lddw, int M, int N, int K,
-                    float alpha, const void* zero_page, hipStream_t stream) {
-  if (M <= 0 || N <= 0 || K <= 0) return CL_OK;
-  if (N % 8 || K % 8 || lddy % 8 || ldx % 8 || lddw % 4 || (reinterpret_cast<uintptr_t>(dW) & 15) || N < 8 || K < 8 || !zero_page) return CL_EINVAL;
-  const int tn = (N + 127) / 128, tk = (K + 127) / 128;
-  const int steps = (M + 31) / 32;
-  // enough workgroups to fill the chip, at least 16 steps (512 rows of m) per split
-  int splits = (g_wgrad_blocks + tn * tk - 1) / (tn * tk);
-  if (splits > steps / g_wgrad_min_steps) splits = steps / g_wgrad_min_steps;
-  if (splits < 1) splits = 1;
-  const int per = (steps + splits - 1) / splits;
-  splits = (steps + per - 1) / per;
-  // partial slabs live in the split-K workspace registered with cl_set_workspace (gemm.hip)
-  void* ws; long ws_bytes;
-  gemm_get_workspace(&ws, &ws_bytes);
-  while (splits > 1 && (long)splits * N * K * 4 > ws_bytes) {
-    --splits;
-  }
-  const int per2 = (steps + splits - 1) / splits;
-  splits = (steps + per2 - 1) / per2;
-  float* slab = splits > 1 ? reinterpret_cast<float*>(ws) : nullptr;
-  const dim3 grid(tn * tk, splits);
+static int launch_group(WgradGroup& grp, int nblocks, int nred, const void* zero_page, hipStream_t stream) {
 #define WGRAD_LAUNCH(RR)                                                                                   \
   do {                                                                                                     \
     static bool attr_set = false;                                                                          \
@@ -224,20 +230,81 @@ int launch_wgrad_tn(const void* dy, long lddy, const void* x, long ldx, float* d
         return CL_ELAUNCH;                                                                                 \
       attr_set = true;                                                                                     \
     }                                                                                                      \
-    hipLaunchKernelGGL(wgrad_tn_kernel<RR>, grid, dim3(256), RR * 16384, stream, (const bf16_t*)dy, lddy,  \
-                       (const bf16_t*)x, ldx, dW, lddw, M, N, K, alpha, tk, per2, zero_page, slab);       \
+    hipLaunchKernelGGL(wgrad_tn_kernel<RR>, dim3(nblocks), dim3(256), RR * 16384, stream, grp, zero_page); \
   } while (0)
   if (g_wgrad_ring == 3) WGRAD_LAUNCH(3);
   else if (g_wgrad_ring == 6) WGRAD_LAUNCH(6);
   else WGRAD_LAUNCH(4);
 #undef WGRAD_LAUNCH
-  if (slab) {
-    const long total = (long)N * (K / 4);
-    int rg = (int)((total + 255) / 256); if (rg > 2048) rg = 2048;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rg), dim3(256), 0, stream, slab, dW, lddw, N, K, splits, alpha);
-  }
+  if (nred > 0) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nred), dim3(256), 0, stream, grp);
   CL_CHECK_LAUNCH();
   return CL_OK;
+}
+
+// probs: host array.  Splits m so that the whole group has about g_wgrad_blocks workgroups in flight; the
+// partial slabs of all problems are carved out of the registered workspace (group flushed early when it is full).
+int launch_wgrad_tn_group(const WgradDesc* probs, int n, const void* zero_page, hipStream_t stream) {
+  if (n <= 0) return CL_OK;
+  if (!zero_page) return CL_EINVAL;
+  void* ws; long ws_bytes;
+  gemm_get_workspace(&ws, &ws_bytes);
+  long tiles_all = 0;
+  for (int i = 0; i < n; ++i) {
+    const WgradDesc& d = probs[i];
+    if (d.M <= 0 || d.N <= 0 || d.K <= 0) continue;
+    if (d.N % 8 || d.K % 8 || d.lddy % 8 || d.ldx % 8 || d.lddw % 4 || d.N < 8 || d.K < 8 ||
+        (reinterpret_cast<uintptr_t>(d.dW) & 15))
+      return CL_EINVAL;
+    tiles_all += (long)((d.N + 127) / 128) * ((d.K + 127) / 128);
+  }
+  if (tiles_all == 0) return CL_OK;
+  // uniform number of m-steps per workgroup across the group
+  long steps_all = 0;
+  for (int i = 0; i < n; ++i)
+    if (probs[i].M > 0) steps_all += (long)((probs[i].N + 127) / 128) * ((probs[i].K + 127) / 128) * ((probs[i].M + 31) / 32);
+  long per = (steps_all + g_wgrad_blocks - 1) / g_wgrad_blocks;
+  if (per < g_wgrad_min_steps) per = g_wgrad_min_steps;
+
+  WgradGroup grp; grp.n = 0; grp.pad = 0;
+  int nblocks = 0, nred = 0; long ws_used = 0;
+  for (int i = 0; i < n; ++i) {
+    const WgradDesc& d = probs[i];
+    if (d.M <= 0 || d.N <= 0 || d.K <= 0) continue;
+    const int tn = (d.N + 127) / 128, tk = (d.K + 127) / 128, steps = (d.M + 31) / 32;
+    int splits = (int)((steps + per - 1) / per);
+    int pp = (steps + splits - 1) / splits;
+    splits = (steps + pp - 1) / pp;
+    long need = splits > 1 ? (long)splits * d.N * d.K * 4 : 0;
+    if (need > ws_bytes) {   // cannot split this far: fewer, longer splits
+      splits = (int)(ws_bytes / ((long)d.N * d.K * 4));
+      if (splits < 1) splits = 1;
+      pp = (steps + splits - 1) / splits; splits = (steps + pp - 1) / pp;
+      need = splits > 1 ? (long)splits * d.N * d.K * 4 : 0;
+    }
+    if (grp.n == WGRAD_MAX_PROBS || ws_used + need > ws_bytes) {   // flush what we have
+      const int rc = launch_group(grp, nblocks, nred, zero_page, stream);
+      if (rc) return rc;
+      grp.n = 0; nblocks = 0; nred = 0; ws_used = 0;
+    }
+    WgradProb& P = grp.p[grp.n++];
+    P.dy = (const bf16_t*)d.dy; P.x = (const bf16_t*)d.x; P.dW = d.dW;
+    P.slab = splits > 1 ? reinterpret_cast<float*>((char*)ws + ws_used) : nullptr;
+    P.lddy = d.lddy; P.ldx = d.ldx; P.lddw = d.lddw; P.M = d.M; P.N = d.N; P.K = d.K; P.alpha = d.alpha;
+    P.tiles_k = tk; P.tiles = tn * tk; P.per = pp; P.splits = splits;
+    P.blk0 = nblocks; P.red0 = nred;
+    nblocks += tn * tk * splits;
+    if (splits > 1) nred += (int)(((long)d.N * (d.K / 4) + 255) / 256);
+    ws_used += (need + 255) & ~255L;
+  }
+  if (grp.n) return launch_group(grp, nblocks, nred, zero_page, stream);
+  return CL_OK;
+}
+
+int launch_wgrad_tn(const void* dy, long lddy, const void* x, long ldx, float* dW, long lddw, int M, int N, int K,
+                    float alpha, const void* zero_page, hipStream_t stream) {
+  WgradDesc d; d.dy = dy; d.lddy = lddy; d.x = x; d.ldx = ldx; d.dW = dW; d.lddw = lddw; d.M = M; d.N = N; d.K = K;
+  d.alpha = alpha;
+  return launch_wgrad_tn_group(&d, 1, zero_page, stream);
 }
 
 }  // namespace cl

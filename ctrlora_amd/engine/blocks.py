@@ -35,6 +35,18 @@ class Ctx:
         self.record = record
         self._gn_ws: Optional[torch.Tensor] = None
         self._tcache: Dict[Tuple[int, int, int, int], torch.Tensor] = {}
+        # queued weight-gradient problems (dy, x, dW, scale): flushed as ONE grouped launch per block
+        self._wq: list = []
+
+    def queue_wgrad(self, dy, x, dW, scale=1.0):
+        self._wq.append((dy, x, dW, scale))        # keeps dy / x alive until the flush
+        if len(self._wq) >= 24:
+            self.flush_wgrad()
+
+    def flush_wgrad(self):
+        if self._wq:
+            hip.weight_grad_tn_group(self._wq)
+            self._wq = []
 
     def new(self, rows: int, cols: int, dtype=None) -> torch.Tensor:
         return torch.empty((rows, cols), dtype=dtype or self.dtype, device=self.device)
@@ -100,9 +112,9 @@ def linear_bwd_lora(ctx: Ctx, L: LinearW, x, t, dy, u):
     """dB += dy^T t ;  dA += u^T x   (fp32, split-K atomics into the flat gradient buffer)."""
     if not L.r:
         return
-    if ctx.dtype == torch.bfloat16:      # transpose-free kernel (LDS transpose reads)
-        hip.weight_grad_tn(dy, t, L.tB.grad)
-        hip.weight_grad_tn(u, x, L.tA.grad)
+    if ctx.dtype == torch.bfloat16:      # transpose-free kernel (LDS transpose reads), grouped per block
+        ctx.queue_wgrad(dy, t, L.tB.grad)
+        ctx.queue_wgrad(u, x, L.tA.grad)
         return
     hip.weight_grad(ctx.transposed(dy), ctx.transposed(t), L.tB.grad)
     hip.weight_grad(ctx.transposed(u), ctx.transposed(x), L.tA.grad)
@@ -111,7 +123,7 @@ def linear_bwd_lora(ctx: Ctx, L: LinearW, x, t, dy, u):
 def dense_bwd_weight(ctx: Ctx, L: LinearW, x, dy, B: int, HW: int, scale: float = 1.0):
     """Trainable dense 1x1 conv (zero convs): dW += scale * dy^T x ; db += scale * colsum(dy)."""
     if ctx.dtype == torch.bfloat16:
-        hip.weight_grad_tn(dy, x, L.tW.grad.view(L.N, L.K), scale)
+        ctx.queue_wgrad(dy, x, L.tW.grad.view(L.N, L.K), scale)
     else:
         hip.weight_grad(ctx.transposed(dy), ctx.transposed(x), L.tW.grad.view(L.N, L.K), scale)
     if L.tb is not None:

@@ -384,7 +384,7 @@ class ControlNetE:
         env.H, env.W = dims[nb]
         dh = self._zero_bwd(ctx, nb, hs[nb], dsinks[nb], scales[nb] * weight, None, B, env.H * env.W)
         dh = _run_bwd(ctx, self.mid, dh, saved[nb], env)
-        self._done(self.stage_spans[nb])
+        self._done(ctx, self.stage_spans[nb])
         for k in range(nb - 1, -1, -1):
             env.H, env.W = dims[k]
             # stage 0: the input conv is frozen and the hint needs no gradient -> weight grads only
@@ -392,11 +392,12 @@ class ControlNetE:
                                 need_dx=k > 0)
             if k > 0:
                 dh = _run_bwd(ctx, self.blocks[k], dh, saved[k], env)
-            self._done(self.stage_spans[k])
+            self._done(ctx, self.stage_spans[k])
         self.time.bwd(ctx, env.dsemb, tsv)
-        self._done(self.time_span)
+        self._done(ctx, self.time_span)
 
-    def _done(self, span):
+    def _done(self, ctx, span):
+        ctx.flush_wgrad()       # the stage's queued weight gradients: one grouped launch
         if self.on_stage_done is not None and span[1] > span[0]:
             self.on_stage_done(span[0], span[1])
 

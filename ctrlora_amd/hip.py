@@ -26,6 +26,12 @@ class HipError(RuntimeError):
     pass
 
 
+class WgradDesc(C.Structure):
+    _fields_ = [("dy", C.c_void_p), ("lddy", C.c_long), ("x", C.c_void_p), ("ldx", C.c_long),
+                ("dW", C.c_void_p), ("lddw", C.c_long), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("scale", C.c_float)]
+
+
 class GemmParams(C.Structure):
     _fields_ = [
         ("A1", C.c_void_p), ("lda1", C.c_long), ("K1", C.c_int),
@@ -56,6 +62,7 @@ _SIGS = {
     "cl_lora_linear_fwd": [_I, _P, _L, _P, _P, _P, _L, _P, _I, _P, _L, _I, _P, _L, _I, _I, _I, _P],
     "cl_lora_linear_bwd_data": [_I, _P, _L, _P, _P, _P, _I, _P, _L, _P, _L, _P, _L, _I, _I, _I, _P],
     "cl_weight_grad": [_I, _P, _L, _P, _L, _P, _L, _I, _I, _I, _F, _P],
+    "cl_weight_grad_tn_group": [_I, _I, _P, _P, _P],
     "cl_weight_grad_tn": [_I, _P, _L, _P, _L, _P, _L, _I, _I, _I, _F, _P, _P],
     "cl_conv3x3_fwd": [_I, _I, _P, _L, _P, _P, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P, _P],
     "cl_conv3x3_bwd_data": [_I, _I, _P, _L, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P, _P],
@@ -205,6 +212,22 @@ def weight_grad(dyT, xT, dW, scale=1.0):
     """dW[N,K] (fp32) += scale * dyT[N,Mp] . xT[K,Mp]^T  (split-K, fp32 atomics)."""
     _chk(lib().cl_weight_grad(dt(dyT), dyT.data_ptr(), ld(dyT), xT.data_ptr(), ld(xT), dW.data_ptr(), ld(dW),
                               dyT.shape[0], xT.shape[0], dyT.shape[1], scale, stream()), "cl_weight_grad")
+
+
+def weight_grad_tn_group(problems):
+    """problems: list of (dy [M,N] bf16, x [M,K] bf16, dW [N,K] fp32, scale): ONE launch for all of them."""
+    n = len(problems)
+    if n == 0:
+        return
+    if _workspace is None:
+        ensure_workspace(problems[0][0].device)
+    arr = (WgradDesc * n)()
+    for d, (dy, x, dW, scale) in zip(arr, problems):
+        d.dy = dy.data_ptr(); d.lddy = ld(dy); d.x = x.data_ptr(); d.ldx = ld(x)
+        d.dW = dW.data_ptr(); d.lddw = ld(dW); d.M = dy.shape[0]; d.N = dy.shape[1]; d.K = x.shape[1]
+        d.scale = scale
+    _chk(lib().cl_weight_grad_tn_group(BF16, n, C.cast(arr, C.c_void_p), zero_page(problems[0][0].device).data_ptr(),
+                                       stream()), "cl_weight_grad_tn_group")
 
 
 def repack(dtype, flat, desc, tile_prefix, ndesc, total_tiles):

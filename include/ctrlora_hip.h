@@ -105,6 +105,18 @@ int cl_weight_grad(int dtype, const void* dyT, long lddyt, const void* xT, long 
 int cl_weight_grad_tn(int dtype, const void* dy, long lddy, const void* x, long ldx, float* dW, long lddw,
                       int M, int N, int K, float scale, const void* zero_page, void* stream);
 
+/* grouped form: n independent weight gradients in ONE launch (+ one slab-reduce launch).  The LoRA
+ * matrices are small, so a single problem cannot fill the chip; the engine queues the problems of a
+ * transformer block and flushes them together.  `descs` is a HOST array (copied into the kernel arguments,
+ * hipGraph-replayable). */
+typedef struct cl_wgrad_desc {
+  const void* dy; long lddy;      /* [M, N] row-major bf16 */
+  const void* x; long ldx;        /* [M, K] row-major bf16 */
+  float* dW; long lddw;           /* [N, K] fp32, accumulated */
+  int M, N, K; float scale;
+} cl_wgrad_desc;
+int cl_weight_grad_tn_group(int dtype, int n, const cl_wgrad_desc* descs, const void* zero_page, void* stream);
+
 /* 3x3 convolutions of ResBlock / Downsample / Upsample / input conv / out conv
  * (ldm/modules/diffusionmodules/openaimodel.py:108-118,150,203,229,729; cldm/cldm.py:141):
  * out = conv(x) + bias + emb[b, :] (openaimodel.py:272) + residual (openaimodel.py:274).

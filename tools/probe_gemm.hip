@@ -192,7 +192,7 @@ static void wgrad_suite(bool timeit) {
   case_wgrad("wgrad 4096x128x320", 4096, 128, 320, 1.0f);
   case_wgrad("wgrad 1000x8x40 (tiny)", 1000, 8, 40, 1.0f);
   if (timeit) {
-    const int rings[] = {4}, mins[] = {32, 16, 8, 4}, blks[] = {256, 512, 1024};
+    const int rings[] = {4}, mins[] = {16, 8}, blks[] = {256, 512};
     for (int r : rings) for (int mn : mins) for (int b : blks) {
       g_wgrad_ring = r; g_wgrad_min_steps = mn; g_wgrad_blocks = b;
       char nm[96]; snprintf(nm, 96, "wgrad 32768x320x128 R%d min%d blk%d", r, mn, b);
