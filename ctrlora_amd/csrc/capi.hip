@@ -25,6 +25,10 @@ int cl_set_workspace(void* ptr, long bytes) {
   gemm_set_workspace(ptr, bytes);
   return CL_OK;
 }
+int cl_set_stream_workspace(void* stream, void* ptr, long bytes) {
+  if (bytes <= 0 || !ptr || (reinterpret_cast<uintptr_t>(ptr) & 15)) return CL_EINVAL;
+  return gemm_set_stream_workspace(S(stream), ptr, bytes);
+}
 int cl_gemm_force_config(int cfg) { g_gemm_force_cfg = cfg; return CL_OK; }
 
 int cl_gemm(const cl_gemm_params* p, int dtype, void* stream) {

@@ -41,6 +41,8 @@ int launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);
 // one workspace per process, used stream-ordered by whichever stream launches the GEMM.
 void gemm_set_workspace(void* p, long bytes);
 void gemm_get_workspace(void** p, long* bytes);
+void gemm_get_workspace_for(hipStream_t st, void** p, long* bytes);
+int gemm_set_stream_workspace(hipStream_t st, void* p, long bytes);
 // transpose-free weight gradient (wgrad.hip, bf16 only): dW[N,K] += alpha * dy[M,N]^T . x[M,K]
 int launch_wgrad_tn(const void* dy, long lddy, const void* x, long ldx, float* dW, long lddw, int M, int N, int K,
                     float alpha, const void* zero_page, hipStream_t stream);

@@ -42,10 +42,24 @@
 
 namespace cl {
 
+// Split-K scratch: a default region plus optional per-stream regions, so that two streams running
+// contractions concurrently (ControlNet trunk || UNet encoder) never share partial slabs.
 static void* g_ws = nullptr;
 static long g_ws_bytes = 0;
+struct StreamWs { hipStream_t st; void* p; long bytes; };
+static StreamWs g_sws[4] = {};
+static thread_local hipStream_t t_stream = nullptr;     // stream of the launch being prepared
 void gemm_set_workspace(void* p, long bytes) { g_ws = p; g_ws_bytes = bytes; }
-void gemm_get_workspace(void** p, long* bytes) { *p = g_ws; *bytes = g_ws_bytes; }
+int gemm_set_stream_workspace(hipStream_t st, void* p, long bytes) {
+  for (auto& e : g_sws) if (e.st == st || e.p == nullptr) { e.st = st; e.p = p; e.bytes = bytes; return CL_OK; }
+  return CL_EINVAL;
+}
+static void ws_for(hipStream_t st, void** p, long* bytes) {
+  for (auto& e : g_sws) if (e.p && e.st == st) { *p = e.p; *bytes = e.bytes; return; }
+  *p = g_ws; *bytes = g_ws_bytes;
+}
+void gemm_get_workspace(void** p, long* bytes) { ws_for(t_stream, p, bytes); }
+void gemm_get_workspace_for(hipStream_t st, void** p, long* bytes) { ws_for(st, p, bytes); }
 
 template <int N> __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -379,7 +393,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_kernel(GemmParams p, i
 // validity mask computed once, and a wave-uniform (scalar) tap offset updated when the tap changes.
 enum { FL_LINEAR = 0, FL_CONV_S1 = 1, FL_CONV_ANY = 2 };
 
-template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int R>
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int R, int PRIO = 0>
 __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p, int tiles_m, int tiles_n,
                                                                  float* __restrict__ slab) {
   constexpr int NW = WGM * WGN;
@@ -608,7 +622,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p
     for (int i = 0; i < FM; ++i) asm volatile("" : "+v"(ga[i]));
 #pragma unroll
     for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(gb[j]));
+    if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);
     mma_all(ga, gb);
+    if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
     // two-slot ring: stage s has been read completely by every wave (barrier above), refill its slot
     if constexpr (issue && R == 2) issue_next(slot);
     wait_frags(fa, fb);
@@ -669,15 +685,17 @@ static int launch_cfg(const GemmParams& p0, hipStream_t stream) {
   } else {
     // deterministic split-K through the workspace when the tile grid cannot fill the chip
     int sk = 1;
-    if (p.splitk <= 1 && tiles < 160 && ksub >= 32 && g_ws) {
+    void* wsp; long wsb;
+    ws_for(stream, &wsp, &wsb);
+    if (p.splitk <= 1 && tiles < 160 && ksub >= 32 && wsp) {
       sk = (int)((256 + tiles - 1) / tiles);
       if (sk > ksub / 16) sk = ksub / 16;
       if (sk > 16) sk = 16;
-      while (sk > 1 && (long)sk * p.M * p.N * 4 > g_ws_bytes) --sk;
+      while (sk > 1 && (long)sk * p.M * p.N * 4 > wsb) --sk;
       if (sk < 1) sk = 1;
     }
     p.splitk = sk;
-    if (sk > 1) slab = reinterpret_cast<float*>(g_ws);
+    if (sk > 1) slab = reinterpret_cast<float*>(wsp);
   }
   // every split must own at least one substep (the kernel assumes total >= 1 except for empty K)
   if (p.splitk > 1) {
@@ -696,22 +714,25 @@ static int launch_cfg(const GemmParams& p0, hipStream_t stream) {
 }
 
 // choose the split-K factor: `want` workgroups in flight, at least `min_steps` pipeline steps per split
-static int pick_splitk(GemmParams& p, long tiles, int steps, int want, int min_steps, float** slab) {
+static int pick_splitk(GemmParams& p, long tiles, int steps, int want, int min_steps, float** slab,
+                       hipStream_t stream) {
+  void* wsp; long wsb;
+  ws_for(stream, &wsp, &wsb);
   *slab = nullptr;
   if (p.atomic) {
     if (p.splitk < 1) p.splitk = 1;
     if (p.splitk > steps) p.splitk = steps > 0 ? steps : 1;
   } else {
     int sk = 1;
-    if (tiles < want && steps >= 2 * min_steps && g_ws) {
+    if (tiles < want && steps >= 2 * min_steps && wsp) {
       sk = (int)((want + tiles - 1) / tiles);
       if (sk > steps / min_steps) sk = steps / min_steps;
       if (sk > 32) sk = 32;
-      while (sk > 1 && (long)sk * p.M * p.N * 4 > g_ws_bytes) --sk;
+      while (sk > 1 && (long)sk * p.M * p.N * 4 > wsb) --sk;
       if (sk < 1) sk = 1;
     }
     p.splitk = sk;
-    if (sk > 1) *slab = reinterpret_cast<float*>(g_ws);
+    if (sk > 1) *slab = reinterpret_cast<float*>(wsp);
   }
   if (p.splitk > 1) {   // every split owns at least one step
     const int per = (steps + p.splitk - 1) / p.splitk;
@@ -720,11 +741,11 @@ static int pick_splitk(GemmParams& p, long tiles, int steps, int want, int min_s
   return p.splitk;
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int R>
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int R, int PRIO = 0>
 static int launch_fl_mode(const GemmParams& p0, hipStream_t stream) {
   constexpr int NW = WGM * WGN;
   constexpr int SMEM = R * (BM / 8 + BN / 8) * 1024;
-  auto kern = &gemm_fl_kernel<T, BM, BN, WGM, WGN, MODE, R>;
+  auto kern = &gemm_fl_kernel<T, BM, BN, WGM, WGN, MODE, R, PRIO>;
   static bool attr_set = false;
   if (!attr_set) {
     if (SMEM > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -738,7 +759,7 @@ static int launch_fl_mode(const GemmParams& p0, hipStream_t stream) {
   const long tiles = (long)tm * tn;
   const int steps = ((MODE == FL_LINEAR ? 1 : 9) * p.K1 + p.K2) / kps;
   float* slab;
-  pick_splitk(p, tiles, steps, R == 3 ? 256 : 512, 4, &slab);
+  pick_splitk(p, tiles, steps, R == 3 ? 256 : 512, 4, &slab, stream);
   hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * p.splitk)), dim3(NW * 64), SMEM, stream, p, tm, tn, slab);
   if (slab) {
     const long total = (long)p.M * (p.N / 8);
@@ -749,11 +770,11 @@ static int launch_fl_mode(const GemmParams& p0, hipStream_t stream) {
   return CL_OK;
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int R>
+template <typename T, int BM, int BN, int WGM, int WGN, int R, int PRIO = 0>
 static int launch_fl(const GemmParams& p, hipStream_t stream) {
-  if (p.mode == GEMM_LINEAR) return launch_fl_mode<T, BM, BN, WGM, WGN, FL_LINEAR, R>(p, stream);
+  if (p.mode == GEMM_LINEAR) return launch_fl_mode<T, BM, BN, WGM, WGN, FL_LINEAR, R, PRIO>(p, stream);
   if (p.K2) return CL_EINVAL;   // a second K segment exists for linear operands only
-  if (p.mode == GEMM_CONV_S1) return launch_fl_mode<T, BM, BN, WGM, WGN, FL_CONV_S1, R>(p, stream);
+  if (p.mode == GEMM_CONV_S1) return launch_fl_mode<T, BM, BN, WGM, WGN, FL_CONV_S1, R, PRIO>(p, stream);
   return launch_fl_mode<T, BM, BN, WGM, WGN, FL_CONV_ANY, R>(p, stream);
 }
 
@@ -778,7 +799,7 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
       const long t256 = (long)((p.M + 255) / 256) * ((p.N + bn - 1) / bn);
       const int steps = ((p.mode == GEMM_LINEAR ? 1 : 9) * p.K1 + p.K2) / kps;
       const long need = (256 + t256 - 1) / t256;   // split factor that fills 256 CUs
-      if (t256 >= 200 || (g_ws && steps >= 8 * need)) cfg = (bn == 160) ? 8 : 9;
+      if (t256 >= 200 || (g_ws && steps >= 8 * need)) cfg = 12 + (bn == 160 ? 0 : 1);
     }
   }
   switch (cfg) {
@@ -795,6 +816,12 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
       if (p.K1 % kps || p.K2 % kps || (p.mode != GEMM_LINEAR && p.K2))
         return launch_cfg<T, 128, 128, 2, 2, 2, 4>(p, stream);
       return cfg == 8 ? launch_fl<T, 256, 160, 4, 2, 3>(p, stream) : launch_fl<T, 256, 128, 4, 2, 3>(p, stream);
+    }
+    case 12: case 13: {   // production: cfg 8 / 9 with s_setprio(1) around the pure-MFMA half of every stage (+2-3 %)
+      const int kps = 128 / (int)sizeof(T);
+      if (p.K1 % kps || p.K2 % kps || (p.mode != GEMM_LINEAR && p.K2))
+        return launch_cfg<T, 128, 128, 2, 2, 2, 4>(p, stream);
+      return cfg == 12 ? launch_fl<T, 256, 160, 4, 2, 3, 1>(p, stream) : launch_fl<T, 256, 128, 4, 2, 3, 1>(p, stream);
     }
     case 10: case 11: {   // 128-row tiles, 4 waves, 2-slot ring: two workgroups per CU (small-K / mid-size products)
       const int kps = 128 / (int)sizeof(T);

@@ -247,7 +247,7 @@ int launch_wgrad_tn_group(const WgradDesc* probs, int n, const void* zero_page, 
   if (n <= 0) return CL_OK;
   if (!zero_page) return CL_EINVAL;
   void* ws; long ws_bytes;
-  gemm_get_workspace(&ws, &ws_bytes);
+  gemm_get_workspace_for(stream, &ws, &ws_bytes);
   long tiles_all = 0;
   for (int i = 0; i < n; ++i) {
     const WgradDesc& d = probs[i];

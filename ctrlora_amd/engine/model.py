@@ -18,6 +18,8 @@ from .packing import TrainableSet, rup
 
 
 class CtrLoRAEngine:
+    overlap_streams = True     # ControlNet trunk || UNet encoder on two HIP streams (forward)
+
     def __init__(self, sd_unet: Dict[str, torch.Tensor], sd_controls: Sequence[Dict[str, torch.Tensor]], cfg: NetCfg,
                  dtype: torch.dtype = torch.bfloat16, device="cuda", need_bwd: bool = True,
                  unet_prefix: str = "", control_prefix: str = ""):
@@ -29,6 +31,7 @@ class CtrLoRAEngine:
         self._rec = None
         self.cache_context_kv = False
         self._kv: Optional[dict] = None
+        self._side = None
 
     @classmethod
     def from_executors(cls, unet: UNetE, controls: Sequence[ControlNetE]) -> "CtrLoRAEngine":
@@ -38,6 +41,7 @@ class CtrLoRAEngine:
         self.cfg, self.dtype, self.device = unet.cfg, unet.dtype, unet.device
         self.unet, self.controls = unet, list(controls)
         self._rec, self.cache_context_kv, self._kv = None, False, None
+        self._side = None
         return self
 
     @torch.no_grad()
@@ -93,13 +97,40 @@ class CtrLoRAEngine:
             if self._kv is None:
                 self._kv = {"unet": {}, "cn": [dict() for _ in self.controls]}
             kvs = self._kv
+        # The ControlNet trunk (everything but its zero convs) does not depend on the UNet encoder: run it on a
+        # second stream so that the under-filled 32x32 / 16x16 / 8x8 levels of the two networks overlap.
+        # Separate Ctx (GroupNorm scratch) and per-stream split-K workspace keep the streams from sharing state.
+        overlap = self.overlap_streams and hints is not None and not only_mid_control
+        trunks = []
+        if overlap:
+            assert len(hints) == len(self.controls)
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = hip.side_stream(self.device)
+            hint_toks = [self._tok_in(h) for h in hints]
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                ctx_cn = Ctx(self.dtype, self.device, record)
+                for i, (cn, ht) in enumerate(zip(self.controls, hint_toks)):
+                    trunks.append(cn.fwd_trunk(ctx_cn, ht, t, c, B, H, W, kv=None if kvs is None else kvs["cn"][i]))
         semb, hs, dims, h_mid = self.unet.encode(ctx, self._tok_in(x_noisy), t, c, B, H, W,
                                                  kv=None if kvs is None else kvs["unet"])
+        if overlap:
+            torch.cuda.current_stream().wait_stream(self._side)
         bufs = self.unet.alloc_decoder_inputs(ctx, B, dims)
         cn_recs = []
         scales = list(control_scales) if control_scales is not None else [1.0] * (len(dims) + 1)
         if hints is None:
             self.unet.fill_without_control(ctx, bufs, hs, h_mid)
+        elif overlap:
+            weights = list(lora_weights) if lora_weights is not None else [1.0] * len(hints)
+            sinks = self.unet.control_sinks(bufs, hs, h_mid)
+            for i, (cn, (rec, cn_hs)) in enumerate(zip(self.controls, trunks)):
+                if i > 0:   # accumulate the next LoRA's weighted residuals in place
+                    sinks = [(o, o) for o, _ in sinks]
+                cn.fwd_zero(cn_hs, sinks, scales, weights[i])
+                cn_recs.append((rec, weights[i]))
+            del trunks
         else:
             assert len(hints) == len(self.controls)
             weights = list(lora_weights) if lora_weights is not None else [1.0] * len(hints)

@@ -353,6 +353,14 @@ class ControlNetE:
 
     def fwd(self, ctx: Ctx, hint_tok, t, c, B, H, W, sinks, scales, weight=1.0, kv=None):
         """sinks[k] = (out_view, residual_view or None); out = (zero_conv_k(h_k)) * scale_k * weight + residual."""
+        rec, hs = self.fwd_trunk(ctx, hint_tok, t, c, B, H, W, kv=kv)
+        self.fwd_zero(hs, sinks, scales, weight)
+        return rec
+
+    def fwd_trunk(self, ctx: Ctx, hint_tok, t, c, B, H, W, kv=None):
+        """Encoder + middle block WITHOUT the zero convs (which need the UNet's skip tensors as residuals):
+        this part is independent of the UNet encoder and may run concurrently with it on another stream.
+        Returns (record or None, [h_k]) -- the 13 stage outputs the zero convs consume."""
         semb, tsv = self.time.fwd(ctx, t)
         env = _Env(B, H, W, semb, c, c.shape[0] // B)
         env.kv = kv
@@ -361,13 +369,15 @@ class ControlNetE:
         for k, layers in enumerate(self.blocks):
             h, sv = _run_fwd(ctx, layers, h, env)
             saved.append(sv); dims.append((env.H, env.W))
-            self._zero_fwd(k, h, sinks[k], scales[k] * weight)
-            hs.append(h if ctx.record else None)
+            hs.append(h)
         h, sv = _run_fwd(ctx, self.mid, h, env)
         saved.append(sv); dims.append((env.H, env.W))
-        self._zero_fwd(len(self.blocks), h, sinks[-1], scales[-1] * weight)
-        hs.append(h if ctx.record else None)
-        return (tsv, semb, saved, hs, dims, c) if ctx.record else None
+        hs.append(h)
+        return ((tsv, semb, saved, hs, dims, c) if ctx.record else None), hs
+
+    def fwd_zero(self, hs, sinks, scales, weight=1.0):
+        for k, h in enumerate(hs):
+            self._zero_fwd(k, h, sinks[k], scales[k] * weight)
 
     def _zero_fwd(self, k, h, sink, alpha):
         out, res = sink

@@ -56,6 +56,7 @@ _P, _L, _I, _F = C.c_void_p, C.c_long, C.c_int, C.c_float
 _SIGS = {
     "cl_abi_version": [],
     "cl_set_workspace": [_P, _L],
+    "cl_set_stream_workspace": [_P, _P, _L],
     "cl_gemm_force_config": [_I],
     "cl_gemm": [C.POINTER(GemmParams), _I, _P],
     "cl_lora_down": [_I, _P, _L, _P, _I, _P, _L, _I, _I, _P],
@@ -156,6 +157,33 @@ def ld(t: Optional[torch.Tensor]) -> int:
 _zero_pages = {}
 _workspace = None
 WORKSPACE_BYTES = 64 << 20
+
+
+_stream_ws = {}
+
+
+def bind_stream_workspace(stream: "torch.cuda.Stream", nbytes: int = 32 << 20) -> None:
+    """Give `stream` its own split-K scratch (needed before running contractions on it concurrently with
+    another stream)."""
+    key = stream.cuda_stream
+    if key not in _stream_ws:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=stream.device)
+        _chk(lib().cl_set_stream_workspace(key, buf.data_ptr(), nbytes), "cl_set_stream_workspace")
+        _stream_ws[key] = buf
+
+
+_side_streams = {}
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    """The process-wide second compute stream of a device (with its own split-K scratch)."""
+    key = str(device)
+    st = _side_streams.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        bind_stream_workspace(st)
+        _side_streams[key] = st
+    return st
 
 
 def ensure_workspace(device) -> None:

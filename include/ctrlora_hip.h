@@ -40,6 +40,9 @@ int cl_abi_version(void);
  * the host (torch) owns the buffer and registers it once per process; without one, split-K is off.
  * 64 MiB covers every CtrLoRA shape at batch 16.  Used stream-ordered on the launching stream. */
 int cl_set_workspace(void* device_ptr, long bytes);
+/* A second (third, fourth) scratch region bound to one stream: contractions launched on that stream use it
+ * instead of the default, so concurrent streams never share split-K slabs. */
+int cl_set_stream_workspace(void* stream, void* device_ptr, long bytes);
 /* tuning hook: force a tile configuration of csrc/gemm.hip (-1 = built-in heuristic) */
 int cl_gemm_force_config(int cfg);
 
