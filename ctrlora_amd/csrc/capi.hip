@@ -7,8 +7,12 @@
 #include "norm.h"
 
 using namespace cl;
+namespace cl { int g_last_hip_error = 0; }
 
-static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+// Every entry point converts its stream argument through S(): it also clears a stale "last error" left by
+// unrelated runtime calls of the host process (e.g. an event query that returned hipErrorNotReady), so that
+// the hipGetLastError() check after our own launch reports OUR launch only.
+static inline hipStream_t S(void* s) { (void)hipGetLastError(); return reinterpret_cast<hipStream_t>(s); }
 
 static GemmParams base_params() {
   GemmParams g{};
@@ -19,6 +23,8 @@ static GemmParams base_params() {
 extern "C" {
 
 int cl_abi_version(void) { return 2; }
+int cl_last_hip_error(void) { return g_last_hip_error; }
+const char* cl_last_hip_error_string(void) { return hipGetErrorString((hipError_t)g_last_hip_error); }
 
 int cl_set_workspace(void* ptr, long bytes) {
   if (bytes < 0 || (bytes > 0 && !ptr) || (reinterpret_cast<uintptr_t>(ptr) & 15)) return CL_EINVAL;

@@ -120,10 +120,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
       (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+extern int g_last_hip_error;   // capi.hip: the hipError_t behind the most recent CL_ELAUNCH (diagnostics)
 #define CL_CHECK_LAUNCH()                                   \
   do {                                                      \
     hipError_t e__ = hipGetLastError();                     \
-    if (e__ != hipSuccess) return cl::CL_ELAUNCH;           \
+    if (e__ != hipSuccess) { cl::g_last_hip_error = (int)e__; return cl::CL_ELAUNCH; } \
   } while (0)
 
 }  // namespace cl

@@ -12,7 +12,13 @@ enum GemmMode {
   GEMM_CONV_T2 = 4,  // 3x3 over the zero-stuffed x2 grid (= data-gradient of GEMM_CONV_S2)
 };
 
-enum GemmAct { ACT_NONE = 0, ACT_SILU = 1 };
+enum GemmAct {
+  ACT_NONE = 0, ACT_SILU = 1,
+  // GEGLU fused into the projection (attention.py:49-56), inference / no-grad forwards only: W's rows are
+  // permuted so that every 160-column tile holds 80 value columns followed by their 80 gate columns; the
+  // epilogue writes value * gelu(gate) into C[M, N/2] (ldc).  Needs N % 160 == 0, no rowbias / residual.
+  ACT_GEGLU = 2
+};
 
 struct GemmParams {
   // out[M,N] = act( A1 . W1^T + A2 . W2^T + bias[n] + rowbias[m / rows_per_batch, n] ) * alpha

@@ -119,9 +119,10 @@ __device__ __forceinline__ EpiArgs epi_of(const GemmParams& p) {
 
 // Accumulator tile -> memory: each wave stages 32 (or 16) x WN fp32 through LDS so that residual
 // reads and output writes are whole 16-byte vectors along rows, then applies the epilogue.
-template <typename T, int FM, int FN>
+template <typename T, int FM, int FN, bool PAIR = false>
 __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4_t (&acc)[FM][FN], float* stg, int row0,
-                                           int col0, int lane, float* slab, int zsplit) {
+                                           int col0, int lane, float* slab, int zsplit, int wn = 0,
+                                           float* stg_partner = nullptr) {
   constexpr int WN = FN * 16;
   constexpr int EST = WN + 4;
   constexpr int LPR = WN / 8;      // lanes per output row
@@ -130,6 +131,8 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4_t (&acc)[F
   constexpr int FPP = (FM >= 2) ? 2 : 1;  // m-frags per pass
   constexpr int ITERS = (FPP * 16 + RPI - 1) / RPI;
   const EpiArgs e = epi_of(p);
+  // PAIR: the two waves of a tile row (wn = 0: value columns, wn = 1: gate columns) combine for GEGLU
+  const bool geglu = PAIR && p.act == ACT_GEGLU && !slab;
 #pragma unroll
   for (int ps = 0; ps < PASSES; ++ps) {
 #pragma unroll
@@ -140,6 +143,40 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4_t (&acc)[F
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           stg[(i2 * 16 + (lane >> 4) * 4 + r) * EST + j * 16 + (lane & 15)] = acc[i][j][r];
+    }
+    if constexpr (PAIR) {
+      if (geglu) {
+        __syncthreads();   // both waves' staging is complete (uniform branch: p.act)
+        const float* sv = wn == 0 ? stg : stg_partner;
+        const float* sg = wn == 0 ? stg_partner : stg;
+        const int n0 = col0 - wn * WN;                 // first column of the 2*WN-wide tile
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+          if ((it & 1) != wn) continue;                // the two waves share the rows
+          const int rr = it * RPI + lane / LPR;
+          const int cg = (lane % LPR) * 8;
+          const int grow = row0 + ps * 32 + rr;
+          if (lane < RPI * LPR && rr < FPP * 16 && grow < p.M) {
+            float v[8], gt[8];
+            const float4 a0 = *reinterpret_cast<const float4*>(&sv[rr * EST + cg]);
+            const float4 a1 = *reinterpret_cast<const float4*>(&sv[rr * EST + cg + 4]);
+            const float4 g0 = *reinterpret_cast<const float4*>(&sg[rr * EST + cg]);
+            const float4 g1 = *reinterpret_cast<const float4*>(&sg[rr * EST + cg + 4]);
+            v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+            gt[0] = g0.x; gt[1] = g0.y; gt[2] = g0.z; gt[3] = g0.w; gt[4] = g1.x; gt[5] = g1.y; gt[6] = g1.z; gt[7] = g1.w;
+            if (e.bias) {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) { v[k] += e.bias[n0 + cg + k]; gt[k] += e.bias[n0 + WN + cg + k]; }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] *= gelu_f(gt[k]);
+            if (p.out_f32) store8(reinterpret_cast<float*>(e.C) + (long)grow * e.ldc + n0 / 2 + cg, v);
+            else store8(reinterpret_cast<T*>(e.C) + (long)grow * e.ldc + n0 / 2 + cg, v);
+          }
+        }
+        __syncthreads();   // staging free for the next pass
+        continue;
+      }
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -157,7 +194,7 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4_t (&acc)[F
         v[4] = s1.x; v[5] = s1.y; v[6] = s1.z; v[7] = s1.w;
         if (slab) {   // split-K partial: raw accumulators, epilogue applied by the reduce kernel
           store8(slab + ((long)zsplit * p.M + grow) * p.N + gcol, v);
-        } else {
+        } else if (p.act != 77) {   // act 77: timing probe only (skip the stores)
           epilogue8<T>(e, v, grow, gcol);
         }
       }
@@ -363,8 +400,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_kernel(GemmParams p, i
   __syncthreads();  // all waves done with the operand slots; reuse LDS for the epilogue
 
   // ---- epilogue
-  store_tile<T, FM, FN>(p, acc, reinterpret_cast<float*>(smem) + wave * (EROWS * EST), m0 + wm * WM, n0 + wn * WN,
-                        lane, slab, zsplit);
+  store_tile<T, FM, FN, (WGN == 2 && FN == 5)>(p, acc, reinterpret_cast<float*>(smem) + wave * (EROWS * EST),
+                                               m0 + wm * WM, n0 + wn * WN, lane, slab, zsplit, wn,
+                                               reinterpret_cast<float*>(smem) + (wave ^ 1) * (EROWS * EST));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -635,16 +673,44 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p
   for (; s < total; ++s) stage(std::false_type{}, s + 1 < total);
   __syncthreads();  // all waves done with the operand slots; reuse LDS for the epilogue
 
-  store_tile<T, FM, FN>(p, acc, reinterpret_cast<float*>(smem) + wave * (EROWS * EST), m0 + wm * WM, n0 + wn * WN,
-                        lane, slab, zsplit);
+  store_tile<T, FM, FN, (WGN == 2 && FN == 5)>(p, acc, reinterpret_cast<float*>(smem) + wave * (EROWS * EST),
+                                               m0 + wm * WM, n0 + wn * WN, lane, slab, zsplit, wn,
+                                               reinterpret_cast<float*>(smem) + (wave ^ 1) * (EROWS * EST));
 }
 
 // sum the split-K slabs and apply the epilogue: one lane per 8 output columns
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, const float* __restrict__ slab, int splits) {
+  const EpiArgs e = epi_of(p);
+  if (p.act == ACT_GEGLU) {   // value / gate columns interleaved per 160-column tile -> C[M, N/2]
+    const int o8 = p.N / 16;
+    const long total = (long)p.M * o8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+      const int grow = (int)(i / o8), ocol = (int)(i % o8) * 8;
+      const int vcol = (ocol / 80) * 160 + ocol % 80;
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int z = 0; z < splits; ++z) {
+        float t[8];
+        load8(slab + ((long)z * p.M + grow) * p.N + vcol, t);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += t[k];
+        load8(slab + ((long)z * p.M + grow) * p.N + vcol + 80, t);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g[k] += t[k];
+      }
+      if (e.bias) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v[k] += e.bias[vcol + k]; g[k] += e.bias[vcol + 80 + k]; }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] *= gelu_f(g[k]);
+      if (p.out_f32) store8(reinterpret_cast<float*>(e.C) + (long)grow * e.ldc + ocol, v);
+      else store8(reinterpret_cast<T*>(e.C) + (long)grow * e.ldc + ocol, v);
+    }
+    return;
+  }
   const int n8 = p.N / 8;
   const long total = (long)p.M * n8;
-  const EpiArgs e = epi_of(p);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int grow = (int)(i / n8), gcol = (int)(i % n8) * 8;
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -783,6 +849,7 @@ int g_gemm_force_cfg = -1;   // probe / tuning hook: >= 0 forces a tile configur
 template <typename T>
 static int launch_t(const GemmParams& p, hipStream_t stream) {
   int cfg = g_gemm_force_cfg;
+  if (p.act == ACT_GEGLU && cfg != 2 && cfg != 12 && cfg != 8 && cfg != 10) cfg = -2;   // needs a 2 x 80-column wave pair
   if (cfg < 0) {
     // v2 (64-byte substeps, 4 waves) choices
     if (p.M <= 64 || p.N <= 64) cfg = 0;
@@ -801,6 +868,7 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
       const long need = (256 + t256 - 1) / t256;   // split factor that fills 256 CUs
       if (t256 >= 200 || (g_ws && steps >= 8 * need)) cfg = 12 + (bn == 160 ? 0 : 1);
     }
+    if (p.act == ACT_GEGLU && cfg != 12) cfg = 2;
   }
   switch (cfg) {
     case 0: return launch_cfg<T, 64, 64, 2, 2, 1, 4>(p, stream);
@@ -842,6 +910,7 @@ int launch_gemm(const GemmParams& p, int dtype, hipStream_t stream) {
   if (p.K2 && (!p.A2 || !p.W2)) return CL_EINVAL;
   if (p.atomic == 0 && p.splitk > 1) return CL_EINVAL;
   if (p.rowbias && p.rows_per_batch <= 0) return CL_EINVAL;
+  if (p.act == ACT_GEGLU && (p.N % 160 || p.rowbias || p.residual || p.atomic || p.alpha != 1.0f)) return CL_EINVAL;
   return dtype == CL_BF16 ? launch_t<bf16_t>(p, stream) : launch_t<float>(p, stream);
 }
 

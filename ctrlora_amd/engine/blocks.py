@@ -393,9 +393,22 @@ class SpatialTransformerE:
         n2, s2 = self.ln2.fwd(ctx, h1)
         h2, sv2 = self.attn2.fwd(ctx, n2, c, B, N, Nkv, residual=h1, kv_cache=kv_cache)
         n3, s3 = self.ln3.fwd(ctx, h2)
-        p, tp = linear_fwd(ctx, self.ff_proj, n3)                    # [M, 8C]
-        gg = ctx.new(B * N, 4 * self.C)
-        hip.geglu_fwd(p, gg)
+        if not ctx.record and self.ff_proj.geglu_ok():
+            # no backward will need the 8C-wide pre-activation: value * gelu(gate) is formed in the projection's
+            # epilogue (half the output bytes, no separate GEGLU pass)
+            L = self.ff_proj
+            Wg, bg, Bg = L.geglu_pack()
+            tp = None
+            if L.r:
+                tp = ctx.new(B * N, L.r)
+                hip.gemm(n3, L.A, tp)
+            gg = ctx.new(B * N, 4 * self.C)
+            hip.gemm(n3, Wg, gg, a2=tp, w2=Bg, bias=bg, act=hip.ACT_GEGLU, N=L.N)
+            p = None
+        else:
+            p, tp = linear_fwd(ctx, self.ff_proj, n3)                # [M, 8C]
+            gg = ctx.new(B * N, 4 * self.C)
+            hip.geglu_fwd(p, gg)
         h3, tf = linear_fwd(ctx, self.ff_out, gg, residual=h2)
         out, _ = linear_fwd(ctx, self.proj_out, h3, out=out, residual=x)
         saved = (x, st0, h0, s1, sv1, h1, s2, sv2, h2, s3, n3, p, tp, gg, tf, h3) if ctx.record else None

@@ -350,6 +350,8 @@ class ControlNetE:
         desc, prefix, n, tiles = tab
         if n:
             hip.repack(self.dtype, self.tr.flat, desc, prefix, n, tiles)
+        for L in self._b.linears:
+            L.invalidate_geglu()     # permuted (GEGLU-fused) copies are rebuilt lazily from the fresh B
 
     def fwd(self, ctx: Ctx, hint_tok, t, c, B, H, W, sinks, scales, weight=1.0, kv=None):
         """sinks[k] = (out_view, residual_view or None); out = (zero_conv_k(h_k)) * scale_k * weight + residual."""

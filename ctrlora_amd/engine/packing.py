@@ -92,6 +92,28 @@ class LinearW:
         self.tb: Optional[Trainable] = None
         self.dtype = dtype
 
+    # ---- GEGLU-fused projection (no-grad forwards): rows permuted so that every 160-column tile of the
+    # product holds 80 value columns followed by their 80 gate columns (csrc/gemm.h: ACT_GEGLU)
+    def geglu_ok(self) -> bool:
+        return self.N % 320 == 0 and (self.N // 2) % 80 == 0
+
+    def geglu_pack(self):
+        g = self.__dict__.get("_geglu")
+        if g is None:
+            half = self.N // 2
+            j = torch.arange(half // 80, device=self.W.device).repeat_interleave(160)
+            c = torch.arange(160, device=self.W.device).repeat(half // 80)
+            perm = torch.where(c < 80, j * 80 + c, half + j * 80 + (c - 80))
+            Wg = self.W.index_select(0, perm).contiguous()
+            bg = None if self.bias is None else self.bias.index_select(0, perm).contiguous()
+            Bg = self.B.index_select(0, perm).contiguous() if self.r else None
+            g = (Wg, bg, Bg)
+            self.__dict__["_geglu"] = g
+        return g
+
+    def invalidate_geglu(self):
+        self.__dict__.pop("_geglu", None)
+
     def attach_lora(self, tA: Trainable, tB: Trainable, device):
         self.tA, self.tB = tA, tB
         self.r = tA.shape[0]

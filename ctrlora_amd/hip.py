@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libctrlora_hip.so")
 
 BF16, F32 = 0, 1
 LINEAR, CONV_S1, CONV_S2, CONV_UP2, CONV_T2 = 0, 1, 2, 3, 4
-ACT_NONE, ACT_SILU = 0, 1
+ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
 
 
 class HipError(RuntimeError):
@@ -55,6 +55,7 @@ _lib = None
 _P, _L, _I, _F = C.c_void_p, C.c_long, C.c_int, C.c_float
 _SIGS = {
     "cl_abi_version": [],
+    "cl_last_hip_error": [],
     "cl_set_workspace": [_P, _L],
     "cl_set_stream_workspace": [_P, _P, _L],
     "cl_gemm_force_config": [_I],
@@ -122,8 +123,12 @@ def lib():
 
 def _chk(rc: int, what: str):
     if rc != 0:
-        raise HipError(f"{what} failed with code {rc} "
-                       f"({'unsupported shape/alignment' if rc == 1 else 'HIP launch error'})")
+        detail = "unsupported shape/alignment"
+        if rc != 1:
+            L = lib()
+            L.cl_last_hip_error_string.restype = C.c_char_p
+            detail = f"HIP launch error {L.cl_last_hip_error()}: {L.cl_last_hip_error_string().decode()}"
+        raise HipError(f"{what} failed with code {rc} ({detail})")
 
 
 def dt(t: torch.Tensor) -> int:

@@ -34,6 +34,8 @@ extern "C" {
 #endif
 
 int cl_abi_version(void);
+/* the hipError_t behind the most recent CL_ELAUNCH return (diagnostics) */
+int cl_last_hip_error(void);
 
 /* Scratch for the deterministic split-K path of the contraction kernels (fp32 partial slabs for
  * the deep-K / small-MN products of the 8x8 and 16x16 UNet levels).  The library never allocates:

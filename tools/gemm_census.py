@@ -29,6 +29,18 @@ def main():
         loss.backward()
         opt.step()
 
+    ddim = "--ddim" in sys.argv
+    if ddim:   # one CFG-batched forward at B = 2 x 16 through the inference engine
+        del model, opt
+        torch.cuda.empty_cache()
+        minf = bench.build_model("inference/ctrlora_sd15_rank128_1lora.yaml", 0).to(device).eval()
+        minf.set_engine_dtype(torch.bfloat16)
+        d32 = bench.synth(32, 64, minf.control_model.context_dim, device, 7, 1)
+
+        def step():   # noqa: F811
+            with torch.no_grad():
+                minf.apply_model(d32["z"][0], d32["t"][0], {"c_crossattn": [d32["ctx"][0]], "c_concat": [d32["hint"][0]]})
+
     step()
     torch.cuda.synchronize()
     calls = collections.OrderedDict()

@@ -7,6 +7,7 @@ timeout 300 ./build/probe_attn_bwd --time > gpurun_out/probe_attn_bwd.log 2>&1
 grep -E "TIME|ALL PASS|FAIL" gpurun_out/probe_attn.log gpurun_out/probe_attn_bwd.log | tail -20
 timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
 tail -3 gpurun_out/pytest_gpu.log
+timeout 600 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1; tail -3 gpurun_out/smoke.log
 timeout 900 python bench.py --no-cpu-baseline > gpurun_out/bench.log 2>&1; echo "bench rc=$?" >> gpurun_out/bench.log
 tail -2 gpurun_out/bench.log
 rm -rf gpurun_out/prof

@@ -86,6 +86,45 @@ static void case_linear(const char* name, int dtype, int M, int N, int K1, int K
   report(name, num, den, odt == CL_BF16 ? 4e-3 : 2e-5);
 }
 
+// ---------------- GEGLU-fused projection ----------------
+static void case_geglu(const char* name, int dtype, int M, int half, int K1, int K2, bool out_f32) {
+  const int N = 2 * half;
+  Buf A1, W1, A2, W2, C; std::vector<float> hb(N);
+  A1.init((size_t)M * K1, dtype); W1.init((size_t)N * K1, dtype, 0.1f);
+  if (K2) { A2.init((size_t)M * K2, dtype); W2.init((size_t)N * K2, dtype, 0.1f); }
+  for (auto& v : hb) v = frand();
+  // device copies with the rows permuted: tile j = [80 value rows 80j.. | 80 gate rows half+80j..]
+  auto perm = [&](int r) { const int j = r / 160, c = r % 160; return c < 80 ? j * 80 + c : half + j * 80 + (c - 80); };
+  Buf Wp, W2p; Wp.init((size_t)N * K1, dtype, 1.f, true); if (K2) W2p.init((size_t)N * K2, dtype, 1.f, true);
+  std::vector<float> hbp(N);
+  for (int r = 0; r < N; ++r) {
+    memcpy(&Wp.h[(size_t)r * K1], &W1.h[(size_t)perm(r) * K1], K1 * 4);
+    if (K2) memcpy(&W2p.h[(size_t)r * K2], &W2.h[(size_t)perm(r) * K2], K2 * 4);
+    hbp[r] = hb[perm(r)];
+  }
+  Wp.upload(); if (K2) W2p.upload();
+  float* dbias; HIPCHK(hipMalloc(&dbias, N * 4)); HIPCHK(hipMemcpy(dbias, hbp.data(), N * 4, hipMemcpyHostToDevice));
+  const int odt = out_f32 ? CL_F32 : dtype;
+  C.init((size_t)M * half, odt, 1.0f, true);
+  GemmParams p{}; p.A1 = A1.d; p.lda1 = K1; p.K1 = K1; p.W1 = Wp.d; p.ldw1 = K1;
+  if (K2) { p.A2 = A2.d; p.lda2 = K2; p.K2 = K2; p.W2 = W2p.d; p.ldw2 = K2; }
+  p.M = M; p.N = N; p.mode = GEMM_LINEAR; p.zero_page = g_zero; p.bias = dbias; p.alpha = 1.f; p.act = ACT_GEGLU;
+  p.C = C.d; p.ldc = half; p.out_f32 = out_f32; p.splitk = 1;
+  int rc = launch_gemm(p, dtype, 0);
+  HIPCHK(hipDeviceSynchronize());
+  if (rc) { printf("[FAIL] %s rc=%d\n", name, rc); g_fail++; return; }
+  C.download(odt);
+  double num = 0, den = 0;
+  for (int m = 0; m < M; ++m) for (int o = 0; o < half; ++o) {
+    double v = hb[o], g = hb[half + o];
+    for (int k = 0; k < K1; ++k) { v += (double)A1.h[(size_t)m * K1 + k] * W1.h[(size_t)o * K1 + k]; g += (double)A1.h[(size_t)m * K1 + k] * W1.h[(size_t)(half + o) * K1 + k]; }
+    for (int k = 0; k < K2; ++k) { v += (double)A2.h[(size_t)m * K2 + k] * W2.h[(size_t)o * K2 + k]; g += (double)A2.h[(size_t)m * K2 + k] * W2.h[(size_t)(half + o) * K2 + k]; }
+    const double r = v * 0.5 * g * (1.0 + std::erf(g * 0.70710678118654752440));
+    const double d = C.h[(size_t)m * half + o] - r; num += d * d; den += r * r;
+  }
+  report(name, num, den, odt == CL_BF16 ? 4e-3 : 2e-5);
+}
+
 // ---------------- conv cases ----------------
 static void case_conv(const char* name, int dtype, int mode, int B, int Hin, int Win, int C, int N) {
   int Hout, Wout;
@@ -128,6 +167,7 @@ static void case_conv(const char* name, int dtype, int mode, int B, int Hin, int
 }
 
 // ---------------- timing ----------------
+static int g_probe_act = 0;
 static void time_case(const char* name, int dtype, int mode, int M, int N, int K1, int B, int H, int W, int K2 = 0) {
   Buf A, Wt, C, A2, W2;
   const int taps = mode == GEMM_LINEAR ? 1 : 9;
@@ -137,7 +177,7 @@ static void time_case(const char* name, int dtype, int mode, int M, int N, int K
   C.init((size_t)M * N, dtype, 1.f, true);
   GemmParams p{}; p.A1 = A.d; p.lda1 = K1; p.K1 = K1; p.W1 = Wt.d; p.ldw1 = taps * K1; p.M = M; p.N = N; p.mode = mode;
   if (K2) { p.A2 = A2.d; p.lda2 = K2; p.K2 = K2; p.W2 = W2.d; p.ldw2 = K2; }
-  p.B = B; p.Hin = H; p.Win = W; p.Hout = H; p.Wout = W; p.zero_page = g_zero; p.alpha = 1.f; p.C = C.d; p.ldc = N; p.splitk = 1;
+  p.B = B; p.Hin = H; p.Win = W; p.Hout = H; p.Wout = W; p.zero_page = g_zero; p.alpha = 1.f; p.C = C.d; p.ldc = N; p.splitk = 1; p.act = g_probe_act;
   hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   for (int i = 0; i < 3; ++i) launch_gemm(p, dtype, 0);
   HIPCHK(hipDeviceSynchronize());
@@ -228,6 +268,10 @@ static void correctness_suite(const char* tag) {
   case_linear("linear bf16 K%64 one stage 520x136x64", CL_BF16, 520, 136, 64, 0, false, false, false, 0, 1.f, 0.f, true, 1);
   case_linear("linear bf16 K%64 two stages 70x72x128", CL_BF16, 70, 72, 128, 0, true, false, false, 0, 1.f, 0.f, true, 1);
   case_linear("linear f32 K%32 600x320x96+32", CL_F32, 600, 320, 96, 32, true, true, false, 0, 1.f, 1.f, true, 1);
+  case_geglu("geglu bf16 700x320(out)x128 f32out", CL_BF16, 700, 320, 128, 0, true);
+  case_geglu("geglu bf16 300x160x192+64 bf16out", CL_BF16, 300, 160, 192, 64, false);
+  case_geglu("geglu bf16 130x240x2048 (split-K)", CL_BF16, 130, 240, 2048, 0, true);
+  case_geglu("geglu f32 200x160x96", CL_F32, 200, 160, 96, 0, true);
   case_linear("linear bf16 M=8 (emb)", CL_BF16, 8, 1280, 320, 32, true, false, false, ACT_SILU, 1.f, 0.f, false, 1);
   case_conv("conv3x3 s1 bf16 2x12x12x32->64", CL_BF16, GEMM_CONV_S1, 2, 12, 12, 32, 64);
   case_conv("conv3x3 s1 bf16 big 2x40x40x64->136", CL_BF16, GEMM_CONV_S1, 2, 40, 40, 64, 136);
@@ -256,17 +300,31 @@ int main(int argc, char** argv) {
     if (which == 1) time_case("gemm bf16 4096^3", CL_BF16, GEMM_LINEAR, 4096, 4096, 4096, 0, 0, 0);
     if (which == 2) time_case("conv bf16 1280->1280 @16^2 B8", CL_BF16, GEMM_CONV_S1, 8 * 16 * 16, 1280, 1280, 8, 16, 16);
     if (which == 3) time_case("gemm bf16 32768x2560x320 (GEGLU proj)", CL_BF16, GEMM_LINEAR, 32768, 2560, 320, 0, 0, 0);
+    if (which == 4) {
+      time_case("gemm bf16 131072x2560x320 normal", CL_BF16, GEMM_LINEAR, 131072, 2560, 320, 0, 0, 0);
+      g_probe_act = 77;
+      time_case("gemm bf16 131072x2560x320 no stores", CL_BF16, GEMM_LINEAR, 131072, 2560, 320, 0, 0, 0);
+      g_probe_act = 0;
+      time_case("gemm bf16 131072x320x320 normal", CL_BF16, GEMM_LINEAR, 131072, 320, 320, 0, 0, 0);
+      g_probe_act = 77;
+      time_case("gemm bf16 131072x320x320 no stores", CL_BF16, GEMM_LINEAR, 131072, 320, 320, 0, 0, 0);
+      g_probe_act = 0;
+      time_case("gemm bf16 131072x2560x1280 normal", CL_BF16, GEMM_LINEAR, 131072, 2560, 1280, 0, 0, 0);
+      g_probe_act = 77;
+      time_case("gemm bf16 131072x2560x1280 no stores", CL_BF16, GEMM_LINEAR, 131072, 2560, 1280, 0, 0, 0);
+      g_probe_act = 0;
+    }
     return 0;
   }
   wgrad_suite(argc > 1 && !strcmp(argv[1], "--time"));
   if (argc > 2 && !strcmp(argv[2], "--wgrad-only")) return g_fail ? 1 : 0;
   g_gemm_force_cfg = -1; correctness_suite("heuristic config");
-  const int cfgs[] = {12};
+  const int cfgs[] = {12, 2, 10};
   for (int c : cfgs) { char tag[32]; snprintf(tag, 32, "forced cfg %d", c); g_gemm_force_cfg = c; correctness_suite(tag); }
   g_gemm_force_cfg = -1;
 
   if (argc > 1 && !strcmp(argv[1], "--time")) {
-    const int tc[] = {8, 12, 8, 12};
+    const int tc[] = {-1};
     for (int c : tc) {
       g_gemm_force_cfg = c;
       printf("---- timing, cfg %d (-1 heuristic, 6 = round-0 structure)\n", c);
