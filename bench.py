@@ -68,7 +68,9 @@ def synth(B, H, ctx_dim, device, seed, n):
 
 
 def conv_kernel_probe(device, dtype, iters=30):
-    """Dominant kernel: ResBlock conv 320->320 @ 64x64, B=8 (gemm_kernel<bf16,128,128>), HIP-event timed."""
+    """Dominant kernel: ResBlock conv 320->320 @ 64x64, B=8 -- gemm_fl_kernel<bf16,256,160> (implicit-GEMM, stride-1
+    conv mode) -- timed with HIP events on the stream it is launched on (torch's current stream).  `traffic` is
+    the HBM bytes per launch measured with rocprofv3 PMC passes on the same launch (profiles/dominant_kernel_traffic.json)."""
     from ctrlora_amd import hip
     B, H, C = 8, 64, 320
     x = torch.randn(B * H * H, C, device=device).to(dtype)
@@ -86,9 +88,15 @@ def conv_kernel_probe(device, dtype, iters=30):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * B * H * H * C * 9 * C
-    return dict(kernel="gemm_kernel<bf16,128,128> conv3x3 320->320 @64x64 B8", ms=round(ms, 4),
-                achieved=round(flops / ms * 1e-9, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                frac=round(flops / ms * 1e-9 / PEAK_BF16_TFLOPS, 4))
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")) as f:
+            traffic = json.load(f)["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return dict(kernel="gemm_fl_kernel<bf16,256x160,8 waves> conv3x3 320->320 @64x64 B8 (60.4 GFLOP/launch)",
+                ms=round(ms, 4), achieved=round(flops / ms * 1e-9, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                frac=round(flops / ms * 1e-9 / PEAK_BF16_TFLOPS, 4), traffic=traffic)
 
 
 def ddim_bench(device, dtype, B=16, S=50, tiny=False):
@@ -161,6 +169,8 @@ def main():
     ap.add_argument("--no-ddim", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--ddim-only", action="store_true", help="profiling aid: run only the DDIM leg")
+    ap.add_argument("--force-split-graphs", action="store_true",
+                    help="test aid: use the multi-rank structure (graph A | all-reduce | graph B) even with one rank")
     ap.add_argument("--tiny", action="store_true", help="debug: narrow model")
     args = ap.parse_args()
 
@@ -170,7 +180,7 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -196,7 +206,7 @@ def main():
         from ctrlora_amd.train import GraphedTrainStep
         try:
             graphed = GraphedTrainStep(model, opt, data["z"][0], data["ctx"][0], data["hint"][0], data["t"][0],
-                                       data["noise"][0])
+                                       data["noise"][0], split_graphs=True if args.force_split_graphs else None)
         except Exception as e:   # capture is an optimisation: never lose the measurement to it
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches",
                   file=sys.stderr)
@@ -255,17 +265,40 @@ def main():
         roof = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                 "basis": f"{tf_img} TFLOP/image algorithmic (SURVEY.md 8d), per GPU"}
+        roof["whole_step"] = {"achieved": roof["achieved"], "frac": roof["frac"], "basis": roof.pop("basis")}
         if world == 1 and not args.tiny and args.dtype == "bf16":
-            roof["dominant_kernel"] = conv_kernel_probe(device, dtype)
+            dk = conv_kernel_probe(device, dtype)
+            # contract fields describe the dominant kernel; the whole-step figure stays alongside
+            roof.update(achieved=dk["achieved"], frac=dk["frac"], traffic=dk["traffic"], kernel=dk["kernel"],
+                        ms_per_launch=dk["ms"])
         out["roofline"] = roof
-        if world == 1 and not args.no_ddim:
-            del model, opt
-            torch.cuda.empty_cache()
-            out["ddim"] = ddim_bench(device, dtype, tiny=args.tiny)
+    # DDIM leg: every rank samples its own batch (replicas, no collective); aggregate = sum over ranks
+    ddim = None
+    if not args.no_ddim:
+        del graphed, model, opt
+        torch.cuda.empty_cache()
+        try:
+            ddim = ddim_bench(device, dtype, tiny=args.tiny)
+            if world > 1:
+                tt = torch.tensor([ddim["S"] / ddim["value"]], device=device, dtype=torch.float64)   # seconds per loop
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                ddim["value"] = round(world * ddim["S"] / float(tt), 3)
+                ddim["ms_per_step"] = round(float(tt) / ddim["S"] * 1e3, 2)
+                ddim["mfma_frac"] = round(DDIM_TFLOP_PER_STEP_IMAGE * ddim["batch"] * ddim["value"] / world / PEAK_BF16_TFLOPS, 4)
+                ddim["note"] += f"; {world} independent replicas (one batch of {ddim['batch']} per GPU), value = sum"
+        except Exception as e:
+            print(f"[bench] DDIM leg failed on rank {rank}: {type(e).__name__}: {e}", file=sys.stderr)
+            ddim = None
+            if world > 1:   # keep the ranks in step
+                tt = torch.tensor([0.0], device=device, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        if ddim is not None:
+            out["ddim"] = ddim
         if world == 1 and not args.no_cpu_baseline and not args.tiny:
             out["cpu_baseline"] = cpu_baseline(args.rank_lora)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -147,11 +147,14 @@ class GraphedTrainStep:
     `model` is a ControlFinetuneLDM-like module (p_losses / dp / control_model), `opt` its FusedAdamW.
     """
 
-    def __init__(self, model, opt, z, cond_txt, hint, t, noise, warmup: int = 2):
+    def __init__(self, model, opt, z, cond_txt, hint, t, noise, warmup: int = 2, split_graphs=None):
         import torch.distributed as dist
         self.model, self.opt = model, opt
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.dist = dist
+        # two graphs with the all-reduce in between whenever there is more than one rank (or when forced, to
+        # exercise that structure on a single GPU)
+        split = (self.world > 1) if split_graphs is None else bool(split_graphs)
         self.s_z, self.s_ctx, self.s_hint = z.clone(), cond_txt.clone(), hint.clone()
         self.s_t, self.s_noise = t.clone(), noise.clone()
         self.loss = None
@@ -167,7 +170,7 @@ class GraphedTrainStep:
             return loss.detach()
 
         def reduce_grads():
-            if self.world > 1:
+            if split and dist.is_initialized():
                 for ex in opt.executors:
                     dist.all_reduce(ex.tr.flat_grad, op=dist.ReduceOp.SUM)
 
@@ -181,7 +184,7 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.g_a = torch.cuda.CUDAGraph()
-        if self.world == 1:
+        if not split:
             with torch.cuda.graph(self.g_a):
                 self.loss = fwd_bwd()
                 opt.step()
