@@ -7,7 +7,6 @@
 #include "norm.h"
 
 using namespace cl;
-namespace cl { int g_last_hip_error = 0; }
 
 // Every entry point converts its stream argument through S(): it also clears a stale "last error" left by
 // unrelated runtime calls of the host process (e.g. an event query that returned hipErrorNotReady), so that

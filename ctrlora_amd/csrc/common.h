@@ -120,7 +120,8 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
       (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-extern int g_last_hip_error;   // capi.hip: the hipError_t behind the most recent CL_ELAUNCH (diagnostics)
+// the hipError_t behind the most recent CL_ELAUNCH (diagnostics; read through cl_last_hip_error())
+inline int g_last_hip_error = 0;
 #define CL_CHECK_LAUNCH()                                   \
   do {                                                      \
     hipError_t e__ = hipGetLastError();                     \

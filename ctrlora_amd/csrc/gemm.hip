@@ -534,15 +534,15 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p
   long tapoff = 0;
   if constexpr (MODE == FL_CONV_S1) tapoff = ((long)(tap / 3 - 1) * p.Win + (tap % 3 - 1)) * pixb;
 
-  auto issue_next = [&](int slot) {
+  // DMA issue of the next stage, in two parts so that a schedule can put the (expensive) A-operand address
+  // generation and the (cheap) B-operand part into different MFMA batches: issue_a first, then issue_b,
+  // which also advances the walk.
+  auto issue_a = [&](int slot) {
     char* As = smem + slot * SLOT;
-    char* Bs = As + AI * 1024;
     if constexpr (MODE == FL_LINEAR) {
-      if (ks2 && kt_next == ks1) {   // switch both operands to the second K segment (LoRA up-projection)
+      if (ks2 && kt_next == ks1) {   // switch to the second K segment (LoRA up-projection)
 #pragma unroll
         for (int j = 0; j < AJ; ++j) pa[j] = a2[j];
-#pragma unroll
-        for (int j = 0; j < BJ; ++j) pw[j] = w2[j];
       }
 #pragma unroll
       for (int j = 0; j < AJ; ++j) { glds16(pa[j], As + (j * NW + wave) * 1024); pa[j] += 128; }
@@ -553,11 +553,6 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p
         const char* src = ((vmask[j] >> tap) & 1u) ? pa[j] + soff : zpage;
         glds16(src, As + (j * NW + wave) * 1024);
       }
-      const bool wrap = cc + 1 == cpt;          // wave-uniform: scalar selects, no branch
-      cc = wrap ? 0 : cc + 1;
-      tap += wrap ? 1 : 0;
-      const int ky = (tap * 11) >> 5;           // tap / 3 for tap in [0, 9]
-      tapoff = ((long)(ky - 1) * p.Win + (tap - 3 * ky - 1)) * pixb;
     } else {
       const int ky = tap / 3, kx = tap - ky * 3;
       const int sy = (p.mode == GEMM_CONV_S2) ? 2 : 1;
@@ -578,12 +573,29 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p
         const char* src = ok ? pa[j] + pix * pixb + (long)cc * 128 : zpage;
         glds16(src, As + (j * NW + wave) * 1024);
       }
+    }
+  };
+  auto issue_b = [&](int slot) {
+    char* Bs = smem + slot * SLOT + AI * 1024;
+    if constexpr (MODE == FL_LINEAR) {
+      if (ks2 && kt_next == ks1) {
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) pw[j] = w2[j];
+      }
+    } else if constexpr (MODE == FL_CONV_S1) {
+      const bool wrap = cc + 1 == cpt;          // wave-uniform: scalar selects, no branch
+      cc = wrap ? 0 : cc + 1;
+      tap += wrap ? 1 : 0;
+      const int ky = (tap * 11) >> 5;           // tap / 3 for tap in [0, 9]
+      tapoff = ((long)(ky - 1) * p.Win + (tap - 3 * ky - 1)) * pixb;
+    } else {
       if (++cc == cpt) { cc = 0; ++tap; }
     }
 #pragma unroll
     for (int j = 0; j < BJ; ++j) { glds16(pw[j], Bs + binst[j] * 1024); pw[j] += 128; }
     ++kt_next;
   };
+  auto issue_next = [&](int slot) { issue_a(slot); issue_b(slot); };
 
   f32x4_t acc[FM][FN];
 #pragma unroll
@@ -623,8 +635,50 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p
       for (int j = 0; j < FN; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
   };
 
-  // ---- prologue: stages 0 and 1 in flight; stage 0 landed, its k-half 0 in registers
   u32x4_t fa[FM], fb[FN], ga[FM], gb[FN];
+  int slot = 0;
+  if constexpr (PRIO == 2) {
+    // ---- split-issue schedule (R = 3): the A-operand DMAs of stage s+2 ride in the first MFMA batch of stage
+    // s, the B-operand DMAs in the second one, so both batches carry a similar share of address-generation ALU.
+    // (A "late issue" variant -- DMA of stage s+3 issued after the mid-stage barrier, two stages in flight --
+    // was measured slower than the baseline schedule: DMA latency is not what limits this kernel.)
+    static_assert(PRIO != 2 || R == 3, "split issue needs the 3-slot ring");
+    issue_next(0);
+    if (total > 1) { issue_next(1); wait_vm<G>(); } else { wait_vm<0>(); }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(0, 0, fa, fb);
+    wait_frags(fa, fb);
+    auto stage2 = [&](auto ISSUE, bool has_next) {
+      constexpr bool issue = decltype(ISSUE)::value;
+      const int slot1 = (slot == R - 1) ? 0 : slot + 1;
+      const int slot2 = (slot1 == R - 1) ? 0 : slot1 + 1;
+      read_frags(slot, 1, ga, gb);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_all(fa, fb);
+      if constexpr (issue) issue_a(slot2);                      // slot2 was last read before the previous barrier
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // k-half 1 fragments have landed
+      // own DMA of stage s+1 (A and B parts) has landed; only the A part of stage s+2 may still fly
+      if constexpr (issue) wait_vm<AJ>(); else wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (has_next) read_frags(slot1, 0, fa, fb);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) asm volatile("" : "+v"(ga[i]));
+#pragma unroll
+      for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(gb[j]));
+      mma_all(ga, gb);
+      if constexpr (issue) issue_b(slot2);
+      wait_frags(fa, fb);
+      slot = slot1;
+    };
+    int s = 0;
+    for (; s + 2 < total; ++s) stage2(std::true_type{}, true);
+    for (; s < total; ++s) stage2(std::false_type{}, s + 1 < total);
+  } else {
+  // ---- prologue: stages 0 and 1 in flight; stage 0 landed, its k-half 0 in registers
   issue_next(0);
   if (total > 1) {
     issue_next(1);
@@ -640,7 +694,6 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p
   // One pipeline stage.  ISSUE (compile time): start the DMA of stage s+2 -- true for all but the last
   // two stages, so that the MFMAs of k-half 0 and the address generation + DMA issue sit in ONE basic
   // block and the scheduler can slot the scalar/vector ALU work into the MFMA issue gaps.
-  int slot = 0;
   auto stage = [&](auto ISSUE, bool has_next) {
     constexpr bool issue = decltype(ISSUE)::value;
     const int slot1 = (slot == R - 1) ? 0 : slot + 1;
@@ -671,6 +724,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p
   int s = 0;
   for (; s + 2 < total; ++s) stage(std::true_type{}, true);
   for (; s < total; ++s) stage(std::false_type{}, s + 1 < total);
+  }
   __syncthreads();  // all waves done with the operand slots; reuse LDS for the epilogue
 
   store_tile<T, FM, FN, (WGN == 2 && FN == 5)>(p, acc, reinterpret_cast<float*>(smem) + wave * (EROWS * EST),
@@ -849,7 +903,7 @@ int g_gemm_force_cfg = -1;   // probe / tuning hook: >= 0 forces a tile configur
 template <typename T>
 static int launch_t(const GemmParams& p, hipStream_t stream) {
   int cfg = g_gemm_force_cfg;
-  if (p.act == ACT_GEGLU && cfg != 2 && cfg != 12 && cfg != 8 && cfg != 10) cfg = -2;   // needs a 2 x 80-column wave pair
+  if (p.act == ACT_GEGLU && cfg != 2 && cfg != 12 && cfg != 8 && cfg != 10 && cfg != 14) cfg = -2;   // needs a 2 x 80-column wave pair
   if (cfg < 0) {
     // v2 (64-byte substeps, 4 waves) choices
     if (p.M <= 64 || p.N <= 64) cfg = 0;
@@ -866,9 +920,9 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
       const long t256 = (long)((p.M + 255) / 256) * ((p.N + bn - 1) / bn);
       const int steps = ((p.mode == GEMM_LINEAR ? 1 : 9) * p.K1 + p.K2) / kps;
       const long need = (256 + t256 - 1) / t256;   // split factor that fills 256 CUs
-      if (t256 >= 200 || (g_ws && steps >= 8 * need)) cfg = 12 + (bn == 160 ? 0 : 1);
+      if (t256 >= 200 || (g_ws && steps >= 8 * need)) cfg = 14 + (bn == 160 ? 0 : 1);   // split-issue schedule
     }
-    if (p.act == ACT_GEGLU && cfg != 12) cfg = 2;
+    if (p.act == ACT_GEGLU && cfg != 14) cfg = 2;
   }
   switch (cfg) {
     case 0: return launch_cfg<T, 64, 64, 2, 2, 1, 4>(p, stream);
@@ -890,6 +944,12 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
       if (p.K1 % kps || p.K2 % kps || (p.mode != GEMM_LINEAR && p.K2))
         return launch_cfg<T, 128, 128, 2, 2, 2, 4>(p, stream);
       return cfg == 12 ? launch_fl<T, 256, 160, 4, 2, 3, 1>(p, stream) : launch_fl<T, 256, 128, 4, 2, 3, 1>(p, stream);
+    }
+    case 14: case 15: {   // production: split-issue schedule (A-operand DMAs in MFMA batch 1, B-operand DMAs in batch 2)
+      const int kps = 128 / (int)sizeof(T);
+      if (p.K1 % kps || p.K2 % kps || (p.mode != GEMM_LINEAR && p.K2))
+        return launch_cfg<T, 128, 128, 2, 2, 2, 4>(p, stream);
+      return cfg == 14 ? launch_fl<T, 256, 160, 4, 2, 3, 2>(p, stream) : launch_fl<T, 256, 128, 4, 2, 3, 2>(p, stream);
     }
     case 10: case 11: {   // 128-row tiles, 4 waves, 2-slot ring: two workgroups per CU (small-K / mid-size products)
       const int kps = 128 / (int)sizeof(T);
