@@ -532,7 +532,15 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p
   int cc = (MODE == FL_LINEAR) ? 0 : kbeg - tap * cpt;
   const long pixb = (long)p.lda1 * sizeof(T);          // bytes per pixel row of A
   long tapoff = 0;
-  if constexpr (MODE == FL_CONV_S1) tapoff = ((long)(tap / 3 - 1) * p.Win + (tap % 3 - 1)) * pixb;
+  const char* cur[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) cur[j] = nullptr;
+  if constexpr (MODE == FL_CONV_S1) {
+    tapoff = ((long)(tap / 3 - 1) * p.Win + (tap % 3 - 1)) * pixb;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j)   // a split-K workgroup may start in the middle of a tap
+      cur[j] = ((vmask[j] >> tap) & 1u) ? pa[j] + tapoff + (long)cc * 128 : zpage + (long)cc * 128;
+  }
 
   // DMA issue of the next stage, in two parts so that a schedule can put the (expensive) A-operand address
   // generation and the (cheap) B-operand part into different MFMA batches: issue_a first, then issue_b,
@@ -547,12 +555,15 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p
 #pragma unroll
       for (int j = 0; j < AJ; ++j) { glds16(pa[j], As + (j * NW + wave) * 1024); pa[j] += 128; }
     } else if constexpr (MODE == FL_CONV_S1) {
-      const long soff = tapoff + (long)cc * 128;
+      // cur[j] walks the channel chunks of the current tap (+128 B per stage); lanes whose tap falls outside
+      // the image walk the zero page instead (it is at least (K1 / 64 + 1) * 128 bytes long), so a DMA costs
+      // one 64-bit add.  The select against the 9-bit mask happens only when the tap changes.
+      if (cc == 0) {
 #pragma unroll
-      for (int j = 0; j < AJ; ++j) {
-        const char* src = ((vmask[j] >> tap) & 1u) ? pa[j] + soff : zpage;
-        glds16(src, As + (j * NW + wave) * 1024);
+        for (int j = 0; j < AJ; ++j) cur[j] = ((vmask[j] >> tap) & 1u) ? pa[j] + tapoff : zpage;
       }
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) { glds16(cur[j], As + (j * NW + wave) * 1024); cur[j] += 128; }
     } else {
       const int ky = tap / 3, kx = tap - ky * 3;
       const int sy = (p.mode == GEMM_CONV_S2) ? 2 : 1;
@@ -637,7 +648,125 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p
 
   u32x4_t fa[FM], fb[FN], ga[FM], gb[FN];
   int slot = 0;
-  if constexpr (PRIO == 2) {
+  if constexpr (PRIO == 4) {
+    // ---- coarse ping-pong (R = 3): two sections per stage, L(s) = all fragment reads of stage s + the whole DMA
+    // issue of stage s+2 + waits, M(s) = 40 MFMAs; the wave groups one barrier apart as in PRIO 3.
+    //   RAW  the vmcnt for stage s (end of L(s-1)) precedes barrier 2s in both groups; L(s) starts after it.
+    //   WAR  stage s-1 was last read in L(s-1) (retired before barrier 2s); the DMA into its slot is issued in L(s).
+    static_assert(PRIO != 4 || R == 3, "ping-pong needs the 3-slot ring");
+    const int grp = wave / (NW / 2);
+    issue_next(0);
+    if (total > 1) { issue_next(1); wait_vm<G>(); } else { wait_vm<0>(); }
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    auto stage4 = [&](auto ISSUE) {
+      constexpr bool issue = decltype(ISSUE)::value;
+      const int slot1 = (slot == R - 1) ? 0 : slot + 1;
+      const int slot2 = (slot1 == R - 1) ? 0 : slot1 + 1;
+      read_frags(slot, 0, fa, fb);
+      read_frags(slot, 1, ga, gb);
+      if constexpr (issue) issue_next(slot2);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if constexpr (issue) wait_vm<G>(); else wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) { asm volatile("" : "+v"(fa[i])); asm volatile("" : "+v"(ga[i])); }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) { asm volatile("" : "+v"(fb[j])); asm volatile("" : "+v"(gb[j])); }
+      __builtin_amdgcn_s_setprio(1);
+      mma_all(fa, fb);
+      mma_all(ga, gb);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      slot = slot1;
+    };
+    int s = 0;
+    for (; s + 2 < total; ++s) stage4(std::true_type{});
+    for (; s < total; ++s) stage4(std::false_type{});
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+  } else if constexpr (PRIO == 3) {
+    // ---- ping-pong schedule (R = 3).  Every stage is four barrier-delimited sections per wave,
+    //     L0 | M0 | L1 | M1      L = LDS fragment reads + DMA issue + waits, M = 20 bare MFMAs at priority 1
+    // and the upper four waves run ONE barrier behind the lower four (each SIMD hosts one wave of either group),
+    // so on every SIMD one wave feeds the matrix pipe while the other one loads.
+    //   L0(s): read k-half 1 of stage s; issue B-operand DMA of stage s+2; vmcnt: own DMA of stage s+1 landed
+    //   L1(s): read k-half 0 of stage s+1; issue A-operand DMA of stage s+3 (into the slot of stage s)
+    // Hazards, in barrier generations (group 0 executes L0(s) before barrier 4s+1, group 1 before 4s+2):
+    //   RAW  every wave's vmcnt for stage s+1 precedes barrier 4s+2; the earliest L1(s) starts after it.
+    //   WAR  the last reads of stage s (L0(s), retired by lgkmcnt(0) before the section's barrier) precede
+    //        barrier 4s+2; the earliest DMA into that slot (L1(s) of group 0) is issued after it.
+    static_assert(PRIO != 3 || R == 3, "ping-pong needs the 3-slot ring");
+    const int grp = wave / (NW / 2);
+    issue_next(0);
+    if (total > 1) issue_next(1);
+    if (total > 2) { issue_a(2); wait_vm<G + AJ>(); } else if (total > 1) { wait_vm<G>(); } else { wait_vm<0>(); }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(0, 0, fa, fb);
+    wait_frags(fa, fb);
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // the stagger
+    __builtin_amdgcn_sched_barrier(0);
+    auto stage3 = [&](auto IB_, auto IA_, bool has_next) {
+      constexpr bool IB = decltype(IB_)::value, IA = decltype(IA_)::value;
+      const int slot1 = (slot == R - 1) ? 0 : slot + 1;
+      const int slot2 = (slot1 == R - 1) ? 0 : slot1 + 1;
+      // L0
+#ifndef FLP_NOLDS
+      read_frags(slot, 1, ga, gb);
+#endif
+      if constexpr (IB) issue_b(slot2);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if constexpr (IB) wait_vm<G>(); else wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // M0
+      __builtin_amdgcn_s_setprio(1);
+      mma_all(fa, fb);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // L1
+#ifndef FLP_NOLDS
+      if (has_next) read_frags(slot1, 0, fa, fb);
+#endif
+      if constexpr (IA) issue_a(slot);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // M1
+#pragma unroll
+      for (int i = 0; i < FM; ++i) asm volatile("" : "+v"(ga[i]));
+#pragma unroll
+      for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(gb[j]));
+      __builtin_amdgcn_s_setprio(1);
+      mma_all(ga, gb);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) asm volatile("" : "+v"(fa[i]));
+#pragma unroll
+      for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(fb[j]));
+      slot = slot1;
+    };
+    int s = 0;
+#ifdef FLP_NODMA
+    for (; s + 3 < total; ++s) stage3(std::false_type{}, std::false_type{}, true);
+#endif
+    for (; s + 3 < total; ++s) stage3(std::true_type{}, std::true_type{}, true);
+    for (; s + 2 < total; ++s) stage3(std::true_type{}, std::false_type{}, true);
+    for (; s < total; ++s) stage3(std::false_type{}, std::false_type{}, s + 1 < total);
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
+  } else if constexpr (PRIO == 2) {
     // ---- split-issue schedule (R = 3): the A-operand DMAs of stage s+2 ride in the first MFMA batch of stage
     // s, the B-operand DMAs in the second one, so both batches carry a similar share of address-generation ALU.
     // (A "late issue" variant -- DMA of stage s+3 issued after the mid-stage barrier, two stages in flight --
@@ -903,7 +1032,7 @@ int g_gemm_force_cfg = -1;   // probe / tuning hook: >= 0 forces a tile configur
 template <typename T>
 static int launch_t(const GemmParams& p, hipStream_t stream) {
   int cfg = g_gemm_force_cfg;
-  if (p.act == ACT_GEGLU && cfg != 2 && cfg != 12 && cfg != 8 && cfg != 10 && cfg != 14) cfg = -2;   // needs a 2 x 80-column wave pair
+  if (p.act == ACT_GEGLU && cfg != 2 && cfg != 12 && cfg != 8 && cfg != 10 && cfg != 14 && cfg != 16 && cfg != 18) cfg = -2;   // needs a 2 x 80-column wave pair
   if (cfg < 0) {
     // v2 (64-byte substeps, 4 waves) choices
     if (p.M <= 64 || p.N <= 64) cfg = 0;
@@ -920,9 +1049,9 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
       const long t256 = (long)((p.M + 255) / 256) * ((p.N + bn - 1) / bn);
       const int steps = ((p.mode == GEMM_LINEAR ? 1 : 9) * p.K1 + p.K2) / kps;
       const long need = (256 + t256 - 1) / t256;   // split factor that fills 256 CUs
-      if (t256 >= 200 || (g_ws && steps >= 8 * need)) cfg = 14 + (bn == 160 ? 0 : 1);   // split-issue schedule
+      if (t256 >= 200 || (g_ws && steps >= 8 * need)) cfg = 16 + (bn == 160 ? 0 : 1);   // ping-pong schedule
     }
-    if (p.act == ACT_GEGLU && cfg != 14) cfg = 2;
+    if (p.act == ACT_GEGLU && cfg != 16) cfg = 2;
   }
   switch (cfg) {
     case 0: return launch_cfg<T, 64, 64, 2, 2, 1, 4>(p, stream);
@@ -939,17 +1068,29 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
         return launch_cfg<T, 128, 128, 2, 2, 2, 4>(p, stream);
       return cfg == 8 ? launch_fl<T, 256, 160, 4, 2, 3>(p, stream) : launch_fl<T, 256, 128, 4, 2, 3>(p, stream);
     }
-    case 12: case 13: {   // production: cfg 8 / 9 with s_setprio(1) around the pure-MFMA half of every stage (+2-3 %)
+    case 12: case 13: {   // cfg 8 / 9 with s_setprio(1) around the pure-MFMA half of every stage (+2-3 %)
       const int kps = 128 / (int)sizeof(T);
       if (p.K1 % kps || p.K2 % kps || (p.mode != GEMM_LINEAR && p.K2))
         return launch_cfg<T, 128, 128, 2, 2, 2, 4>(p, stream);
       return cfg == 12 ? launch_fl<T, 256, 160, 4, 2, 3, 1>(p, stream) : launch_fl<T, 256, 128, 4, 2, 3, 1>(p, stream);
     }
-    case 14: case 15: {   // production: split-issue schedule (A-operand DMAs in MFMA batch 1, B-operand DMAs in batch 2)
+    case 14: case 15: {   // split-issue schedule (A-operand DMAs in MFMA batch 1, B-operand DMAs in batch 2)
       const int kps = 128 / (int)sizeof(T);
       if (p.K1 % kps || p.K2 % kps || (p.mode != GEMM_LINEAR && p.K2))
         return launch_cfg<T, 128, 128, 2, 2, 2, 4>(p, stream);
       return cfg == 14 ? launch_fl<T, 256, 160, 4, 2, 3, 2>(p, stream) : launch_fl<T, 256, 128, 4, 2, 3, 2>(p, stream);
+    }
+    case 16: case 17: {   // production: ping-pong schedule: two wave groups one barrier apart, MFMA sections at priority 1
+      const int kps = 128 / (int)sizeof(T);
+      if (p.K1 % kps || p.K2 % kps || (p.mode != GEMM_LINEAR && p.K2))
+        return launch_cfg<T, 128, 128, 2, 2, 2, 4>(p, stream);
+      return cfg == 16 ? launch_fl<T, 256, 160, 4, 2, 3, 3>(p, stream) : launch_fl<T, 256, 128, 4, 2, 3, 3>(p, stream);
+    }
+    case 18: case 19: {   // coarse ping-pong (one L and one M section per stage)
+      const int kps = 128 / (int)sizeof(T);
+      if (p.K1 % kps || p.K2 % kps || (p.mode != GEMM_LINEAR && p.K2))
+        return launch_cfg<T, 128, 128, 2, 2, 2, 4>(p, stream);
+      return cfg == 18 ? launch_fl<T, 256, 160, 4, 2, 3, 4>(p, stream) : launch_fl<T, 256, 128, 4, 2, 3, 4>(p, stream);
     }
     case 10: case 11: {   // 128-row tiles, 4 waves, 2-slot ring: two workgroups per CU (small-K / mid-size products)
       const int kps = 128 / (int)sizeof(T);

@@ -159,6 +159,7 @@ def ld(t: Optional[torch.Tensor]) -> int:
     return t.stride(0)
 
 
+ZERO_PAGE_BYTES = 16384   # conv halo source: >= 4 * Cin bytes (include/ctrlora_hip.h), 16 KiB covers Cin <= 4096
 _zero_pages = {}
 _workspace = None
 WORKSPACE_BYTES = 64 << 20
@@ -202,7 +203,7 @@ def ensure_workspace(device) -> None:
 def zero_page(device) -> torch.Tensor:
     k = str(device)
     if k not in _zero_pages:
-        _zero_pages[k] = torch.zeros(1024, dtype=torch.uint8, device=device)
+        _zero_pages[k] = torch.zeros(ZERO_PAGE_BYTES, dtype=torch.uint8, device=device)
     return _zero_pages[k]
 
 

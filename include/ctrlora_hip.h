@@ -69,7 +69,8 @@ typedef struct cl_gemm_params {
   int M, N;
   int mode;
   int B, Hin, Win, Hout, Wout;        /* conv geometry                                       */
-  const void* zero_page;              /* >= 64 zero bytes on the device (conv halo)          */
+  const void* zero_page;              /* zeros on the device for conv halos: >= 4*K1 + 128 bytes (16 KiB is enough for every
+                                         CtrLoRA shape); the stride-1 conv path walks it like an image row     */
   const float* bias;                  /* fp32 [N] or NULL                                    */
   const void* rowbias; long ldrb; int rows_per_batch;
   const void* residual; long ldr;
@@ -106,7 +107,7 @@ int cl_weight_grad(int dtype, const void* dyT, long lddyt, const void* xT, long 
 
 /* the same weight gradient without materialised transposes (bf16 only): dW[N,K] += scale * dy[M,N]^T . x[M,K],
  * both operands row-major as the forward/backward pass left them; fragments are built with the gfx950 LDS
- * transpose read (csrc/wgrad.hip).  zero_page: >= 64 zero bytes on the device (rows past M). */
+ * transpose read (csrc/wgrad.hip).  zero_page: >= 64 zero bytes on the device (rows past M; >= 64 bytes). */
 int cl_weight_grad_tn(int dtype, const void* dy, long lddy, const void* x, long ldx, float* dW, long lddw,
                       int M, int N, int K, float scale, const void* zero_page, void* stream);
 

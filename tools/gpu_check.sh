@@ -2,9 +2,6 @@
 # One GPU-box visit: kernel probes, parity tests, headline bench (no CPU baseline), kernel-trace profile.
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 300 ./build/probe_attn --time > gpurun_out/probe_attn.log 2>&1
-timeout 300 ./build/probe_attn_bwd --time > gpurun_out/probe_attn_bwd.log 2>&1
-grep -E "TIME|ALL PASS|FAIL" gpurun_out/probe_attn.log gpurun_out/probe_attn_bwd.log | tail -20
 timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
 tail -3 gpurun_out/pytest_gpu.log
 timeout 600 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1; tail -3 gpurun_out/smoke.log
@@ -13,4 +10,5 @@ tail -2 gpurun_out/bench.log
 rm -rf gpurun_out/prof
 timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o train -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-ddim > gpurun_out/prof.log 2>&1
 python tools/prof_summary.py gpurun_out/prof/train_results.db > gpurun_out/prof_summary.txt 2>&1
+head -30 gpurun_out/prof_summary.txt
 head -30 gpurun_out/prof_summary.txt

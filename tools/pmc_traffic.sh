@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/pmc_traffic; rm -rf $OUT; mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/$c -o r --output-format csv -- ./build/probe_gemm --one 12 0 > $OUT/$c.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/$c -o r --output-format csv -- ./build/probe_gemm --one 16 0 > $OUT/$c.log 2>&1
 done
 python3 - <<PY
 import csv,glob

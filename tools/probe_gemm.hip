@@ -290,7 +290,7 @@ static void correctness_suite(const char* tag) {
 int main(int argc, char** argv) {
   hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s  CUs=%d  arch=%s\n", prop.name, prop.multiProcessorCount, prop.gcnArchName);
-  HIPCHK(hipMalloc(&g_zero, 4096)); HIPCHK(hipMemset(g_zero, 0, 4096));
+  HIPCHK(hipMalloc(&g_zero, 16384)); HIPCHK(hipMemset(g_zero, 0, 16384));
   void* ws; HIPCHK(hipMalloc(&ws, 64 << 20)); gemm_set_workspace(ws, 64 << 20);
 
   if (argc > 3 && !strcmp(argv[1], "--one")) {   // profiling aid: one timed shape under one forced config
@@ -319,12 +319,12 @@ int main(int argc, char** argv) {
   wgrad_suite(argc > 1 && !strcmp(argv[1], "--time"));
   if (argc > 2 && !strcmp(argv[2], "--wgrad-only")) return g_fail ? 1 : 0;
   g_gemm_force_cfg = -1; correctness_suite("heuristic config");
-  const int cfgs[] = {14, 15};
+  const int cfgs[] = {16, 17, 18, 19};
   for (int c : cfgs) { char tag[32]; snprintf(tag, 32, "forced cfg %d", c); g_gemm_force_cfg = c; correctness_suite(tag); }
   g_gemm_force_cfg = -1;
 
   if (argc > 1 && !strcmp(argv[1], "--time")) {
-    const int tc[] = {12, 14, 12, 14, 13, 15};
+    const int tc[] = {16, 18, 16, 18};
     for (int c : tc) {
       g_gemm_force_cfg = c;
       printf("---- timing, cfg %d (-1 heuristic, 6 = round-0 structure)\n", c);
