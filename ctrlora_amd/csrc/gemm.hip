@@ -1032,7 +1032,7 @@ int g_gemm_force_cfg = -1;   // probe / tuning hook: >= 0 forces a tile configur
 template <typename T>
 static int launch_t(const GemmParams& p, hipStream_t stream) {
   int cfg = g_gemm_force_cfg;
-  if (p.act == ACT_GEGLU && cfg != 2 && cfg != 12 && cfg != 8 && cfg != 10 && cfg != 14 && cfg != 16 && cfg != 18) cfg = -2;   // needs a 2 x 80-column wave pair
+  if (p.act == ACT_GEGLU && cfg != 2 && cfg != 12 && cfg != 8 && cfg != 10 && cfg != 14 && cfg != 16 && cfg != 18 && cfg != 20) cfg = -2;   // needs a 2 x 80-column wave pair
   if (cfg < 0) {
     // v2 (64-byte substeps, 4 waves) choices
     if (p.M <= 64 || p.N <= 64) cfg = 0;
@@ -1049,9 +1049,12 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
       const long t256 = (long)((p.M + 255) / 256) * ((p.N + bn - 1) / bn);
       const int steps = ((p.mode == GEMM_LINEAR ? 1 : 9) * p.K1 + p.K2) / kps;
       const long need = (256 + t256 - 1) / t256;   // split factor that fills 256 CUs
-      if (t256 >= 200 || (g_ws && steps >= 8 * need)) cfg = 16 + (bn == 160 ? 0 : 1);   // ping-pong schedule
+      if (t256 >= 200 || (g_ws && steps >= 8 * need && steps > 48))
+        cfg = 16 + (bn == 160 ? 0 : 1);   // ping-pong schedule, 256-row tiles (split-K for the deep-K convs)
+      else if (steps <= 48 && (steps >= 16 || (long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn) >= 128))
+        cfg = 20 + (bn == 160 ? 0 : 1);   // mid-size linears (16x16 / 32x32 levels): 128-row tiles fill the chip
     }
-    if (p.act == ACT_GEGLU && cfg != 16) cfg = 2;
+    if (p.act == ACT_GEGLU && cfg != 16 && cfg != 20) cfg = 2;
   }
   switch (cfg) {
     case 0: return launch_cfg<T, 64, 64, 2, 2, 1, 4>(p, stream);
@@ -1091,6 +1094,12 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
       if (p.K1 % kps || p.K2 % kps || (p.mode != GEMM_LINEAR && p.K2))
         return launch_cfg<T, 128, 128, 2, 2, 2, 4>(p, stream);
       return cfg == 18 ? launch_fl<T, 256, 160, 4, 2, 3, 4>(p, stream) : launch_fl<T, 256, 128, 4, 2, 3, 4>(p, stream);
+    }
+    case 20: case 21: {   // ping-pong on 128-row tiles (8 waves of 32 x 80 / 32 x 64): mid-size products
+      const int kps = 128 / (int)sizeof(T);
+      if (p.K1 % kps || p.K2 % kps || (p.mode != GEMM_LINEAR && p.K2))
+        return launch_cfg<T, 128, 128, 2, 2, 2, 4>(p, stream);
+      return cfg == 20 ? launch_fl<T, 128, 160, 4, 2, 3, 3>(p, stream) : launch_fl<T, 128, 128, 4, 2, 3, 3>(p, stream);
     }
     case 10: case 11: {   // 128-row tiles, 4 waves, 2-slot ring: two workgroups per CU (small-K / mid-size products)
       const int kps = 128 / (int)sizeof(T);

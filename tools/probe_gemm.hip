@@ -319,12 +319,12 @@ int main(int argc, char** argv) {
   wgrad_suite(argc > 1 && !strcmp(argv[1], "--time"));
   if (argc > 2 && !strcmp(argv[2], "--wgrad-only")) return g_fail ? 1 : 0;
   g_gemm_force_cfg = -1; correctness_suite("heuristic config");
-  const int cfgs[] = {16, 17, 18, 19};
+  const int cfgs[] = {16, 17, 20, 21};
   for (int c : cfgs) { char tag[32]; snprintf(tag, 32, "forced cfg %d", c); g_gemm_force_cfg = c; correctness_suite(tag); }
   g_gemm_force_cfg = -1;
 
   if (argc > 1 && !strcmp(argv[1], "--time")) {
-    const int tc[] = {16, 18, 16, 18};
+    const int tc[] = {-1, -1};
     for (int c : tc) {
       g_gemm_force_cfg = c;
       printf("---- timing, cfg %d (-1 heuristic, 6 = round-0 structure)\n", c);
