@@ -2,6 +2,7 @@
 // All activations are token-major [rows, C] with an explicit row stride so they
 // can address column slices of wider buffers (decoder concat, fused QKV).
 #include "elementwise.h"
+#include "gemm.h"
 
 namespace cl {
 
@@ -314,7 +315,10 @@ __global__ void pool2x2_kernel(const T* __restrict__ in, long ldi, T* __restrict
 // broadcast, openaimodel.py:272, and bias gradients of the zero convs)
 template <typename T>
 __global__ void colsum_kernel(const T* __restrict__ in, long ldi, float* __restrict__ out, long ldo, int HW, int C,
-                              int ppc, float scale) {
+                              int ppc, float scale, float* __restrict__ partial) {
+  // partial != nullptr: the block's column sums go to partial[(b * nchunk + chunk) * C + c] and a second kernel
+  // adds them up (one writer per column: deterministic, and no same-cache-line atomics -- 512 blocks x 320
+  // atomics onto ten cache lines cost ~25 us, five times the 21 MB read itself)
   __shared__ float red[256 * 8];
   const int C8 = C / 8;
   const int b = blockIdx.y, p0 = blockIdx.x * ppc, p1 = min(HW, p0 + ppc);
@@ -329,9 +333,20 @@ __global__ void colsum_kernel(const T* __restrict__ in, long ldi, float* __restr
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = 0.f;
     if (live && v < C8) {
-      for (int p = p0 + py; p < p1; p += PY) {
+      const T* src = in + ((long)b * HW) * ldi + v * 8;
+      int p = p0 + py;
+      for (; p + 3 * PY < p1; p += 4 * PY) {   // four independent loads in flight
+        float f0[8], f1[8], f2[8], f3[8];
+        load8(src + (long)p * ldi, f0);
+        load8(src + (long)(p + PY) * ldi, f1);
+        load8(src + (long)(p + 2 * PY) * ldi, f2);
+        load8(src + (long)(p + 3 * PY) * ldi, f3);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += (f0[e] + f1[e]) + (f2[e] + f3[e]);
+      }
+      for (; p < p1; p += PY) {
         float f[8];
-        load8(in + ((long)b * HW + p) * ldi + v * 8, f);
+        load8(src + (long)p * ldi, f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) s[e] += f[e];
       }
@@ -343,10 +358,36 @@ __global__ void colsum_kernel(const T* __restrict__ in, long ldi, float* __restr
       for (int k = 1; k < PY; ++k)
 #pragma unroll
         for (int e = 0; e < 8; ++e) s[e] += red[(k * VX + vx) * 8 + e];
+      if (partial) {
+        float* dst = partial + ((long)b * gridDim.x + blockIdx.x) * C + v * 8;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) atomicAdd(out + (long)b * ldo + v * 8 + e, s[e] * scale);
+        for (int e = 0; e < 8; ++e) dst[e] = s[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(out + (long)b * ldo + v * 8 + e, s[e] * scale);
+      }
     }
     __syncthreads();
+  }
+}
+
+// out[b][c] += scale * sum_k partial[(b * nchunk + k) * C + c]; 32 columns x 32 chunk lanes per workgroup
+__global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __restrict__ partial, int nchunk, int C,
+                                                             float* __restrict__ out, long ldo, float scale) {
+  __shared__ float red[1024];
+  const int b = blockIdx.y, cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float s = 0.f;
+  if (c < C)
+#pragma unroll 8
+    for (int k = kl; k < nchunk; k += 32) s += partial[((long)b * nchunk + k) * C + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (kl == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) t += red[k * 32 + cl];
+    out[(long)b * ldo + c] += scale * t;
   }
 }
 
@@ -477,8 +518,15 @@ int colsum(int dtype, const void* in, long ldi, float* out, long ldo, int B, int
   const int ppc = (HW + nchunk - 1) / nchunk;
   nchunk = (HW + ppc - 1) / ppc;
   dim3 grid(nchunk, B);
-  if (dtype == CL_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)in, ldi, out, ldo, HW, C, ppc, scale);
-  else hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, st, (const float*)in, ldi, out, ldo, HW, C, ppc, scale);
+  // block partials through the stream's registered scratch (cl_set_workspace) when there is one; otherwise
+  // fp32 atomics straight into out
+  void* wsp = nullptr; long wsb = 0;
+  gemm_get_workspace_for(st, &wsp, &wsb);
+  float* partial = (nchunk > 1 && wsp && (long)B * nchunk * C * 4 <= wsb) ? (float*)wsp : nullptr;
+  if (dtype == CL_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)in, ldi, out, ldo, HW, C, ppc, scale, partial);
+  else hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, st, (const float*)in, ldi, out, ldo, HW, C, ppc, scale, partial);
+  if (partial)
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 31) / 32, B), dim3(1024), 0, st, partial, nchunk, C, out, ldo, scale);
   CL_CHECK_LAUNCH(); return CL_OK;
 }
 int pack2d(int dtype, const float* in, long ldi, void* out, long ldo, long R, int C, int Cpad, hipStream_t st) {

@@ -56,6 +56,7 @@ int launch_wgrad_tn(const void* dy, long lddy, const void* x, long ldx, float* d
 struct WgradDesc { const void* dy; long lddy; const void* x; long ldx; float* dW; long lddw; int M, N, K; float alpha; };
 int launch_wgrad_tn_group(const WgradDesc* probs, int n, const void* zero_page, hipStream_t stream);
 extern int g_wgrad_blocks, g_wgrad_min_steps, g_wgrad_ring;
+extern int g_fl128_split_want, g_tiny_m_minsub;
 extern int g_gemm_force_cfg;   // tuning/probe hook (tile configuration override), -1 = heuristic
 
 }  // namespace cl

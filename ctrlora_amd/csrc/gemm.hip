@@ -938,7 +938,8 @@ static int launch_cfg(const GemmParams& p0, hipStream_t stream) {
     ws_for(stream, &wsp, &wsb);
     if (p.splitk <= 1 && tiles < 160 && ksub >= 32 && wsp) {
       sk = (int)((256 + tiles - 1) / tiles);
-      if (sk > ksub / 16) sk = ksub / 16;
+      const int minsub = p.M <= 64 ? g_tiny_m_minsub : 16;
+      if (sk > ksub / minsub) sk = ksub / minsub;
       if (sk > 16) sk = 16;
       while (sk > 1 && (long)sk * p.M * p.N * 4 > wsb) --sk;
       if (sk < 1) sk = 1;
@@ -1008,7 +1009,7 @@ static int launch_fl_mode(const GemmParams& p0, hipStream_t stream) {
   const long tiles = (long)tm * tn;
   const int steps = ((MODE == FL_LINEAR ? 1 : 9) * p.K1 + p.K2) / kps;
   float* slab;
-  pick_splitk(p, tiles, steps, R == 3 ? 256 : 512, 4, &slab, stream);
+  pick_splitk(p, tiles, steps, R == 3 ? (BM == 128 ? g_fl128_split_want : 256) : 512, 4, &slab, stream);
   hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * p.splitk)), dim3(NW * 64), SMEM, stream, p, tm, tn, slab);
   if (slab) {
     const long total = (long)p.M * (p.N / 8);
@@ -1024,10 +1025,12 @@ static int launch_fl(const GemmParams& p, hipStream_t stream) {
   if (p.mode == GEMM_LINEAR) return launch_fl_mode<T, BM, BN, WGM, WGN, FL_LINEAR, R, PRIO>(p, stream);
   if (p.K2) return CL_EINVAL;   // a second K segment exists for linear operands only
   if (p.mode == GEMM_CONV_S1) return launch_fl_mode<T, BM, BN, WGM, WGN, FL_CONV_S1, R, PRIO>(p, stream);
-  return launch_fl_mode<T, BM, BN, WGM, WGN, FL_CONV_ANY, R>(p, stream);
+  return launch_fl_mode<T, BM, BN, WGM, WGN, FL_CONV_ANY, R>(p, stream);   // ping-pong measured slower here (heavy address VALU in the L sections)
 }
 
 int g_gemm_force_cfg = -1;   // probe / tuning hook: >= 0 forces a tile configuration
+int g_fl128_split_want = 128;   // 128-row full-line tiles: split K while the grid is below this many workgroups
+int g_tiny_m_minsub = 8;        // fallback kernel, M <= 64: minimum 64-byte substeps per K split
 
 template <typename T>
 static int launch_t(const GemmParams& p, hipStream_t stream) {
@@ -1049,9 +1052,9 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
       const long t256 = (long)((p.M + 255) / 256) * ((p.N + bn - 1) / bn);
       const int steps = ((p.mode == GEMM_LINEAR ? 1 : 9) * p.K1 + p.K2) / kps;
       const long need = (256 + t256 - 1) / t256;   // split factor that fills 256 CUs
-      if (t256 >= 200 || (g_ws && steps >= 8 * need && steps > 48))
+      if (t256 >= 200 || (g_ws && steps >= 8 * need && (p.mode != GEMM_LINEAR || steps > 48)))
         cfg = 16 + (bn == 160 ? 0 : 1);   // ping-pong schedule, 256-row tiles (split-K for the deep-K convs)
-      else if (steps <= 48 && (steps >= 16 || (long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn) >= 128))
+      else if (p.mode == GEMM_LINEAR && steps <= 48 && (steps >= 16 || (long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn) >= 128))
         cfg = 20 + (bn == 160 ? 0 : 1);   // mid-size linears (16x16 / 32x32 levels): 128-row tiles fill the chip
     }
     if (p.act == ACT_GEGLU && cfg != 16 && cfg != 20) cfg = 2;

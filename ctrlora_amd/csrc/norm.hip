@@ -14,6 +14,7 @@
 // (attention.py:88-89,295; eps 1e-6, no SiLU), BasicTransformerBlock.norm1-3
 // (attention.py:263-265; eps 1e-5), UNetModel.out[0:2] (openaimodel.py:726-728).
 #include "norm.h"
+#include "gemm.h"
 
 namespace cl {
 
@@ -395,90 +396,143 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, lo
 
 // dx = rstd * (dyh - mean(dyh) - xh * mean(dyh * xh)),  dyh = dy * gamma ; optional (+ accum)
 // WG: dgamma += sum_rows dy * xh ; dbeta += sum_rows dy  (per-lane column sums -> LDS across the 4 waves
-// -> one fp32 atomic per column per workgroup)
-template <typename T, bool WG>
+// -> block partial row, or one fp32 atomic per column per workgroup)
+// NV = 16-byte vectors per lane (D <= 512 NV); RPI = rows per wave iteration, all kept in registers between
+// the statistics pass and the output pass.  A row is only D * 2 bytes per operand (40 of 64 lanes at D = 320),
+// so one row per wave leaves the kernel bound by the load -> reduce -> store latency chain; RPI rows in flight
+// per wave (4 / 2 / 1 at NV = 1 / 2 / 3, ~96 data registers each way) is what fills the memory pipeline.
+// A row past the end is clamped for its loads, contributes nothing and is not stored.
+template <typename T, bool WG, int NV, int RPI>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy,
                                                      long lddy, const T* __restrict__ accum, long ldacc,
                                                      T* __restrict__ dx, long lddx, int M, int D,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ stats,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ float red[WG ? 2 * LN_MAXV * 512 : 1];
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     float* __restrict__ partial) {
+  // per-wave column sums (plain 16-byte LDS stores; LDS float atomics measured ~20 us per workgroup here)
+  __shared__ __attribute__((aligned(16))) float red[WG ? 4 * 2 * NV * 512 : 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int D8 = D / 8;
-  float gsum[WG ? LN_MAXV : 1][8], bsum[WG ? LN_MAXV : 1][8];
+  float gsum[WG ? NV : 1][8], bsum[WG ? NV : 1][8];
   if (WG) {
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k)
+    for (int k = 0; k < NV; ++k)
 #pragma unroll
       for (int e = 0; e < 8; ++e) { gsum[k][e] = 0.f; bsum[k][e] = 0.f; }
-    for (int i = threadIdx.x; i < 2 * LN_MAXV * 512; i += 256) red[i] = 0.f;
   }
-  float gam[LN_MAXV][8];
+  float gam[NV][8];
 #pragma unroll
-  for (int k = 0; k < LN_MAXV; ++k) {
+  for (int k = 0; k < NV; ++k) {
     const int v = lane + 64 * k;
 #pragma unroll
     for (int e = 0; e < 8; ++e) gam[k][e] = v < D8 ? gamma[v * 8 + e] : 0.f;
   }
-  for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
-    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
-    float c1 = 0.f, c2 = 0.f;
-    // pass 1: row statistics of dyh (+ column sums); pass 2 re-reads the row (L1/L2 resident) to keep
-    // the register footprint small enough for >= 3 waves per SIMD
+  const long rstride = (long)gridDim.x * 4;
+  for (long row0 = (long)blockIdx.x * 4 + wave; row0 < M; row0 += RPI * rstride) {
+    long rows[RPI];
+    bool ok[RPI];
+    float mean[RPI], rstd[RPI], c1[RPI], c2[RPI];
+    float f[RPI][NV][8], d[RPI][NV][8], o[RPI][NV][8];
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
-      const int v = lane + 64 * k;
-      if (v < D8) {
-        float f[8], d[8];
-        load8(x + row * ldx + v * 8, f);
-        load8(dy + row * lddy + v * 8, d);
+    for (int r = 0; r < RPI; ++r) {
+      rows[r] = row0 + r * rstride;
+      ok[r] = rows[r] < M;
+      if (!ok[r]) rows[r] = row0;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float xh = (f[e] - mean) * rstd;
-          if (WG) { gsum[k][e] += d[e] * xh; bsum[k][e] += d[e]; }
-          const float dh = d[e] * gam[k][e];
-          c1 += dh; c2 += dh * xh;
+      for (int k = 0; k < NV; ++k) {
+        const int v = lane + 64 * k;
+        if (v < D8) {
+          load8(x + rows[r] * ldx + v * 8, f[r][k]);
+          load8(dy + rows[r] * lddy + v * 8, d[r][k]);
+          if (accum) load8(accum + rows[r] * ldacc + v * 8, o[r][k]);
+        }
+      }
+      mean[r] = stats[rows[r] * 2]; rstd[r] = stats[rows[r] * 2 + 1];
+      c1[r] = 0.f; c2[r] = 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < RPI; ++r) {
+      const float live = ok[r] ? 1.f : 0.f;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int v = lane + 64 * k;
+        if (v < D8) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float xh = (f[r][k][e] - mean[r]) * rstd[r];
+            const float de = d[r][k][e] * live;
+            if (WG) { gsum[k][e] += de * xh; bsum[k][e] += de; }
+            const float dh = de * gam[k][e];
+            c1[r] += dh; c2[r] += dh * xh;
+            f[r][k][e] = xh; d[r][k][e] = dh;
+          }
         }
       }
     }
-    c1 = wave_sum(c1) / D; c2 = wave_sum(c2) / D;
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
-      const int v = lane + 64 * k;
-      if (v < D8) {
-        float f[8], d[8], o[8];
-        load8(x + row * ldx + v * 8, f);
-        load8(dy + row * lddy + v * 8, d);
-        if (accum) load8(accum + row * ldacc + v * 8, o);
+    for (int r = 0; r < RPI; ++r) { c1[r] = wave_sum(c1[r]) / D; c2[r] = wave_sum(c2[r]) / D; }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float xh = (f[e] - mean) * rstd;
-          const float r = rstd * (d[e] * gam[k][e] - c1 - xh * c2);
-          o[e] = accum ? o[e] + r : r;
+    for (int r = 0; r < RPI; ++r) {
+      if (!ok[r]) continue;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int v = lane + 64 * k;
+        if (v < D8) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float g = rstd[r] * (d[r][k][e] - c1[r] - f[r][k][e] * c2[r]);
+            o[r][k][e] = accum ? o[r][k][e] + g : g;
+          }
+          store8(dx + rows[r] * lddx + v * 8, o[r][k]);
         }
-        store8(dx + row * lddx + v * 8, o);
       }
     }
   }
   if (WG) {
-    __syncthreads();
+    constexpr int WS = 2 * NV * 512;   // floats per wave: [dgamma NV*512 | dbeta NV*512]
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
+    for (int k = 0; k < NV; ++k) {
       const int v = lane + 64 * k;
       if (v < D8) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          atomicAdd(&red[v * 8 + e], gsum[k][e]);
-          atomicAdd(&red[LN_MAXV * 512 + v * 8 + e], bsum[k][e]);
-        }
+        float4* pg = reinterpret_cast<float4*>(&red[wave * WS + v * 8]);
+        float4* pb = reinterpret_cast<float4*>(&red[wave * WS + NV * 512 + v * 8]);
+        pg[0] = make_float4(gsum[k][0], gsum[k][1], gsum[k][2], gsum[k][3]);
+        pg[1] = make_float4(gsum[k][4], gsum[k][5], gsum[k][6], gsum[k][7]);
+        pb[0] = make_float4(bsum[k][0], bsum[k][1], bsum[k][2], bsum[k][3]);
+        pb[1] = make_float4(bsum[k][4], bsum[k][5], bsum[k][6], bsum[k][7]);
       }
     }
     __syncthreads();
+    float* dst = partial ? partial + (long)blockIdx.x * 2 * D : nullptr;
     for (int c = threadIdx.x; c < D; c += 256) {
-      atomicAdd(dgamma + c, red[c]);
-      atomicAdd(dbeta + c, red[LN_MAXV * 512 + c]);
+      const float g = (red[c] + red[WS + c]) + (red[2 * WS + c] + red[3 * WS + c]);
+      const float b = (red[NV * 512 + c] + red[WS + NV * 512 + c]) +
+                      (red[2 * WS + NV * 512 + c] + red[3 * WS + NV * 512 + c]);
+      if (dst) { dst[c] = g; dst[D + c] = b; }   // block partials [grid][2 D]; ln_bwd_finish_kernel adds them up
+      else { atomicAdd(dgamma + c, g); atomicAdd(dbeta + c, b); }
     }
+  }
+}
+
+// dgamma[c] += sum_blocks partial[blk][c] ; dbeta[c] += sum_blocks partial[blk][D + c]
+// 32 columns x 32 block lanes per 1024-thread workgroup (few columns: the depth of each lane's loop is what counts)
+__global__ __launch_bounds__(1024) void ln_bwd_finish_kernel(const float* __restrict__ partial, int nblk, int D,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float red[1024];
+  const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;   // column of the [2 D] partial row
+  float s = 0.f;
+  if (c < 2 * D)
+#pragma unroll 8
+    for (int k = kl; k < nblk; k += 32) s += partial[(long)k * 2 * D + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (kl == 0 && c < 2 * D) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) t += red[k * 32 + cl];
+    if (c < D) dgamma[c] += t; else dbeta[c - D] += t;
   }
 }
 
@@ -502,16 +556,36 @@ int ln_fwd(const LnArgs& a, int dtype, hipStream_t st) {
 int ln_bwd(const LnBwdArgs& a, int dtype, hipStream_t st) {
   if (a.D % 8 || a.D > 64 * LN_MAXV * 8 || a.ldx % 8 || a.lddy % 8 || a.lddx % 8) return CL_EINVAL;
   if ((a.dgamma == nullptr) != (a.dbeta == nullptr)) return CL_EINVAL;
-  int grid = (a.M + 3) / 4;
+  const int rpi = a.D <= 512 ? 4 : a.D <= 1024 ? 2 : 1;   // rows per wave iteration (see ln_bwd_kernel)
+  int grid = (a.M + 4 * rpi - 1) / (4 * rpi);
   if (grid > 2048) grid = 2048;
-  if (a.dgamma && grid > 512) grid = 512;  // bounds the same-address atomics per column
-#define LN_BWD_LAUNCH(TT, WG)                                                                                   \
-  hipLaunchKernelGGL((ln_bwd_kernel<TT, WG>), dim3(grid), dim3(256), 0, st, (const TT*)a.x, a.ldx,             \
+  float* partial = nullptr;
+  if (a.dgamma) {
+    // column sums: block partials through the stream's registered scratch + a finishing kernel when there is
+    // one (grid 1024); otherwise fp32 atomics with the grid bounded to 512 (same-address contention)
+    void* wsp = nullptr; long wsb = 0;
+    gemm_get_workspace_for(st, &wsp, &wsb);
+    if (grid > 1024) grid = 1024;
+    if (wsp && (long)grid * 2 * a.D * 4 <= wsb) partial = (float*)wsp;
+    else if (grid > 512) grid = 512;
+  }
+#define LN_BWD_LAUNCH2(TT, WG, NV, RPI)                                                                         \
+  hipLaunchKernelGGL((ln_bwd_kernel<TT, WG, NV, RPI>), dim3(grid), dim3(256), 0, st, (const TT*)a.x, a.ldx,     \
                      (const TT*)a.dy, a.lddy, (const TT*)a.accum, a.ldacc, (TT*)a.dx, a.lddx, a.M, a.D, a.gamma, \
-                     a.stats, a.dgamma, a.dbeta)
+                     a.stats, a.dgamma, a.dbeta, partial)
+#define LN_BWD_LAUNCH(TT, WG)                                                                                   \
+  do {                                                                                                          \
+    if (a.D <= 512) LN_BWD_LAUNCH2(TT, WG, 1, 4);                                                               \
+    else if (a.D <= 1024) LN_BWD_LAUNCH2(TT, WG, 2, 2);                                                         \
+    else LN_BWD_LAUNCH2(TT, WG, 3, 1);                                                                          \
+  } while (0)
   if (dtype == CL_BF16) { if (a.dgamma) LN_BWD_LAUNCH(bf16_t, true); else LN_BWD_LAUNCH(bf16_t, false); }
   else { if (a.dgamma) LN_BWD_LAUNCH(float, true); else LN_BWD_LAUNCH(float, false); }
+#undef LN_BWD_LAUNCH2
 #undef LN_BWD_LAUNCH
+  if (partial)
+    hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((2 * a.D + 31) / 32), dim3(1024), 0, st, partial, grid, a.D,
+                       a.dgamma, a.dbeta);
   CL_CHECK_LAUNCH();
   return CL_OK;
 }

@@ -137,6 +137,50 @@ def test_elementwise_and_layout_kernels(dtype):
     assert rel_l2(dst.float().cpu(), ref) < tol
 
 
+@pytest.mark.parametrize("with_ws", [False, True])
+def test_column_sum_kernels_both_reduction_paths(with_ws):
+    """LayerNorm dgamma/dbeta and cl_colsum reduce their per-block column sums either through the registered
+    scratch + a finishing kernel (with_ws) or with fp32 atomics (no scratch registered); both must match torch."""
+    _need_gpu()
+    from ctrlora_amd import hip
+    dev = "cuda"
+    L = hip.lib()
+    saved = hip._workspace
+    try:
+        if with_ws:
+            hip.ensure_workspace(dev)
+        else:
+            hip._chk(L.cl_set_workspace(None, 0), "cl_set_workspace")
+        g = torch.Generator().manual_seed(77)
+        for M, D in [(5000, 320), (4100, 640), (900, 1280)]:
+            x = (torch.randn(M, D, generator=g) * 2 + 0.5).bfloat16(); dy = torch.randn(M, D, generator=g).bfloat16()
+            gamma = 1 + 0.2 * torch.randn(D, generator=g); beta = 0.2 * torch.randn(D, generator=g)
+            xr = x.double().requires_grad_(True); gr = gamma.double().requires_grad_(True)
+            br = beta.double().requires_grad_(True)
+            torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-5).backward(dy.double())
+            xd, dyd = x.to(dev), dy.to(dev)
+            y = torch.empty_like(xd); dx = torch.empty_like(xd); stats = torch.empty(M, 2, device=dev)
+            dgam, dbet = torch.ones(D, device=dev), torch.ones(D, device=dev)      # accumulate onto existing values
+            hip.layernorm_fwd(xd, y, gamma.to(dev), beta.to(dev), 1e-5, stats)
+            hip.layernorm_bwd(xd, dyd, dx, gamma.to(dev), stats, dgamma=dgam, dbeta=dbet)
+            assert rel_l2(dx.float().cpu(), xr.grad) < 1.2e-2
+            assert rel_l2(dgam.cpu() - 1, gr.grad) < 1e-2
+            assert rel_l2(dbet.cpu() - 1, br.grad) < 1e-2
+        for B, HW, C in [(1, 5000, 320), (3, 700, 1280), (2, 50, 64)]:
+            yv = torch.randn(B * HW, C, generator=g).bfloat16().to(dev)
+            cs = torch.ones(B, C, device=dev)
+            hip.colsum(yv, cs, B, HW, 0.5)
+            ref = 1 + 0.5 * yv.float().cpu().double().reshape(B, HW, C).sum(1)
+            assert rel_l2(cs.cpu(), ref) < 1e-5
+    finally:   # restore the registration exactly as it was
+        if saved is not None:
+            hip._workspace = saved
+            hip._chk(L.cl_set_workspace(saved.data_ptr(), hip.WORKSPACE_BYTES), "cl_set_workspace")
+        else:
+            hip._workspace = None
+            hip._chk(L.cl_set_workspace(None, 0), "cl_set_workspace")
+
+
 def test_timestep_embedding_qsample_mse_ddim_adamw_match_oracle():
     _need_gpu()
     from ctrlora_amd import hip

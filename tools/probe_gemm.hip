@@ -178,6 +178,8 @@ static void time_case(const char* name, int dtype, int mode, int M, int N, int K
   GemmParams p{}; p.A1 = A.d; p.lda1 = K1; p.K1 = K1; p.W1 = Wt.d; p.ldw1 = taps * K1; p.M = M; p.N = N; p.mode = mode;
   if (K2) { p.A2 = A2.d; p.lda2 = K2; p.K2 = K2; p.W2 = W2.d; p.ldw2 = K2; }
   p.B = B; p.Hin = H; p.Win = W; p.Hout = H; p.Wout = W; p.zero_page = g_zero; p.alpha = 1.f; p.C = C.d; p.ldc = N; p.splitk = 1; p.act = g_probe_act;
+  if (mode == GEMM_CONV_UP2) { p.Hout = 2 * H; p.Wout = 2 * W; }
+  if (mode == GEMM_CONV_S2) { p.Hout = H / 2; p.Wout = W / 2; }
   hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   for (int i = 0; i < 3; ++i) launch_gemm(p, dtype, 0);
   HIPCHK(hipDeviceSynchronize());
@@ -316,6 +318,27 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  if (argc > 1 && !strcmp(argv[1], "--knobs")) {   // split-K tuning knobs on the shapes they affect
+    for (int want : {256, 128, 256, 128}) {
+      g_fl128_split_want = want;
+      printf("---- g_fl128_split_want = %d\n", want);
+      time_case("gemm bf16 2048x1280x1280", CL_BF16, GEMM_LINEAR, 2048, 1280, 1280, 0, 0, 0);
+      time_case("gemm bf16 2048x1280x1280+r128", CL_BF16, GEMM_LINEAR, 2048, 1280, 1280, 0, 0, 0, 128);
+      time_case("gemm bf16 512x1280x1280", CL_BF16, GEMM_LINEAR, 512, 1280, 1280, 0, 0, 0);
+      time_case("gemm bf16 2048x128x1280", CL_BF16, GEMM_LINEAR, 2048, 128, 1280, 0, 0, 0);
+      time_case("gemm bf16 8192x640x640", CL_BF16, GEMM_LINEAR, 8192, 640, 640, 0, 0, 0);
+    }
+    g_fl128_split_want = 256;
+    for (int ms : {16, 8, 4, 16, 8, 4}) {
+      g_tiny_m_minsub = ms;
+      printf("---- g_tiny_m_minsub = %d\n", ms);
+      time_case("gemm bf16 8x128x1280", CL_BF16, GEMM_LINEAR, 8, 128, 1280, 0, 0, 0);
+      time_case("gemm bf16 8x1280x1280", CL_BF16, GEMM_LINEAR, 8, 1280, 1280, 0, 0, 0);
+      time_case("gemm bf16 8x1280x1280+r128", CL_BF16, GEMM_LINEAR, 8, 1280, 1280, 0, 0, 0, 128);
+      time_case("gemm bf16 8x640x1280", CL_BF16, GEMM_LINEAR, 8, 640, 1280, 0, 0, 0);
+    }
+    return 0;
+  }
   wgrad_suite(argc > 1 && !strcmp(argv[1], "--time"));
   if (argc > 2 && !strcmp(argv[2], "--wgrad-only")) return g_fail ? 1 : 0;
   g_gemm_force_cfg = -1; correctness_suite("heuristic config");
@@ -348,6 +371,8 @@ int main(int argc, char** argv) {
       time_case("conv bf16 1280->1280 @16^2 B8", CL_BF16, GEMM_CONV_S1, 8 * 16 * 16, 1280, 1280, 8, 16, 16);
       time_case("conv bf16 1280->1280 @8^2 B8", CL_BF16, GEMM_CONV_S1, 8 * 8 * 8, 1280, 1280, 8, 8, 8);
       time_case("conv bf16 2560->1280 @16^2 B8", CL_BF16, GEMM_CONV_S1, 8 * 16 * 16, 1280, 2560, 8, 16, 16);
+      time_case("conv up2 bf16 640->640 32^2->64^2 B8", CL_BF16, GEMM_CONV_UP2, 8 * 64 * 64, 640, 640, 8, 32, 32);
+      time_case("conv s2 bf16 320->320 64^2->32^2 B8", CL_BF16, GEMM_CONV_S2, 8 * 32 * 32, 320, 320, 8, 64, 64);
     }
     g_gemm_force_cfg = -1;
     time_case("gemm f32 4096x1280x1280", CL_F32, GEMM_LINEAR, 4096, 1280, 1280, 0, 0, 0);
