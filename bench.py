@@ -266,7 +266,7 @@ def main():
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                 "basis": f"{tf_img} TFLOP/image algorithmic (SURVEY.md 8d), per GPU"}
         roof["whole_step"] = {"achieved": roof["achieved"], "frac": roof["frac"], "basis": roof.pop("basis")}
-        if world == 1 and not args.tiny and args.dtype == "bf16":
+        if not args.tiny and args.dtype == "bf16":   # rank 0 only; no collective inside
             dk = conv_kernel_probe(device, dtype)
             # contract fields describe the dominant kernel; the whole-step figure stays alongside
             roof.update(achieved=dk["achieved"], frac=dk["frac"], traffic=dk["traffic"], kernel=dk["kernel"],

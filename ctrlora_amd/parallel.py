@@ -65,3 +65,48 @@ class GradAllReduce:
         for w in self._pending:
             w.wait()
         self._pending.clear()
+
+
+class BankedGradAllReduce:
+    """Gradient exchange for multi-task pre-training under data parallelism.
+
+    The reference's `BatchSchedulerSampler` (datasets/multi_task_scheduler.py:59) draws the task order from an
+    unseeded per-rank numpy RNG, so in one step different ranks may train different tasks: each rank touches the
+    shared (base-ControlNet) gradients and ONE LoRA bank.  Lightning DDP then averages every parameter over the
+    world size, ranks that did not use a bank contributing zeros.  Restated here without moving dead bytes:
+
+      * `shared`: flat gradient buffers every rank produces (all-reduced every step);
+      * `banks[task]`: one flat gradient buffer per task bank; a small MAX all-reduce of the per-rank "used"
+        mask tells every rank which banks are live anywhere this step, and only those are all-reduced (a rank
+        that did not use a live bank contributes zeros).  With T tasks and N ranks at most min(T, N) banks move
+        instead of T.
+
+    The result in every buffer is the SUM over ranks; averaging (1 / world_size, as DDP does) is left to the
+    optimizer's `grad_scale`, like `GradAllReduce`.  Returns the list of tasks whose banks were exchanged.
+    """
+
+    def __init__(self, shared, banks, group=None):
+        self.group = group
+        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.shared = list(shared)
+        self.tasks = list(banks.keys())
+        self.banks = dict(banks)
+
+    @torch.no_grad()
+    def exchange(self, used_tasks) -> List[str]:
+        used = set(used_tasks)
+        assert used <= set(self.tasks), f"unknown task(s) {sorted(used - set(self.tasks))}"
+        if self.world_size == 1:
+            return [t for t in self.tasks if t in used]
+        ref = self.shared[0] if self.shared else next(iter(self.banks.values()))
+        mask = torch.tensor([1 if t in used else 0 for t in self.tasks], dtype=torch.int32, device=ref.device)
+        dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)
+        live = [t for t, m in zip(self.tasks, mask.tolist()) if m]
+        work = [dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for buf in self.shared]
+        for t in live:
+            if t not in used:
+                self.banks[t].zero_()       # this rank did not train the bank: zero contribution
+            work.append(dist.all_reduce(self.banks[t], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for w in work:
+            w.wait()
+        return live

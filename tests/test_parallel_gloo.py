@@ -89,3 +89,55 @@ def test_grad_allreduce_two_ranks_gloo():
     first = [r for r in res if r[2] == min(x[2] for x in res)]
     assert first[0][2] >= 2, "bucketing should have produced more than one collective"
     assert first[0][3] == n * 4, "every gradient element is exchanged exactly once per step"
+
+
+# ------------------------------------------------------------------ multi-task pre-training exchange (f3)
+
+def _bank_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ctrlora_amd.parallel import BankedGradAllReduce
+    try:
+        tasks = ["hed", "canny", "depth"]
+        mk = lambda seed, n: torch.randn(n, generator=torch.Generator().manual_seed(seed))
+        shared = [mk(10 + rank, 300), mk(20 + rank, 50)]
+        banks = {t: mk(100 * (i + 1) + rank, 120) for i, t in enumerate(tasks)}
+        stale = {t: b.clone() for t, b in banks.items()}
+        ex = BankedGradAllReduce(shared, banks)
+        # step 1: the ranks train DIFFERENT tasks (rank 0 -> hed, rank 1 -> depth); canny is idle everywhere
+        mine = "hed" if rank == 0 else "depth"
+        live = ex.exchange([mine])
+        ok = live == ["hed", "depth"]
+        ok &= all(torch.allclose(s, mk(10 * (j + 1), s.numel()) + mk(10 * (j + 1) + 1, s.numel()), atol=1e-6)
+                  for j, s in enumerate(shared))
+        # a live bank = the owner's gradient + zeros from the other rank (DDP: unused parameter -> zero contribution)
+        ok &= torch.allclose(banks["hed"], mk(100, 120), atol=1e-6)
+        ok &= torch.allclose(banks["depth"], mk(301, 120), atol=1e-6)
+        ok &= torch.equal(banks["canny"], stale["canny"])          # idle bank: not touched, not communicated
+        # step 2: both ranks train the same task -> plain sum
+        banks["canny"].copy_(mk(200 + rank, 120))
+        live2 = ex.exchange(["canny"])
+        ok &= live2 == ["canny"] and torch.allclose(banks["canny"], mk(200, 120) + mk(201, 120), atol=1e-6)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_banked_grad_exchange_two_ranks_different_tasks_gloo():
+    """under the reference's per-rank task order two ranks may train different LoRA banks in one
+    step; every bank that is live anywhere is summed over ranks with zero contribution from non-users, idle
+    banks do not move."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
