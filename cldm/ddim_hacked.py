@@ -10,6 +10,8 @@ What changes underneath, not in the results:
   * schedule tables are computed exactly as the reference does (fp64 numpy / fp32 torch on the host) --
     index and timestep bookkeeping is bit-exact.
 """
+import contextlib
+
 import numpy as np
 import torch
 
@@ -88,13 +90,16 @@ class DDIMSampler(object):
         size = (batch_size, C, H, W)
         if verbose:
             print(f"Data shape for DDIM sampling is {size}, eta {eta}")
-        return self.ddim_sampling(conditioning, size, callback=callback, img_callback=img_callback,
-                                  quantize_denoised=quantize_x0, mask=mask, x0=x0, ddim_use_original_steps=False,
-                                  noise_dropout=noise_dropout, temperature=temperature,
-                                  score_corrector=score_corrector, corrector_kwargs=corrector_kwargs, x_T=x_T,
-                                  log_every_t=log_every_t, unconditional_guidance_scale=unconditional_guidance_scale,
-                                  unconditional_conditioning=unconditional_conditioning,
-                                  dynamic_threshold=dynamic_threshold, ucg_schedule=ucg_schedule)
+        # condition images do not change during a run: their VAE encode is done once (ControlLDM.hint_cache)
+        scope = getattr(self.model, "hint_cache", None)
+        with (scope() if callable(scope) else contextlib.nullcontext()):
+            return self.ddim_sampling(conditioning, size, callback=callback, img_callback=img_callback,
+                                      quantize_denoised=quantize_x0, mask=mask, x0=x0, ddim_use_original_steps=False,
+                                      noise_dropout=noise_dropout, temperature=temperature,
+                                      score_corrector=score_corrector, corrector_kwargs=corrector_kwargs, x_T=x_T,
+                                      log_every_t=log_every_t, unconditional_guidance_scale=unconditional_guidance_scale,
+                                      unconditional_conditioning=unconditional_conditioning,
+                                      dynamic_threshold=dynamic_threshold, ucg_schedule=ucg_schedule)
 
     @torch.no_grad()
     def ddim_sampling(self, cond, shape, x_T=None, ddim_use_original_steps=False, callback=None, timesteps=None,

@@ -202,3 +202,60 @@ def test_batch_scheduler_batches_are_single_task():
         assert len({task_of(i) for i in idx[b:b + 3]}) == 1
     # the largest task is covered at least once per epoch
     assert {i for i in idx if task_of(i) == 0} == set(range(11))
+
+
+# ------------------------------------------------------------------ f1 (minimum): hint encode leaves the DDIM loop
+
+def test_hint_posterior_is_encoded_once_per_sampling_scope_and_resampled_every_call():
+    """the reference VAE-encodes the condition image in EVERY apply_model call (2 x S per
+    sampling run).  Inside ControlLDM.hint_cache() the encoder runs once per image, while each call still draws
+    its own posterior sample (same distribution as the reference); outside a scope nothing is cached."""
+    import yaml
+    from ldm.util import instantiate_from_config
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "inference", "ctrlora_sd15_rank128_2loras.yaml")))["model"]
+    p = cfg["params"]
+    p["control_stage_config"]["params"] = tiny_control_params(dict(lora_rank=32, lora_num=2))
+    un = dict(p["unet_config"]["params"]); un.update(model_channels=64, context_dim=96)
+    p["unet_config"]["params"] = un
+    p["first_stage_config"] = {"target": "torch.nn.Identity"}
+    p["cond_stage_config"] = {"target": "torch.nn.Identity"}
+    model = instantiate_from_config(cfg).eval()
+
+    class Posterior:
+        def __init__(self, mean):
+            self.mean = mean
+
+        def sample(self):
+            return self.mean + 0.5 * torch.randn_like(self.mean)
+
+    class CountingVAE(torch.nn.Module):
+        calls = 0
+
+        def encode(self, x):
+            CountingVAE.calls += 1
+            return Posterior(torch.nn.functional.avg_pool2d(x, 8)[:, :1].repeat(1, 4, 1, 1))
+
+    model.first_stage_model = CountingVAE()
+    img_a, img_b = torch.rand(2, 3, 64, 64), torch.rand(2, 3, 64, 64)
+    cond_a, unc_a = {"c_concat": [img_a]}, {"c_concat": [img_a]}      # api.py: cond / un_cond share the image tensor
+    cond_b = {"c_concat": [img_b]}
+    lat4 = {"c_concat": [torch.randn(2, 4, 8, 8)]}
+    # no scope: the reference behaviour, one encode per call
+    model._hint_latent(cond_a); model._hint_latent(cond_a)
+    assert CountingVAE.calls == 2
+    CountingVAE.calls = 0
+    with model.hint_cache():
+        zs = [model._hint_latent(c) for c in (cond_a, unc_a, cond_b, cond_a, unc_a, cond_b)]
+        assert CountingVAE.calls == 2                                   # one per distinct image
+        assert zs[0].shape == (2, 4, 8, 8)
+        assert not torch.equal(zs[0], zs[3])                            # fresh posterior sample every call
+        mean_a = model.scale_factor * torch.nn.functional.avg_pool2d(img_a, 8)[:, :1].repeat(1, 4, 1, 1)
+        assert float((torch.stack([model._hint_latent(cond_a) for _ in range(200)]).mean(0) - mean_a).abs().max()) < 0.05
+        assert model._hint_latent(lat4) is not None and CountingVAE.calls == 2   # latents pass through
+        with model.hint_cache():                                        # nested scopes share the cache
+            model._hint_latent(cond_b)
+            assert CountingVAE.calls == 2
+        assert "_hint_cache" in model.__dict__
+    assert "_hint_cache" not in model.__dict__
+    model._hint_latent(cond_a)
+    assert CountingVAE.calls == 3
