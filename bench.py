@@ -171,6 +171,9 @@ def main():
     ap.add_argument("--ddim-only", action="store_true", help="profiling aid: run only the DDIM leg")
     ap.add_argument("--force-split-graphs", action="store_true",
                     help="test aid: use the multi-rank structure (graph A | all-reduce | graph B) even with one rank")
+    ap.add_argument("--probe-only", action="store_true",
+                    help="profiling aid: run only the dominant-kernel probe (the rocprofv3 --stats summary of this "
+                         "command, profiles/r01_dominant_kernel_stats.csv, is what roofline.ms_per_launch is checked against)")
     ap.add_argument("--tiny", action="store_true", help="debug: narrow model")
     args = ap.parse_args()
 
@@ -186,6 +189,9 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     if args.ddim_only:
         print(json.dumps(ddim_bench(device, dtype, tiny=args.tiny)))
+        return
+    if args.probe_only:
+        print(json.dumps(conv_kernel_probe(device, dtype, iters=200)))
         return
 
     model = build_model(f"ctrlora_finetune_sd15_rank{args.rank_lora}.yaml", 0, tiny=args.tiny).to(device).train()

@@ -22,7 +22,32 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
 sys.dont_write_bytecode = True
-sys.path.insert(0, ROOT)
+
+
+def use_reference_packages():
+    """Make `import cldm / ldm / datasets` resolve to the REFERENCE and `import oracle` to this repo.
+
+    The reference's cldm/ and ldm/ have no __init__.py (namespace packages); this repo's mirror has regular
+    packages of the same names, and a regular package ANYWHERE on sys.path beats a namespace portion found
+    earlier.  So the repo root must not be on sys.path at all while the reference is imported: it is removed
+    (with '' / cwd entries pointing at it), already-imported mirror modules are purged, and `oracle` -- the only
+    repo package the generators need -- is registered by file location."""
+    import importlib.util
+    root = os.path.realpath(ROOT)
+    sys.path[:] = [p for p in sys.path if os.path.realpath(p or os.getcwd()) != root]
+    for name in [m for m in sys.modules if m.split(".")[0] in ("cldm", "ldm", "datasets", "scripts", "api")]:
+        del sys.modules[name]
+    sys.path.insert(0, REF)
+    if "oracle" not in sys.modules:
+        spec = importlib.util.spec_from_file_location("oracle", os.path.join(ROOT, "oracle", "__init__.py"),
+                                                      submodule_search_locations=[os.path.join(ROOT, "oracle")])
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules["oracle"] = mod
+        spec.loader.exec_module(mod)
+    import cldm
+    import ldm
+    for pkg in (cldm, ldm):
+        assert all(os.path.realpath(p).startswith(REF) for p in pkg.__path__), (pkg.__name__, list(pkg.__path__))
 
 
 def install_stubs():
@@ -242,8 +267,8 @@ def gen_lora_golden():
 if __name__ == "__main__":
     assert os.path.isdir(REF), "run in the build container (needs /root/reference)"
     install_stubs()
-    sys.path.insert(0, REF)
     os.chdir("/tmp")
+    use_reference_packages()
     from oracle import arch
     gen_lora_golden()
     gen_schedule_golden()

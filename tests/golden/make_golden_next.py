@@ -23,8 +23,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
 sys.dont_write_bytecode = True
-sys.path.insert(0, HERE)
-sys.path.insert(0, ROOT)
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)      # make_golden helpers; the repo root is deliberately NOT added (see use_reference_packages)
 
 
 def key_tensor(key: str, shape, salt: str = "") -> torch.Tensor:
@@ -160,14 +160,93 @@ def gen_sampler_golden(out):
     print("[golden-next] sampler:", {k: len(v["idx"]) for k, v in res.items()})
 
 
+def gen_variant_golden(out):
+    """Reference outputs for the apply_model variants the fine-tune goldens do not reach (pins the oracle's
+    apply_model_multi / only_mid_control / pre-train task switching):
+      * ControlInferenceLDM, 2 LoRA banks, lora_weights (0.3, 0.7), non-trivial control_scales
+        (cldm/cldm_ctrlora_inference.py:156-178), banks filled through the api.CtrLoRA load sequence;
+      * ControlFinetuneLDM with only_mid_control=True (cldm/cldm.py:34-41);
+      * ControlPretrainLDM.apply_model with cond['task'] switching between two banks (cldm_ctrlora_pretrain.py:95-111).
+    Weights are oracle/arch.py key-addressed draws, inputs tests/golden/make_golden.py:inputs_for."""
+    from ldm.util import instantiate_from_config
+    from make_golden import inputs_for, ref_kwargs
+    from oracle import arch
+    cfg = arch.TINY
+    check_key = lambda k: 'lora_layer' in k or 'zero_convs' in k or 'middle_block_out' in k or 'norm' in k
+
+    def ldm(target_ldm, target_cn, cn_extra, drop=()):
+        cn = ref_kwargs(cfg, True)
+        for d in drop:
+            cn.pop(d)
+        cn.update(cn_extra)
+        conf = dict(target=target_ldm, params=dict(
+            linear_start=0.00085, linear_end=0.0120, num_timesteps_cond=1, log_every_t=200, timesteps=1000,
+            first_stage_key="jpg", cond_stage_key="txt", control_key="hint", image_size=64, channels=4,
+            cond_stage_trainable=False, conditioning_key="crossattn", monitor="val/loss_simple_ema",
+            scale_factor=0.18215, use_ema=False, only_mid_control=False,
+            control_stage_config=dict(target=target_cn, params=cn),
+            unet_config=dict(target="cldm.cldm.ControlledUnetModel", params=ref_kwargs(cfg, False)),
+            first_stage_config=dict(target="torch.nn.Identity"), cond_stage_config=dict(target="torch.nn.Identity")))
+        m = instantiate_from_config(conf)
+        m.encode_first_stage = lambda x: x
+        m.get_first_stage_encoding = lambda z: z
+        return m.eval()
+
+    seed = 4
+    inp = inputs_for(cfg, 2, 16, seed)
+    sd_un = arch.make_state(arch.unet_shapes(cfg), seed)
+    sd_a = arch.make_state(arch.controlnet_shapes(cfg), 4)
+    sd_b5 = arch.make_state(arch.controlnet_shapes(cfg), 5)
+    res = dict(meta=dict(B=2, H=16, seed=seed, seed_a=4, seed_b=5, weights=[0.3, 0.7],
+                         scales=[0.5 + 0.1 * i for i in range(13)]))
+    h2 = inp["hint_z"].flip(0)
+    with torch.no_grad():
+        # ---- 2-LoRA inference model: shared base (seed 4), bank 0 = LoRA file of seed 4, bank 1 = of seed 5
+        m = ldm("cldm.cldm_ctrlora_inference.ControlInferenceLDM", "cldm.cldm_ctrlora_inference.ControlNetInference",
+                dict(lora_rank=cfg.lora_rank, lora_num=2), drop=("ft_with_lora", "norm_trainable", "lora_rank"))
+        m.model.diffusion_model.load_state_dict(sd_un, strict=True)
+        pre = lambda sd: {"control_model." + k: v for k, v in sd.items()}
+        m.load_state_dict({k: v for k, v in pre(sd_a).items() if not check_key(k)}, strict=False)
+        for i, sd in enumerate((sd_a, sd_b5)):
+            m.control_model.switch_lora(i)
+            m.load_state_dict({k: v for k, v in pre(sd).items() if check_key(k)}, strict=False)
+            m.control_model.copy_weights_to_switchable()
+        m.lora_weights = list(res["meta"]["weights"])
+        m.control_scales = list(res["meta"]["scales"])
+        conds = [dict(c_crossattn=[inp["ctx"]], c_concat=[inp["hint_z"]]), dict(c_crossattn=[inp["ctx"]], c_concat=[h2])]
+        res["eps_multi"] = m.apply_model(inp["z"], inp["t"], conds).clone()
+        # ---- fine-tune model with only_mid_control
+        f = ldm("cldm.cldm_ctrlora_finetune.ControlFinetuneLDM", "cldm.cldm_ctrlora_finetune.ControlNetFinetune", {})
+        f.model.diffusion_model.load_state_dict(sd_un, strict=True)
+        f.control_model.load_state_dict(sd_a, strict=True)
+        f.only_mid_control = True
+        cond = dict(c_crossattn=[inp["ctx"]], c_concat=[inp["hint_z"]])
+        res["eps_only_mid"] = f.apply_model(inp["z"], inp["t"], cond).clone()
+        # ---- pre-train model: two task banks, the task named in cond selects the bank
+        pt = ldm("cldm.cldm_ctrlora_pretrain.ControlPretrainLDM", "cldm.cldm_ctrlora_pretrain.ControlNetPretrain",
+                 dict(lora_rank=cfg.lora_rank, tasks=["hed", "canny"]), drop=("ft_with_lora", "norm_trainable", "lora_rank"))
+        pt.model.diffusion_model.load_state_dict(sd_un, strict=True)
+        for task, sd in (("hed", sd_a), ("canny", sd_b5)):   # tree (shared) weights from seed 4, bank LoRAs per task
+            pt.control_model.switch_lora(task)
+            sel = {k: v for k, v in sd.items() if "lora_layer" in k} if task == "canny" else sd
+            pt.control_model.load_state_dict(sel, strict=False)
+        for task in ("hed", "canny"):
+            c = dict(cond); c["task"] = task
+            res[f"eps_pretrain_{task}"] = pt.apply_model(inp["z"], inp["t"], c).clone()
+    out["variants"] = res
+    print("[golden-next] variants: |eps_multi|=%.4f |eps_only_mid|=%.4f |eps_hed|=%.4f |eps_canny|=%.4f" % tuple(
+        float(res[k].norm()) for k in ("eps_multi", "eps_only_mid", "eps_pretrain_hed", "eps_pretrain_canny")))
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "run in the build container (needs /root/reference)"
-    from make_golden import install_stubs
+    from make_golden import install_stubs, use_reference_packages
     install_stubs()
-    sys.path.insert(0, REF)
     os.chdir("/tmp")
+    use_reference_packages()
     out = {}
     gen_ckpt_golden(out)
     gen_sampler_golden(out)
+    gen_variant_golden(out)
     torch.save(out, f"{HERE}/next_rows.pt")
     print("[golden-next] wrote", f"{HERE}/next_rows.pt", os.path.getsize(f"{HERE}/next_rows.pt"), "bytes")

@@ -352,6 +352,54 @@ def test_api_training_step_and_ddim_through_the_drop_in_classes():
     assert rel_l2(samples, ref) < 5e-4
 
 
+def test_inference_and_pretrain_drop_in_classes_match_reference_goldens():
+    """ControlInferenceLDM (2 LoRA banks filled through the api.CtrLoRA load sequence, weighted residual sum,
+    non-trivial control_scales) and ControlPretrainLDM (task-selected bank) built from the YAML configs and run on
+    the HIP engine, against eps tensors produced by the UNMODIFIED reference classes
+    (tests/golden/make_golden_next.py:gen_variant_golden)."""
+    _need_gpu()
+    import api
+    import bench
+    from oracle import arch
+    g = torch.load(os.path.join(GOLDEN, "next_rows.pt"), weights_only=False)["variants"]
+    meta = g["meta"]
+    cfg = arch.TINY
+    inp = _inputs(cfg, meta["B"], meta["H"], meta["seed"])
+    cu = lambda v: v.cuda()
+    sd_un = arch.make_state(arch.unet_shapes(cfg), meta["seed"])
+    sd_a = arch.make_state(arch.controlnet_shapes(cfg), meta["seed_a"])
+    sd_5 = arch.make_state(arch.controlnet_shapes(cfg), meta["seed_b"])
+    pre = lambda sd: {"control_model." + k: v for k, v in sd.items()}
+    # ---- inference, 2 LoRAs
+    m = bench.build_model("inference/ctrlora_sd15_rank128_2loras.yaml", 0, tiny=True)
+    m.model.diffusion_model.load_state_dict(sd_un, strict=True)
+    api.CtrLoRA(num_loras=2).load_weights(m, cn_state_dict=pre(sd_a), lora_state_dicts=[pre(sd_a), pre(sd_5)])
+    m = m.cuda().eval()
+    m.set_engine_dtype(torch.float32)
+    m.lora_weights = list(meta["weights"])
+    m.control_scales = list(meta["scales"])
+    conds = [dict(c_crossattn=[cu(inp["ctx"])], c_concat=[cu(inp["hint_z"])]),
+             dict(c_crossattn=[cu(inp["ctx"])], c_concat=[cu(inp["hint_z"].flip(0))])]
+    with torch.no_grad():
+        eps = m.apply_model(cu(inp["z"]), cu(inp["t"]), conds)
+    assert rel_l2(eps, g["eps_multi"]) < 1e-4
+    del m
+    # ---- pre-train model: the task named in cond selects the LoRA bank
+    pt = bench.build_model("ctrlora_pretrain_sd15_9tasks_rank128.yaml", 0, tiny=True)
+    pt.model.diffusion_model.load_state_dict(sd_un, strict=True)
+    for task, sd in (("hed", sd_a), ("canny", sd_5)):
+        pt.control_model.switch_lora(task)
+        sel = {k: v for k, v in sd.items() if "lora_layer" in k} if task == "canny" else sd
+        pt.control_model.load_state_dict(sel, strict=False)
+    pt = pt.cuda().eval()
+    pt.set_engine_dtype(torch.float32)
+    for task in ("canny", "hed", "canny"):
+        cond = dict(c_crossattn=[cu(inp["ctx"])], c_concat=[cu(inp["hint_z"])], task=task)
+        with torch.no_grad():
+            e = pt.apply_model(cu(inp["z"]), cu(inp["t"]), cond)
+        assert rel_l2(e, g[f"eps_pretrain_{task}"]) < 1e-4, task
+
+
 def test_graphed_train_step_matches_eager_steps():
     """hipGraph replay of the whole optimizer step (ctrlora_amd.train.GraphedTrainStep: device-resident AdamW
     step counter / hyper-parameters) gives the same trajectory as eager launches."""

@@ -12,3 +12,8 @@ timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o train -- pyth
 python tools/prof_summary.py gpurun_out/prof/train_results.db > gpurun_out/prof_summary.txt 2>&1
 head -30 gpurun_out/prof_summary.txt
 head -30 gpurun_out/prof_summary.txt
+# dominant kernel alone: the rocprofv3 --stats average that bench.py's roofline.ms_per_launch must agree with
+rm -rf gpurun_out/prof_probe
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_probe -o probe --output-format csv -- python bench.py --probe-only > gpurun_out/prof_probe.log 2>&1
+tail -1 gpurun_out/prof_probe.log | cut -c1-300
+find gpurun_out/prof_probe -name "*kernel_stats.csv" | head -1 | xargs -r head -5
