@@ -233,6 +233,16 @@ def gen_variant_golden(out):
         for task in ("hed", "canny"):
             c = dict(cond); c["task"] = task
             res[f"eps_pretrain_{task}"] = pt.apply_model(inp["z"], inp["t"], c).clone()
+        # ---- ragged shape through the fine-tune model: odd batch, non-square latent 24 x 16 (token counts 384 /
+        #      96 / 24 / 6 per level: none a multiple of the 64-row attention / GEMM tiles)
+        g = torch.Generator().manual_seed(77)
+        rag = dict(z=torch.randn(3, 4, 24, 16, generator=g), hint_z=torch.randn(3, 4, 24, 16, generator=g) * 0.9,
+                   ctx=torch.randn(3, 77, cfg.context_dim, generator=g), noise=torch.randn(3, 4, 24, 16, generator=g),
+                   t=torch.tensor([0, 999, 417]))
+        f.only_mid_control = False
+        x_noisy = f.q_sample(rag["z"], rag["t"], rag["noise"])
+        cond = dict(c_crossattn=[rag["ctx"]], c_concat=[rag["hint_z"]])
+        res["ragged"] = dict(inputs=rag, x_noisy=x_noisy.clone(), eps=f.apply_model(x_noisy, rag["t"], cond).clone())
     out["variants"] = res
     print("[golden-next] variants: |eps_multi|=%.4f |eps_only_mid|=%.4f |eps_hed|=%.4f |eps_canny|=%.4f" % tuple(
         float(res[k].norm()) for k in ("eps_multi", "eps_only_mid", "eps_pretrain_hed", "eps_pretrain_canny")))

@@ -272,6 +272,36 @@ def test_engine_forward_backward_vs_oracle_and_reference_golden(name, dtype, tol
             assert rel_l2(o, r) < tol_eps
 
 
+@pytest.mark.parametrize("dtype,tol_eps,tol_grad", [(torch.float32, 1e-4, 5e-4), (torch.bfloat16, 3e-2, 1.5e-1)])
+def test_engine_ragged_shape_vs_reference_and_oracle(dtype, tol_eps, tol_grad):
+    """Odd batch (3), non-square latent 24 x 16 (384 / 96 / 24 / 6 tokens per level -- no multiple of the 64-row
+    attention tiles or the 128 / 256-row GEMM tiles), timesteps 0 and 999: eps vs the UNMODIFIED reference
+    (tests/golden/next_rows.pt) and every trainable gradient vs the oracle."""
+    _need_gpu()
+    from ctrlora_amd.engine import CtrLoRAEngine
+    from oracle import arch, ref_model as R
+    cfg = arch.TINY
+    g = torch.load(os.path.join(GOLDEN, "next_rows.pt"), weights_only=False)["variants"]
+    r = g["ragged"]; inp = r["inputs"]
+    sd_un = arch.make_state(arch.unet_shapes(cfg), g["meta"]["seed"])
+    sd_cn = arch.make_state(arch.controlnet_shapes(cfg), g["meta"]["seed_a"])
+    eng = CtrLoRAEngine(sd_un, [sd_cn], _netcfg(cfg), dtype=dtype, device="cuda")
+    cu = lambda v: v.cuda()
+    eps = eng.forward(cu(r["x_noisy"]), cu(inp["t"]), cu(inp["ctx"]), [cu(inp["hint_z"])], record=True)
+    assert eps.shape == (3, 4, 24, 16)
+    assert rel_l2(eps, r["eps"]) < tol_eps                          # vs the real reference
+    eng.zero_grad()
+    eng.backward(2.0 * (eps - cu(inp["noise"])) / eps.numel())
+    torch.cuda.synchronize()
+    for k in sd_cn:
+        if arch.is_trainable(k):
+            sd_cn[k].requires_grad_(True)
+    eps_ref = R.apply_model(sd_cn, sd_un, cfg, r["x_noisy"], inp["t"], inp["ctx"], inp["hint_z"])
+    ((eps_ref - inp["noise"]) ** 2).mean().backward()
+    errs = sorted(((rel_l2(t.grad, sd_cn[t.name].grad), t.name) for t in eng.controls[0].tr.items), reverse=True)
+    assert errs[0][0] < tol_grad, errs[:5]
+
+
 def test_multi_lora_weighted_sum_and_only_mid_control():
     _need_gpu()
     from ctrlora_amd.engine import CtrLoRAEngine
