@@ -1,6 +1,11 @@
-"""create_model / load_state_dict (API of the reference's cldm/model.py:1-28).  YAML is read with
-PyYAML (the reference uses OmegaConf; the config trees are plain dict/list data)."""
-import os
+"""Model construction and checkpoint reading with the call signatures of the reference's `cldm.model`
+(`create_model(config_path)`, `load_state_dict(ckpt_path, location)`, `get_state_dict(d)`; cldm/model.py:1-28).
+
+Configs are parsed with PyYAML (the trees are plain mappings; anchors / merge keys of configs/*.yaml resolve at load);
+checkpoints may be Lightning pickles (`{"state_dict": ...}`, possibly nested once more), bare state dicts, or
+safetensors files.
+"""
+from pathlib import Path
 
 import torch
 import yaml
@@ -9,24 +14,27 @@ from ldm.util import instantiate_from_config
 
 
 def get_state_dict(d):
-    return d.get("state_dict", d)
+    """Unwrap one `{"state_dict": ...}` level if present."""
+    return d["state_dict"] if "state_dict" in d else d
+
+
+def _read_tensors(path: Path, location: str):
+    if path.suffix.lower() == ".safetensors":
+        from safetensors.torch import load_file
+        return load_file(str(path), device=location)
+    blob = torch.load(str(path), map_location=torch.device(location), weights_only=False)
+    return get_state_dict(blob)
 
 
 def load_state_dict(ckpt_path, location="cpu"):
-    _, ext = os.path.splitext(ckpt_path)
-    if ext.lower() == ".safetensors":
-        import safetensors.torch
-        sd = safetensors.torch.load_file(ckpt_path, device=location)
-    else:
-        sd = get_state_dict(torch.load(ckpt_path, map_location=torch.device(location), weights_only=False))
-    sd = get_state_dict(sd)
-    print(f"Loaded state_dict from [{ckpt_path}]")
-    return sd
+    tensors = get_state_dict(_read_tensors(Path(ckpt_path), location))
+    print(f"[cldm.model] {len(tensors)} tensors read from {ckpt_path}")
+    return tensors
 
 
 def create_model(config_path):
-    with open(config_path) as f:
-        config = yaml.safe_load(f)
-    model = instantiate_from_config(config["model"]).cpu()
-    print(f"Loaded model config from [{config_path}]")
-    return model
+    with open(config_path) as fh:
+        tree = yaml.safe_load(fh)
+    net = instantiate_from_config(tree["model"])
+    print(f"[cldm.model] built {type(net).__name__} from {config_path}")
+    return net.cpu()

@@ -103,3 +103,30 @@ def test_lora_fuse_unfuse_roundtrip_cpu():
     assert float((lin.weight.data - g["w_fused"]).abs().max()) < 1e-6
     lin._unfuse_lora()
     assert float((lin.weight.data - w0).abs().max()) < 1e-6
+
+
+def test_checkpoint_readers_and_create_model(tmp_path):
+    """cldm.model: Lightning-wrapped / bare pickles and safetensors files read to the same flat dict;
+    create_model builds the class named in the YAML (anchors and merge keys of configs/*.yaml resolved)."""
+    from safetensors.torch import save_file
+    from cldm.model import create_model, get_state_dict, load_state_dict
+    sd = {"control_model.zero_convs.0.0.weight": torch.arange(6.0).reshape(2, 3), "logvar": torch.zeros(3)}
+    torch.save({"state_dict": sd, "epoch": 3}, tmp_path / "lightning.ckpt")
+    torch.save(sd, tmp_path / "bare.ckpt")
+    save_file(sd, str(tmp_path / "weights.safetensors"))
+    for name in ("lightning.ckpt", "bare.ckpt", "weights.safetensors"):
+        got = load_state_dict(str(tmp_path / name), location="cpu")
+        assert sorted(got) == sorted(sd) and all(torch.equal(got[k], sd[k]) for k in sd), name
+    assert get_state_dict({"state_dict": sd}) is sd and get_state_dict(sd) is sd
+    cfg = _cfg("ctrlora_finetune_sd15_rank32.yaml")
+    a, b = cfg["model"]["params"]["control_stage_config"]["params"], cfg["model"]["params"]["unet_config"]["params"]
+    assert a is not b and a["model_channels"] == b["model_channels"] == 320 and a["lora_rank"] == 32 and "lora_rank" not in b
+    # a narrow copy of the YAML builds through create_model
+    cfg["model"]["params"]["control_stage_config"]["params"] = _tiny(a)
+    cfg["model"]["params"]["unet_config"]["params"] = _tiny(b)
+    cfg["model"]["params"]["first_stage_config"] = {"target": "torch.nn.Identity"}
+    cfg["model"]["params"]["cond_stage_config"] = {"target": "torch.nn.Identity"}
+    path = tmp_path / "tiny.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    model = create_model(str(path))
+    assert type(model).__name__ == "ControlFinetuneLDM" and next(model.parameters()).device.type == "cpu"
