@@ -32,7 +32,8 @@ SD = Dict[str, torch.Tensor]
 def timestep_embedding(t: torch.Tensor, dim: int, max_period: float = 10000.0) -> torch.Tensor:
     """ldm/modules/diffusionmodules/util.py:154-174 (repeat_only=False branch)."""
     half = dim // 2
-    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
+    # built on the host and moved, as the reference does (util.py:166-168): the table is bit-identical on any device
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half).to(t.device)
     args = t[:, None].float() * freqs[None]
     emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
     if dim % 2:
