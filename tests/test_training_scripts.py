@@ -167,3 +167,47 @@ def test_image_grid_helper_matches_make_grid_layout():
     assert torch.equal(g[:, 2:4, 2:5], imgs[0]) and torch.equal(g[:, 2:4, 7:10], imgs[1])
     assert torch.equal(g[:, 6:8, 2:5], imgs[4]) and float(g[:, 6:8, 7:].abs().sum()) == 0.0
     assert float(g[:, :2].abs().sum()) == 0.0
+
+
+# ------------------------------------------------------------------ scripts/sample.py
+
+def test_sample_script_geometry_cli_and_output_layout(tmp_path):
+    tool = _script("sample")
+    # short side -> 512, both sides to multiples of 64 (annotator/util.py:28-38)
+    assert tool.target_size(480, 640)[:2] == (512, 704) and tool.target_size(1024, 1024)[:2] == (512, 512)
+    assert tool.target_size(300, 1000)[:2] == (512, 1728)
+    assert tool.resize_image(np.zeros((480, 640, 3), np.uint8)).shape == (512, 704, 3)
+    a = tool.get_parser().parse_args(["--dataroot", "d", "--config", "c", "--ckpt", "k", "--save_dir", str(tmp_path / "out")])
+    assert (a.n_samples, a.ddim_steps, a.ddim_eta, a.strength, a.cfg, a.empty_prompt) == (10, 50, 0.0, 1.0, 7.5, False)
+
+    calls = []
+
+    class FakeModel:
+        control_scales = None
+
+        def get_learned_conditioning(self, prompts):
+            return ("ctx", tuple(prompts))
+
+        def decode_first_stage(self, z):
+            return torch.zeros(z.shape[0], 3, z.shape[2] * 8, z.shape[3] * 8)
+
+    class FakeSampler:
+        def sample(self, S, B, shape, cond, verbose, eta, unconditional_guidance_scale, unconditional_conditioning):
+            calls.append((S, B, shape, cond, eta, unconditional_guidance_scale, unconditional_conditioning))
+            return torch.zeros(B, *shape), None
+
+    items = [dict(jpg=np.zeros((100, 150, 3), np.float32), txt=" a cat ", hint=np.ones((100, 150, 3), np.float32) * 0.5),
+             dict(jpg=np.zeros((64, 64, 3), np.float32), txt="dog", hint=np.zeros((64, 64, 3), np.float32))]
+    a.task, a.strength, a.ddim_steps = "canny", 0.8, 7
+    m = FakeModel()
+    n = tool.sample_dataset(m, FakeSampler(), items, a, device="cpu")
+    assert n == 2 and m.control_scales == [0.8] * 13
+    S, B, shape, cond, eta, cfg, unc = calls[0]
+    assert (S, B, shape, eta, cfg) == (7, 1, (4, 64, 96), 0.0, 7.5)            # 100 x 150 -> 512 x 768 -> latent 64 x 96
+    assert cond["task"] == "canny" and cond["c_crossattn"] == [("ctx", (" a cat ",))] and unc["c_crossattn"] == [("ctx", ("",))]
+    assert cond["c_concat"][0].shape == (1, 3, 512, 768) and cond["c_concat"][0] is unc["c_concat"][0]
+    assert abs(float(cond["c_concat"][0].mean()) - 127 / 255) < 1e-3
+    out = tmp_path / "out"
+    for sub in ("sample", "control", "img"):
+        assert sorted(os.listdir(out / sub)) == ["0.png", "1.png"]
+    assert open(out / "prompt.txt").read() == "a cat\ndog\n"
