@@ -40,7 +40,10 @@ int cl_last_hip_error(void);
 /* Scratch for the deterministic split-K path of the contraction kernels (fp32 partial slabs for
  * the deep-K / small-MN products of the 8x8 and 16x16 UNet levels).  The library never allocates:
  * the host (torch) owns the buffer and registers it once per process; without one, split-K is off.
- * 64 MiB covers every CtrLoRA shape at batch 16.  Used stream-ordered on the launching stream. */
+ * 64 MiB covers every CtrLoRA shape at batch 16.  Used stream-ordered on the launching stream.
+ * The same scratch carries the per-workgroup column-sum partials of cl_colsum and of cl_layernorm_bwd's
+ * dgamma / dbeta (partials + a finishing launch instead of same-cache-line atomics); without a registered
+ * buffer those two fall back to fp32 atomics.  (NULL, 0) unregisters. */
 int cl_set_workspace(void* device_ptr, long bytes);
 /* A second (third, fourth) scratch region bound to one stream: contractions launched on that stream use it
  * instead of the default, so concurrent streams never share split-K slabs. */
@@ -194,6 +197,7 @@ int cl_transpose(int in_dtype, int out_dtype, const void* in, long ldi, long bsi
                  long bso, int Bt, int R, int C, int Rpad, void* stream);
 int cl_nchw_to_tok(int dtype, const float* in, void* out, long ldo, int B, int Cin, int Cpad, int HW, void* stream);
 int cl_tok_to_nchw(int dtype, const void* in, long ldi, float* out, int B, int C, int HW, float alpha, float beta, void* stream);
+/* out[b][c] += scale * sum_p in[b*HW + p][c]  (zero-conv bias gradients, time-embedding gradients) */
 int cl_colsum(int dtype, const void* in, long ldi, float* out, long ldo, int B, int HW, int C, float scale, void* stream);
 int cl_pool2x2(int dtype, const void* in, long ldi, void* out, long ldo, int B, int H, int W, int C, int accumulate, void* stream);
 int cl_pack2d(int dtype, const float* in, long ldi, void* out, long ldo, long R, int C, int Cpad, void* stream);
