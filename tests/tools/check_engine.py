@@ -1,6 +1,6 @@
 """GPU bring-up check: HIP engine vs the CPU oracle (prints errors, asserts nothing)."""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import arch, ref_model as R
 from ctrlora_amd.engine import CtrLoRAEngine, NetCfg

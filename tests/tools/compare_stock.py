@@ -3,7 +3,7 @@ reference modules in plain torch ops (oracle/ref_model.py) -- run on the GPU thr
 (rocBLAS / hipBLASLt / MIOpen / ATen), fp32 and bf16-autocast, forward + backward of one LoRA fine-tuning step
 at the bench's shape (rank 128, B per GPU 8, latent 64x64), timed next to the engine.
 
-Test / measurement infrastructure only (imports oracle/): python tools/compare_stock.py [--batch 8] [--steps 5]
+Test / measurement infrastructure only (imports oracle/): python tests/tools/compare_stock.py [--batch 8] [--steps 5]
 Not run on hardware yet (GPU budget of round 1 was spent); intended for the next round's profiles/.
 """
 import argparse
@@ -14,7 +14,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
 def main():
