@@ -140,6 +140,14 @@ def digest(t: torch.Tensor, n=16):
                 idx=idx.tolist(), vals=f[idx].tolist())
 
 
+def sampled(t: torch.Tensor, n=256):
+    """Fixture form of a big gradient tensor: n evenly spaced entries (as a tensor) + l2 norm + sum."""
+    f = t.detach().float().flatten()
+    idx = torch.linspace(0, f.numel() - 1, min(n, f.numel())).long()
+    return dict(shape=list(t.shape), sum=float(f.double().sum()), l2=float(f.double().norm()), idx=idx,
+                vals=f[idx].clone())
+
+
 def inputs_for(cfg, B, H, seed):
     g = torch.Generator().manual_seed(seed)
     return dict(
@@ -148,7 +156,7 @@ def inputs_for(cfg, B, H, seed):
         t=torch.randint(0, 1000, (B,), generator=g).long())
 
 
-def gen_model_golden(name, cfg, B, H, seed, full_tensors):
+def gen_model_golden(name, cfg, B, H, seed, full_tensors, sampled_grads=False):
     from oracle import arch
     torch.manual_seed(0)
     model = build_ldm(cfg)
@@ -156,7 +164,8 @@ def gen_model_golden(name, cfg, B, H, seed, full_tensors):
     # --- key / shape parity with the real reference modules
     ref_cn = {k: list(v.shape) for k, v in model.control_model.state_dict().items()}
     ref_un = {k: list(v.shape) for k, v in model.model.diffusion_model.state_dict().items()}
-    json.dump(dict(controlnet=ref_cn, unet=ref_un), open(f"{HERE}/keys_{name}.json", "w"))
+    if not sampled_grads:      # (the 64x64 fixture shares keys_sd15.json: same architecture)
+        json.dump(dict(controlnet=ref_cn, unet=ref_un), open(f"{HERE}/keys_{name}.json", "w"))
     assert ref_cn == {k: list(v) for k, v in cn_shapes.items()}, "controlnet key/shape mismatch"
     assert ref_un == {k: list(v) for k, v in un_shapes.items()}, "unet key/shape mismatch"
     model.control_model.load_state_dict(arch.make_state(cn_shapes, seed), strict=True)
@@ -185,6 +194,8 @@ def gen_model_golden(name, cfg, B, H, seed, full_tensors):
     tr = [names[id(p)] for p in opt.param_groups[0]["params"]]
     out["trainable_names"] = tr
     out["grad_digest"] = {n: digest(dict(model.control_model.named_parameters())[n].grad) for n in tr}
+    if sampled_grads:   # the benchmarked shapes: every trainable gradient as 256 sampled entries + norm + sum
+        out["grad_sampled"] = {n: sampled(dict(model.control_model.named_parameters())[n].grad) for n in tr}
     opt.step()
     out["adamw_digest"] = {n: digest(dict(model.control_model.named_parameters())[n]) for n in tr[:: max(1, len(tr) // 24)]}
     if full_tensors:
@@ -270,6 +281,10 @@ if __name__ == "__main__":
     os.chdir("/tmp")
     use_reference_packages()
     from oracle import arch
+    if "--only-sd15-64" in sys.argv:
+        # BASELINE config-2 shapes (latent 64x64: N = 4096 attention, M = 8192 GEMM tiles, split-K levels); B = 2
+        gen_model_golden("sd15_64", arch.SD15, B=2, H=64, seed=7, full_tensors=False, sampled_grads=True)
+        sys.exit(0)
     gen_lora_golden()
     gen_schedule_golden()
     gen_model_golden("tiny", arch.TINY, B=2, H=16, seed=11, full_tensors=True)
