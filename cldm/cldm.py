@@ -152,7 +152,8 @@ class ControlLDM(LatentDiffusion):
         its posterior (mean / std) is kept; every call still draws its own posterior sample, so the latent has the
         reference's distribution at every denoising step while the 1.1 TFLOP/image VAE encode -- half of the
         reference's DDIM FLOPs -- leaves the loop."""
-        hint = torch.cat(cond["c_concat"], 1)
+        cc = cond["c_concat"]
+        hint = cc[0] if len(cc) == 1 else torch.cat(cc, 1)
         if hint.shape[1] == self.channels:      # condition images have 3 channels, latents 4
             return hint
         cache = self.__dict__.get("_hint_cache")

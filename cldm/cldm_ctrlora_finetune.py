@@ -64,6 +64,34 @@ class ControlFinetuneLDM(ControlLDM):
             return self._run(x_noisy, t, cond_txt, None)
         return self._run(x_noisy, t, cond_txt, [self._hint_latent(cond)])
 
+    @torch.no_grad()
+    def engine_train_step(self, x_start, cond, t, noise):
+        """p_losses (ddpm.py:885-920) + backward of the loss WITHOUT torch.autograd: q_sample, apply_model with
+        recording, the p_losses reduction with d loss / d eps, the hand-written backward -- every launch is one of
+        this library's kernels, so the whole thing is capturable as a hipGraph with no ATen nodes
+        (ctrlora_amd.train.GraphedTrainStep).  Returns the device 3-vector {loss_simple, loss_vlb, loss}; gradients
+        land in the flat buffer the optimizer's parameters view."""
+        from ctrlora_amd import hip
+        if self.loss_type != "l2" or self.original_elbo_weight != 0.:
+            raise NotImplementedError("engine_train_step: l2 loss without the elbo term (every CtrLoRA config)")
+        x_noisy = self.q_sample(x_start=x_start, t=t, noise=noise)
+        cc = cond["c_crossattn"]
+        cond_txt = cc[0] if len(cc) == 1 else torch.cat(cc, 1)
+        hints = [self._hint_latent(cond)]
+        self._sync_trainables()
+        eng = self.engine()
+        eps = eng.forward(x_noisy, t, cond_txt, hints, control_scales=list(self.control_scales), record=True,
+                          only_mid_control=self.only_mid_control)
+        out = torch.empty(3, dtype=torch.float32, device=eps.device)
+        scratch = torch.empty(16 * eps.shape[0], dtype=torch.float32, device=eps.device)
+        d_eps = torch.empty_like(eps)
+        hip.p_losses_mse(eps, noise.float().contiguous(), d_eps, t.long().contiguous(), self.lvlb_weights, out, scratch,
+                         1.0, float(self.l_simple_weight), 0.0)
+        eng.backward(d_eps)
+        if self.dp is not None:
+            self.dp.on_backward_done()
+        return out
+
     def trainable_names(self):
         """Name filter of :84-108 (LoRA layers; zero convs incl. middle_block_out; `norm` layers)."""
         cm = self.control_model

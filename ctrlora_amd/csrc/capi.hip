@@ -21,7 +21,7 @@ static GemmParams base_params() {
 
 extern "C" {
 
-int cl_abi_version(void) { return 2; }
+int cl_abi_version(void) { return 3; }
 int cl_last_hip_error(void) { return g_last_hip_error; }
 const char* cl_last_hip_error_string(void) { return hipGetErrorString((hipError_t)g_last_hip_error); }
 
@@ -245,6 +245,8 @@ int cl_mse_loss(const float* eps, const float* target, float* d_eps, float* loss
 int cl_ddim_step(const float* x, const float* e_c, const float* e_u, const float* noise, const float* coef, int index, float scale, float* x_prev, float* pred_x0, long n, void* stream) { return ddim_step(x, e_c, e_u, noise, coef, index, scale, x_prev, pred_x0, n, S(stream)); }
 int cl_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) { return adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, S(stream)); }
 
+int cl_p_losses_mse(const float* eps, const float* target, float* d_eps, const long* t, const float* lvlb, float* out, float* per_sample, float* scratch, int B, long per_sample_elems, float gscale, float w_simple, float w_elbo, void* stream) { return plosses_mse(eps, target, d_eps, t, lvlb, out, per_sample, scratch, B, per_sample_elems, gscale, w_simple, w_elbo, S(stream)); }
+int cl_zero(void* p, long nbytes, void* stream) { return zero_bytes(p, nbytes, S(stream)); }
 int cl_tick(int* counter, void* stream) { return tick(counter, S(stream)); }
 int cl_adamw_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, int* step, void* stream) { return adamw_dev(p, g, m, v, n, hyper, step, S(stream)); }
 int cl_ddim_set_t(const long* table, const int* cursor, int S_, long* ts, int n, void* stream) { return ddim_set_t(table, cursor, S_, ts, n, S(stream)); }

@@ -17,6 +17,10 @@ int timestep_embed(int dtype, const long* t, const float* freqs, void* out, long
 int qsample(const float* z, const float* noise, const long* t, const float* sqrt_ac, const float* sqrt_1mac,
             float* out, int B, long per, hipStream_t st);
 int mse_loss(const float* eps, const float* target, float* d_eps, float* loss, long n, float gscale, hipStream_t st);
+int plosses_mse(const float* eps, const float* target, float* d_eps, const long* t, const float* lvlb, float* out,
+                float* per_sample, float* scratch, int B, long per, float gscale, float w_simple, float w_elbo,
+                hipStream_t st);
+int zero_bytes(void* p, long nbytes, hipStream_t st);
 int ddim_step(const float* x, const float* e_c, const float* e_u, const float* noise, const float* coef, int index,
               float scale, float* x_prev, float* pred_x0, long n, hipStream_t st);
 int tick(int* counter, hipStream_t st);

@@ -198,6 +198,50 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ eps,
   if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv);
 }
 
+// ---------------------------------------------------------------- p_losses reduction (ddpm.py:902-918)
+// Deterministic (no float atomics): block (chunk, b) reduces one slice of sample b into scratch[b][chunk] and
+// writes d_eps; the finishing block sums the slices in a fixed order:
+//   out[0] = loss_simple = mean_b mean((eps-target)^2)          (logvar == 0)
+//   out[1] = loss_vlb    = mean_b lvlb[t_b] * mean((eps-target)^2)
+//   out[2] = loss        = l_simple_weight * loss_simple + elbo_weight * loss_vlb
+constexpr int PL_CHUNKS = 16;
+__global__ __launch_bounds__(256) void plosses_partial_kernel(const float* __restrict__ eps,
+                                                              const float* __restrict__ target,
+                                                              float* __restrict__ d_eps, float* __restrict__ scratch,
+                                                              long per, float gmul) {
+  __shared__ float red[4];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const long base = (long)b * per;
+  const long c0 = per * chunk / PL_CHUNKS, c1 = per * (chunk + 1) / PL_CHUNKS;
+  float acc = 0.f;
+  for (long i = c0 + threadIdx.x; i < c1; i += 256) {
+    const float d = eps[base + i] - target[base + i];
+    acc += d * d;
+    if (d_eps) d_eps[base + i] = d * gmul;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) scratch[b * PL_CHUNKS + chunk] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(64) void plosses_finish_kernel(const float* __restrict__ scratch, const long* __restrict__ t,
+                                                            const float* __restrict__ lvlb, float* __restrict__ out,
+                                                            float* __restrict__ per_sample, int B, long per,
+                                                            float w_simple, float w_elbo) {
+  if (threadIdx.x != 0) return;
+  float ls = 0.f, lv = 0.f;
+  for (int b = 0; b < B; ++b) {
+    float s = 0.f;
+    for (int c = 0; c < PL_CHUNKS; ++c) s += scratch[b * PL_CHUNKS + c];
+    s /= (float)per;
+    if (per_sample) per_sample[b] = s;
+    ls += s;
+    if (lvlb) lv += lvlb[t[b]] * s;
+  }
+  ls /= (float)B; lv /= (float)B;
+  out[0] = ls; out[1] = lv; out[2] = w_simple * ls + w_elbo * lv;
+}
+
 // ---------------------------------------------------------------- DDIM update (ddim_hacked.py:192,203-231)
 // coef = device table [S][4] = {a_t, a_prev, sigma_t, sqrt(1 - a_t)} (fp32), row `index` is used.
 __global__ void ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ e_c,
@@ -485,12 +529,25 @@ int adamw(float* p, const float* g, float* m, float* v, long n, float lr, float 
   hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n)), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, wd, bc1, sqrtf(bc2), gscale);
   CL_CHECK_LAUNCH(); return CL_OK;
 }
+int plosses_mse(const float* eps, const float* target, float* d_eps, const long* t, const float* lvlb, float* out,
+                float* per_sample, float* scratch, int B, long per, float gscale, float w_simple, float w_elbo,
+                hipStream_t st) {
+  if (B < 1 || per < 1) return CL_EINVAL;
+  // d loss / d eps with loss = w_simple * mean(...) (the elbo term is not differentiated: weight 0 in every config)
+  const float gmul = 2.0f * gscale * w_simple / ((float)per * (float)B);
+  hipLaunchKernelGGL(plosses_partial_kernel, dim3(PL_CHUNKS, B), dim3(256), 0, st, eps, target, d_eps, scratch, per, gmul);
+  hipLaunchKernelGGL(plosses_finish_kernel, dim3(1), dim3(64), 0, st, scratch, t, lvlb, out, per_sample, B, per, w_simple, w_elbo);
+  CL_CHECK_LAUNCH(); return CL_OK;
+}
+int zero_bytes(void* p, long nbytes, hipStream_t st) {
+  if (nbytes <= 0) return CL_OK;
+  return hipMemsetAsync(p, 0, (size_t)nbytes, st) == hipSuccess ? CL_OK : CL_ELAUNCH;
+}
 int tick(int* counter, hipStream_t st) {
   hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(1), 0, st, counter);
   CL_CHECK_LAUNCH(); return CL_OK;
 }
 int adamw_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, int* step, hipStream_t st) {
-  hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(1), 0, st, step);
   hipLaunchKernelGGL(adamw_dev_kernel, dim3(ew_grid(n)), dim3(256), 0, st, p, g, m, v, n, hyper, step);
   CL_CHECK_LAUNCH(); return CL_OK;
 }

@@ -52,7 +52,7 @@ class Ctx:
         return torch.empty((rows, cols), dtype=dtype or self.dtype, device=self.device)
 
     def zeros(self, rows: int, cols: int, dtype=None) -> torch.Tensor:
-        return torch.zeros((rows, cols), dtype=dtype or self.dtype, device=self.device)
+        return hip.zero_(torch.empty((rows, cols), dtype=dtype or self.dtype, device=self.device))
 
     def gn_ws(self, B: int, HW: int, C: int) -> torch.Tensor:
         n = hip.groupnorm_ws(B, HW, C)

@@ -195,7 +195,7 @@ class CtrLoRAEngine:
     # ---------------------------------------------------------------- trainables
     def zero_grad(self):
         for cn in self.controls:
-            cn.tr.flat_grad.zero_()
+            hip.zero_(cn.tr.flat_grad)
 
     def repack(self):
         for cn in self.controls:

@@ -95,6 +95,8 @@ _SIGS = {
     "cl_timestep_embedding": [_I, _P, _P, _P, _L, _I, _I, _P],
     "cl_qsample": [_P, _P, _P, _P, _P, _P, _I, _L, _P],
     "cl_mse_loss": [_P, _P, _P, _P, _L, _F, _P],
+    "cl_p_losses_mse": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _P],
+    "cl_zero": [_P, _L, _P],
     "cl_ddim_step": [_P, _P, _P, _P, _P, _I, _F, _P, _P, _L, _P],
     "cl_tick": [_P, _P],
     "cl_adamw_dev": [_P, _P, _P, _P, _L, _P, _P, _P],
@@ -439,6 +441,23 @@ def mse_loss(eps, target, d_eps, loss, gscale=1.0):
     return loss
 
 
+def p_losses_mse(eps, target, d_eps, t, lvlb, out3, scratch, gscale=1.0, w_simple=1.0, w_elbo=0.0, per_sample=None):
+    """Deterministic p_losses reduction: out3 = {loss_simple, loss_vlb, loss}; d_eps = d(w_simple*loss_simple)/d eps."""
+    B = eps.shape[0]
+    assert scratch.numel() >= 16 * B and eps.is_contiguous() and target.is_contiguous()
+    _chk(lib().cl_p_losses_mse(eps.data_ptr(), target.data_ptr(), ptr(d_eps), ptr(t), ptr(lvlb), out3.data_ptr(),
+                               ptr(per_sample), scratch.data_ptr(), B, eps.numel() // B, gscale, w_simple, w_elbo,
+                               stream()), "cl_p_losses_mse")
+    return out3
+
+
+def zero_(t):
+    """In-place clear of a contiguous tensor as a memset node on the current stream (no ATen launch)."""
+    assert t.is_contiguous()
+    _chk(lib().cl_zero(t.data_ptr(), t.numel() * t.element_size(), stream()), "cl_zero")
+    return t
+
+
 def ddim_step(x, e_c, e_u, noise, coef, index, scale, x_prev, pred_x0=None):
     _chk(lib().cl_ddim_step(x.data_ptr(), e_c.data_ptr(), ptr(e_u), ptr(noise), coef.data_ptr(), index, scale,
                             x_prev.data_ptr(), ptr(pred_x0), x.numel(), stream()), "cl_ddim_step")
@@ -456,7 +475,8 @@ def tick(counter):
 
 def adamw_dev(p, g, m, v, hyper, step):
     """AdamW with device-resident hyper-parameters {lr, b1, b2, eps, wd, grad_scale} and step counter
-    (hipGraph-replayable: nothing step-dependent is a kernel argument)."""
+    (hipGraph-replayable: nothing step-dependent is a kernel argument).  The caller advances `step` with
+    tick() ONCE per optimizer step, before the first bank."""
     _chk(lib().cl_adamw_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), hyper.data_ptr(),
                             step.data_ptr(), stream()), "cl_adamw_dev")
 

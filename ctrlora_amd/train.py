@@ -3,7 +3,8 @@
   * ApplyModelFn   -- one autograd node for the whole ControlNet+UNet pass: forward records,
                       backward runs the hand-written backward and fills the flat fp32 gradient buffers
                       (the trainable nn.Parameters' .grad are views of those buffers).
-  * MSELossFn      -- fused mean((eps - target)^2) + its gradient (ddpm.py:902-918 with logvar = 0).
+  * PLossFn        -- p_losses' reduction {loss_simple, loss_vlb, loss} + d loss / d eps, one deterministic kernel pair
+                      (ddpm.py:902-918 with logvar = 0).
   * FusedAdamW     -- torch.optim.AdamW semantics (cldm_ctrlora_finetune.py:105) as ONE kernel over the
                       flat master/grad buffers, followed by the re-pack of the trainables.
   * bind_trainables -- re-points the ControlNet's trainable nn.Parameters at the flat buffers.
@@ -50,21 +51,27 @@ class ApplyModelFn(torch.autograd.Function):
         return (None,) * 10
 
 
-class MSELossFn(torch.autograd.Function):
+class PLossFn(torch.autograd.Function):
+    """LatentDiffusion.p_losses' reduction (ddpm.py:902-918 with logvar = 0) as ONE deterministic HIP reduction:
+    returns the 3-vector {loss_simple, loss_vlb, loss = w_simple * loss_simple + w_elbo * loss_vlb} and keeps
+    d(w_simple * loss_simple) / d eps for the backward (the elbo term is not differentiated; its weight is 0 in
+    every CtrLoRA config and the caller checks that)."""
+
     @staticmethod
-    def forward(ctx, eps, target):
+    def forward(ctx, eps, target, t, lvlb, w_simple, w_elbo):
         eps = eps.float().contiguous()
         target = target.float().contiguous()
-        loss = torch.zeros((), dtype=torch.float32, device=eps.device)
+        out = torch.empty(3, dtype=torch.float32, device=eps.device)
+        scratch = torch.empty(16 * eps.shape[0], dtype=torch.float32, device=eps.device)
         d_eps = torch.empty_like(eps)
-        hip.mse_loss(eps, target, d_eps, loss)
+        hip.p_losses_mse(eps, target, d_eps, t.long().contiguous(), lvlb, out, scratch, 1.0, float(w_simple), float(w_elbo))
         ctx.save_for_backward(d_eps)
-        return loss
+        return out
 
     @staticmethod
     def backward(ctx, g):
         (d_eps,) = ctx.saved_tensors
-        return d_eps * g, None
+        return d_eps * g[2], None, None, None, None, None
 
 
 class FusedAdamW(torch.optim.Optimizer):
@@ -110,6 +117,7 @@ class FusedAdamW(torch.optim.Optimizer):
             self.pre_step_hook()
         if not torch.cuda.is_current_stream_capturing():
             self.sync_hyper()
+        hip.tick(self._step_dev)          # one tick per optimizer step, however many banks follow
         for ex, m, v in zip(self.executors, self._m, self._v):
             hip.adamw_dev(ex.tr.flat, ex.tr.flat_grad, m, v, self._hyper, self._step_dev)
             ex.repack()
@@ -118,7 +126,7 @@ class FusedAdamW(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = False):
         # .grad tensors are views of flat_grad: zero in place, they must stay attached
         for ex in self.executors:
-            ex.tr.flat_grad.zero_()
+            hip.zero_(ex.tr.flat_grad)
 
     def state_dict(self):
         return dict(step=self._step, m=[m.clone() for m in self._m], v=[v.clone() for v in self._v],
@@ -158,13 +166,21 @@ class GraphedTrainStep:
         self.s_z, self.s_ctx, self.s_hint = z.clone(), cond_txt.clone(), hint.clone()
         self.s_t, self.s_noise = t.clone(), noise.clone()
         self.loss = None
+        self.loss3 = None
         dp = model.dp
         if dp is not None:
             dp.enabled = False          # no collectives inside the captured region
 
+        direct = getattr(model, "engine_train_step", None)
+
         def fwd_bwd():
             opt.zero_grad()
             cond = {"c_crossattn": [self.s_ctx], "c_concat": [self.s_hint]}
+            if direct is not None:
+                # p_losses + backward without autograd: the captured region holds hand-written kernels and memset
+                # nodes only (no ATen launch); out = {loss_simple, loss_vlb, loss}
+                self.loss3 = direct(self.s_z, cond, self.s_t, self.s_noise)
+                return self.loss3[2]
             loss, _ = model.p_losses(self.s_z, cond, self.s_t, noise=self.s_noise)
             loss.backward()
             return loss.detach()

@@ -216,6 +216,15 @@ int cl_qsample(const float* z, const float* noise, const long* t, const float* s
                float* out, int B, long per_sample, void* stream);
 /* p_losses MSE (ddpm.py:902-918): *loss = mean((eps - target)^2); d_eps = 2 (eps - target) / n * gscale */
 int cl_mse_loss(const float* eps, const float* target, float* d_eps, float* loss, long n, float gscale, void* stream);
+/* LatentDiffusion.p_losses' reduction, deterministic (ddpm.py:902-918, eps-parameterisation, logvar == 0):
+ *   out[0] = loss_simple = mean_b mean_chw (eps - target)^2        out[1] = loss_vlb = mean_b lvlb[t_b] * (per-sample mean)
+ *   out[2] = loss = w_simple * loss_simple + w_elbo * loss_vlb     per_sample[B] (optional) = per-sample means
+ *   d_eps (optional) = d (w_simple * loss_simple) / d eps * gscale.  scratch: 16 * B floats.  lvlb may be NULL. */
+int cl_p_losses_mse(const float* eps, const float* target, float* d_eps, const long* t, const float* lvlb, float* out,
+                    float* per_sample, float* scratch, int B, long per_sample_elems, float gscale, float w_simple,
+                    float w_elbo, void* stream);
+/* optimizer.zero_grad() / accumulator clears without an ATen launch: memset node on `stream` */
+int cl_zero(void* p, long nbytes, void* stream);
 /* DDIMSampler.p_sample_ddim update (cldm/ddim_hacked.py:192,203-231); coef = device [S][4] fp32 table
  * {a_t, a_prev, sigma_t, sqrt(1-a_t)}; e_u = NULL disables classifier-free guidance. */
 int cl_ddim_step(const float* x, const float* e_c, const float* e_u, const float* noise, const float* coef,
@@ -227,7 +236,8 @@ int cl_adamw(float* p, const float* g, float* m, float* v, long n, float lr, flo
 /* ---- device-resident step state: what a captured hipGraph needs --------------------------
  * A replayed graph re-issues the same kernel arguments, so per-step scalars live in device memory.
  * cl_tick: *counter += 1.  cl_adamw_dev: AdamW with hyper = device {lr, beta1, beta2, eps, weight_decay,
- * grad_scale} and a device step counter (incremented first, as torch does).  cl_ddim_set_t / cl_ddim_step_dev:
+ * grad_scale} and a device step counter that the CALLER advances with cl_tick once per optimizer step, before the
+ * first cl_adamw_dev of that step (one tick however many parameter banks follow; torch increments first too).  cl_ddim_set_t / cl_ddim_step_dev:
  * the DDIM loop body with a device cursor i (iteration number): index = S-1-i, ts[:] = ddim_timesteps[index]
  * (cldm/ddim_hacked.py:157-160,203-231); x_prev may alias x. */
 int cl_tick(int* counter, void* stream);

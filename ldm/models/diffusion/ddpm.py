@@ -205,14 +205,12 @@ class LatentDiffusion(DDPM):
         prefix = "train" if self.training else "val"
         target = noise
         if model_output.is_cuda and self.loss_type == "l2" and self.original_elbo_weight == 0.:
-            # logvar == 0 and original_elbo_weight == 0  =>  loss = l_simple_weight * mean((eps-target)^2)
-            from ctrlora_amd.train import MSELossFn
-            loss_simple = MSELossFn.apply(model_output, target)
-            loss = self.l_simple_weight * loss_simple
-            with torch.no_grad():
-                per = ((model_output.detach() - target) ** 2).mean(dim=(1, 2, 3))
-                loss_vlb = (self.lvlb_weights[t] * per).mean()
-            return loss, {f"{prefix}/loss_simple": loss_simple.detach(), f"{prefix}/loss_vlb": loss_vlb,
+            # logvar == 0 and original_elbo_weight == 0  =>  loss = l_simple_weight * mean((eps-target)^2); the three
+            # logged scalars come out of one deterministic HIP reduction
+            from ctrlora_amd.train import PLossFn
+            out = PLossFn.apply(model_output, target, t, self.lvlb_weights, self.l_simple_weight, 0.0)
+            loss = out[2]
+            return loss, {f"{prefix}/loss_simple": out[0].detach(), f"{prefix}/loss_vlb": out[1].detach(),
                           f"{prefix}/loss": loss.detach()}
         loss_simple = self.get_loss(model_output, target, mean=False).mean([1, 2, 3])
         logvar_t = self.logvar[t].to(self.device)

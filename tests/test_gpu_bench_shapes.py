@@ -151,25 +151,31 @@ def test_graphed_two_stream_train_step_b8_latent64_matches_eager_and_oracle():
     ex = model.control_model.executor()
     grads_g = ex.tr.flat_grad.clone()
     torch.cuda.synchronize()
-    # (a) eager, single stream, same weights
-    eng_b = CtrLoRAEngine(sd_un, [sd_cn], _netcfg(cfg), dtype=torch.bfloat16, device="cuda")
-    eng_b.overlap_streams = False
-    x_noisy = model.q_sample(z, t, noise)
-    eps_b = eng_b.forward(x_noisy, t, ctx, [hint], record=True)
-    eng_b.zero_grad()
+    # (a) eager launches, same weights: with the same two-stream structure (same per-stream split-K scratch, hence the
+    # same summation order) the result must be bit-identical; on ONE stream the split-K factors of the ControlNet
+    # trunk differ (64 MiB default scratch instead of the side stream's 32 MiB), i.e. fp32 summation order changes
+    # and bf16 roundings flip: bounded at bf16 noise level
     from ctrlora_amd import hip
-    d_eps, loss_t = torch.empty_like(eps_b), torch.zeros((), device="cuda")
-    hip.mse_loss(eps_b.contiguous(), noise.contiguous(), d_eps, loss_t)      # the kernel p_losses uses
-    eng_b.backward(d_eps)
-    torch.cuda.synchronize()
-    loss_b = float(loss_t)
-    tr_b = eng_b.controls[0].tr
-    assert [t_.name for t_ in tr_b.items] == [t_.name for t_ in ex.tr.items]
-    same = torch.equal(tr_b.flat_grad, grads_g)
-    d_ge = rel_l2(grads_g, tr_b.flat_grad)
-    _record("graphed_b8", loss_graph=loss_g, loss_eager=loss_b, graph_vs_eager_flat_grad=d_ge, bit_identical=bool(same))
-    assert abs(loss_g - loss_b) < 1e-6 * abs(loss_b)
-    assert d_ge < 1e-6
+    x_noisy = model.q_sample(z, t, noise)
+    res = {}
+    for overlap in (True, False):
+        eng_b = CtrLoRAEngine(sd_un, [sd_cn], _netcfg(cfg), dtype=torch.bfloat16, device="cuda")
+        eng_b.overlap_streams = overlap
+        eps_b = eng_b.forward(x_noisy, t, ctx, [hint], record=True)
+        eng_b.zero_grad()
+        d_eps, loss_t = torch.empty_like(eps_b), torch.zeros((), device="cuda")
+        hip.mse_loss(eps_b.contiguous(), noise.contiguous(), d_eps, loss_t)
+        eng_b.backward(d_eps)
+        torch.cuda.synchronize()
+        tr_b = eng_b.controls[0].tr
+        assert [t_.name for t_ in tr_b.items] == [t_.name for t_ in ex.tr.items]
+        res[overlap] = (float(loss_t), rel_l2(grads_g, tr_b.flat_grad), bool(torch.equal(tr_b.flat_grad, grads_g)))
+        del eng_b
+    _record("graphed_b8", loss_graph=loss_g, loss_eager_two_stream=res[True][0], loss_eager_one_stream=res[False][0],
+            graph_vs_eager_two_stream=res[True][1], bit_identical_two_stream=res[True][2],
+            graph_vs_eager_one_stream=res[False][1])
+    assert abs(loss_g - res[True][0]) < 1e-6 * abs(loss_g) and res[True][1] < 1e-6
+    assert abs(loss_g - res[False][0]) < 1e-4 * abs(loss_g) and res[False][1] < 5e-3
     # (b) fp32 engine and the oracle on the GPU
     eng_f = CtrLoRAEngine(sd_un, [sd_cn], _netcfg(cfg), dtype=torch.float32, device="cuda")
     eps_f = eng_f.forward(x_noisy, t, ctx, [hint], record=True)
@@ -179,6 +185,8 @@ def test_graphed_two_stream_train_step_b8_latent64_matches_eager_and_oracle():
     loss_o, eps_o, grads_o = _oracle_on_gpu(cfg, sd_cn, sd_un, z, t, ctx, hint, noise)
     e_f = rel_l2(eps_f, eps_o)
     gf = sorted(((rel_l2(t_.grad, grads_o[t_.name]), t_.name) for t_ in eng_f.controls[0].tr.items), reverse=True)
+    eng_g = model.engine()
+    eps_b = eng_g.forward(x_noisy, t, ctx, [hint])            # the graphed model's own executors, no-grad forward
     e_b = rel_l2(eps_b, eps_o)
     by_name = {t_.name: t_ for t_ in ex.tr.items}
     gb = sorted(((rel_l2(grads_g[t_.offset:t_.offset + t_.master.numel()].view(t_.shape), grads_o[n]), n)
@@ -296,7 +304,8 @@ def test_attention_production_shapes_fwd_bwd(dh, N, Nkv, B):
     orf.backward(do.double().reshape(B, N, Hh, dh).permute(0, 2, 1, 3))
     back = lambda x, n: x.permute(0, 2, 1, 3).reshape(B * n, inner)
     e_o = rel_l2(o, back(orf, N))
-    e_lse = rel_l2(lse[:, :, :N], torch.logsumexp(s, -1))
+    # the kernels keep log-sum-exp in the exp2 domain (log2 of the softmax denominator of scale * log2(e) * s)
+    e_lse = rel_l2(lse[:, :, :N] * 0.6931471805599453, torch.logsumexp(s, -1))
     e_dq, e_dk, e_dv = rel_l2(dq, back(qr.grad, N)), rel_l2(dk, back(kr.grad, Nkv)), rel_l2(dv, back(vr.grad, Nkv))
     _record("attention", shape=[dh, N, Nkv, B], o=e_o, lse=e_lse, dq=e_dq, dk=e_dk, dv=e_dv)
     assert e_o < 6e-3 and e_lse < 1e-5
