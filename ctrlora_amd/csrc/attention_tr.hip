@@ -243,6 +243,316 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_tr_kernel(AttnFwdArgs p, cons
   }
 }
 
+// =============================================================================== forward, ping-pong schedule
+// Self-attention at the 64x64 / 32x32 levels (N = 4096 / 1024 keys, d_head 40 / 80) is where the attention time
+// goes, and there the kernel above is bound by neither pipe: per 32-query x 64-key step a wave issues 28 MFMAs
+// (448 matrix-pipe cycles) and ~175 VALU instructions (softmax), but the tile barrier keeps every wave of the
+// workgroup in the same phase, so the matrix pipe idles while all waves do softmax and vice versa (measured:
+// ~1400 cycles per wave-step).  This kernel runs 8 waves per workgroup (256 queries) as two groups of four that
+// are ONE phase apart -- waves w and w + 4 share a SIMD -- so that on every SIMD one wave is in its matrix phase
+//     M(u) = O^T += V^T P^T of tile u-1, then S^T = K Q^T of tile u     (28 MFMAs, LDS fragment reads pipelined)
+// while its partner is in its vector phase
+//     V(u) = online softmax of tile u                                     (VALU only, no LDS, no memory)
+// and a workgroup barrier separates the phases.  Schedule in barrier intervals (group A = waves 0-3, B = 4-7):
+//     interval 2u   : A: M(u)   B: V(u-1)      interval 2u+1 : A: V(u)   B: M(u)
+// K/V tiles ride a 3-stage LDS ring: tile u is read in intervals 2u .. 2u+3 (K by the two M(u), V by the two
+// M(u+1)), so its stage is refilled with tile u+3 at the start of interval 2u+4 (every wave issues its share of
+// the DMA there) and every wave drains its own DMA (vmcnt 0) before the barrier that ends interval 2u+5.
+// Softmax VALU diet: (a) the running maximum moves only when some score exceeds it by more than RESCALE_THR
+// (in log2 units) -- the common step has no cross-lane traffic and no rescale of O; (b) for d_head 40 the
+// softmax denominator is produced by the matrix pipe: the V^T operand has spare rows (40..47), row 40 is forced
+// to ones, so O^T[40, q] = sum_k P[q, k] of exactly the bf16 P that multiplies V.
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+template <int OFF> __device__ __forceinline__ u32x4_t lds_read_b128_off(uint32_t addr) {
+  u32x4_t v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+// a value produced by an asynchronous LDS read: every use must follow the wait this is placed after
+__device__ __forceinline__ void pin(u32x4_t& v) { asm volatile("" : "+v"(v)); }
+template <int N> __device__ __forceinline__ void lgkm_wait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int DH>
+__global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnFwdArgs p, const void* __restrict__ V, long ldv,
+                                                             int nqb, int remap) {
+  using G = Geo<DH>;
+  constexpr int CPR = G::CPR, KSTEPS = G::KSTEPS, DN = G::DN, ROWB = G::ROWB, TILE = G::TILE;
+  constexpr int STAGE = 2 * TILE, QW = 2;
+  constexpr bool ONES = (DH % 16) != 0;        // spare V^T rows exist: row DH carries the softmax denominator
+  constexpr int LROW = DH % 16;
+  constexpr float RESCALE_THR = 6.0f;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 stages + 16 rows + 64 bytes of (zeroed) slack
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  const int g = lane >> 4, lq = lane & 15;
+  int bh, qb;
+  {
+    const int id = blockIdx.x;
+    if (remap) {   // all query blocks of one (batch, head) on one XCD: K/V are fetched into ONE L2
+      const int xcd = id & 7, slot = id >> 3;
+      bh = xcd + 8 * (slot / nqb); qb = slot - (slot / nqb) * nqb;
+    } else { bh = id / nqb; qb = id - bh * nqb; }
+  }
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int q0 = qb * 256 + wave * 32;
+  const float sl2 = p.scale * 1.4426950408889634f;
+
+  // fragment over-reads (chunks >= CPR of the last rows) land in the slack: keep it finite (x 0 must stay 0)
+  for (int i = tid; i < (16 * ROWB + 64) / 4; i += 512) reinterpret_cast<uint32_t*>(smem + 3 * STAGE)[i] = 0u;
+
+  u32x4_t qf[QW][KSTEPS];
+#pragma unroll
+  for (int f = 0; f < QW; ++f) {
+    const int row = q0 + f * 16 + lq;
+    const char* qp = (const char*)p.Q + (((long)b * p.N + row) * p.ldq + (long)h * DH) * 2;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int c = 4 * ks + g;
+      qf[f][ks] = (c < CPR) ? *reinterpret_cast<const u32x4_t*>(qp + c * 16) : u32x4_t{0u, 0u, 0u, 0u};
+    }
+  }
+  const char* kbase = (const char*)p.K + ((long)b * p.Nkv * p.ldk + (long)h * DH) * 2;
+  const char* vbase = (const char*)V + ((long)b * p.Nkv * ldv + (long)h * DH) * 2;
+
+  f32x4_t ot[DN][QW];
+#pragma unroll
+  for (int i = 0; i < DN; ++i)
+#pragma unroll
+    for (int f = 0; f < QW; ++f) ot[i][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_run[QW], l_run[QW];
+#pragma unroll
+  for (int f = 0; f < QW; ++f) { m_run[f] = -1e30f; l_run[f] = 0.f; }
+  f32x4_t st[4][QW];
+  u32x4_t pb[2][QW];
+
+  // ---- DMA: wave w issues instructions w, w + 8, ... of a tile (1 KiB each, lane-linear image)
+  constexpr int NJ = (CPR + 7) / 8;
+  int koff[NJ], voff[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = (wave + 8 * j) * 64 + lane, r = c / CPR, cc = (c - r * CPR) * 16;
+    koff[j] = r * (int)(p.ldk * 2) + cc;
+    voff[j] = r * (int)(ldv * 2) + cc;
+  }
+  auto issue = [&](int t, int stage) {
+    const char* kb = kbase + (long)t * 64 * p.ldk * 2;
+    const char* vb = vbase + (long)t * 64 * ldv * 2;
+    char* dst = smem + stage * STAGE;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      if (wave + 8 * j < CPR) {
+        glds16(kb + koff[j], dst + (wave + 8 * j) * 1024);
+        glds16(vb + voff[j], dst + TILE + (wave + 8 * j) * 1024);
+      }
+  };
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const uint32_t krow = lq * ROWB + g * 16;
+  const uint32_t troff = (4 * g + ((lane >> 2) & 3)) * ROWB + (lane & 3) * 8;
+  const bool ones_lane = ONES && lq == LROW;
+  const int nt = p.Nkv / 64;
+
+  // ---- matrix phase: PV of the previous tile (PREV), then QK^T of this one; fragment reads one group ahead
+  auto phaseM = [&](auto PREVc, uint32_t kt, uint32_t vt) {
+    constexpr bool PREV = decltype(PREVc)::value;
+    constexpr int NV = PREV ? DN : 0, NG = NV + 4;
+    u32x4_t va[2][2], ka[2][KSTEPS];
+    auto read_group = [&](auto Jc) {
+      constexpr int J = decltype(Jc)::value;
+      if constexpr (J < NV) {
+        va[J & 1][0] = tr_frag<ROWB, 0>(vt + troff + J * 32);
+        va[J & 1][1] = tr_frag<ROWB, 1>(vt + troff + J * 32);
+      } else if constexpr (J < NG) {
+        constexpr int kf = J - NV;
+        // chunks >= CPR read finite garbage that meets zeros of the Q fragment
+        static_for<0, KSTEPS>([&](auto Kc) {
+          constexpr int ks = decltype(Kc)::value;
+          ka[kf & 1][ks] = lds_read_b128_off<kf * 16 * ROWB + ks * 64>(kt + krow);
+        });
+      }
+    };
+    read_group(std::integral_constant<int, 0>{});
+    read_group(std::integral_constant<int, 1>{});
+    static_for<0, NG>([&](auto Jc) {
+      constexpr int J = decltype(Jc)::value;
+      // instructions of group J+1 may stay outstanding (LDS returns in order)
+      constexpr int next_cnt = (J + 1 >= NG) ? 0 : ((J + 1 < NV) ? 4 : KSTEPS);
+      lgkm_wait<next_cnt>();
+      if constexpr (J < NV) {
+        pin(va[J & 1][0]); pin(va[J & 1][1]);
+        u32x4_t a0 = va[J & 1][0], a1 = va[J & 1][1];
+        if constexpr (ONES && J == DN - 1) {
+          const uint32_t one2 = 0x3F803F80u;
+          a0.x = ones_lane ? one2 : a0.x; a0.y = ones_lane ? one2 : a0.y; a0.z = ones_lane ? one2 : a0.z; a0.w = ones_lane ? one2 : a0.w;
+          a1.x = ones_lane ? one2 : a1.x; a1.y = ones_lane ? one2 : a1.y; a1.z = ones_lane ? one2 : a1.z; a1.w = ones_lane ? one2 : a1.w;
+        }
+#pragma unroll
+        for (int f = 0; f < QW; ++f) Mma<bf16_t>::run(a0, pb[0][f], ot[J][f]);
+#pragma unroll
+        for (int f = 0; f < QW; ++f) Mma<bf16_t>::run(a1, pb[1][f], ot[J][f]);
+      } else {
+        constexpr int kf = J - NV;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) pin(ka[kf & 1][ks]);
+#pragma unroll
+        for (int f = 0; f < QW; ++f) st[kf][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+          for (int f = 0; f < QW; ++f) Mma<bf16_t>::run(ka[kf & 1][ks], qf[f][ks], st[kf][f]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      read_group(std::integral_constant<int, J + 2>{});
+    });
+  };
+
+  // ---- vector phase: online softmax of st -> pb (registers only)
+  auto phaseV = [&]() {
+    float ml[QW];
+    bool need = false;
+#pragma unroll
+    for (int f = 0; f < QW; ++f) {
+      float mx = st[0][f][0];
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kf][f][r]);
+      ml[f] = mx;
+      need |= (mx * sl2 > m_run[f] + RESCALE_THR);
+    }
+    if (__any(need)) {   // wave-uniform, rare after the first tiles: move the running maximum and rescale O (and l)
+#pragma unroll
+      for (int f = 0; f < QW; ++f) {
+        float mx = ml[f];
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run[f], mx * sl2);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);
+        m_run[f] = m_new;
+        l_run[f] *= alpha;
+#pragma unroll
+        for (int i = 0; i < DN; ++i) ot[i][f] *= alpha;
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < QW; ++f) {
+      float ls = 0.f;
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kf][f][r], sl2, -m_run[f]));
+          st[kf][f][r] = e;
+          if constexpr (!ONES) ls += e;
+        }
+      if constexpr (!ONES) l_run[f] += ls;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int f = 0; f < QW; ++f) {
+        f32x4_t tmp[2] = {st[2 * s][f], st[2 * s + 1][f]};
+        pb[s][f] = PFrag<bf16_t>::make(tmp);
+      }
+  };
+
+  issue(0, 0);
+  issue(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                   // tiles 0, 1 landed; slack zeroed
+  int sk = 0;                                        // ring stage of tile u;  tile u-1 sits in stage sp
+  if (grp == 0) {
+    int sp = 2;
+    for (int u = 0; u < nt; ++u) {
+      const int sn = (sk == 2) ? 0 : sk + 1;
+      if (u >= 1 && u + 1 < nt) issue(u + 1, sn);                          // interval 2u
+      if (u == 0) phaseM(std::false_type{}, lds0 + sk * STAGE, 0u);
+      else phaseM(std::true_type{}, lds0 + sk * STAGE, lds0 + sp * STAGE + TILE);
+      __builtin_amdgcn_s_barrier();
+      phaseV();                                                            // interval 2u+1
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      sp = sk; sk = sn;
+    }
+    // interval 2nt: PV of the last tile (reads only; nothing left to guard with a barrier but the count must match)
+    {
+      const uint32_t vt = lds0 + sp * STAGE + TILE;
+      u32x4_t va[2];
+#pragma unroll
+      for (int i = 0; i < DN; ++i) {
+        va[0] = tr_frag<ROWB, 0>(vt + troff + i * 32); va[1] = tr_frag<ROWB, 1>(vt + troff + i * 32);
+        lds_wait();
+        if (ONES && i == DN - 1 && ones_lane) { va[0] = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u}; va[1] = va[0]; }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int f = 0; f < QW; ++f) Mma<bf16_t>::run(va[s], pb[s][f], ot[i][f]);
+      }
+    }
+    __builtin_amdgcn_s_barrier();
+  } else {
+    int sp = 2;
+    __builtin_amdgcn_s_barrier();                                          // interval 0: idle
+    for (int u = 0; u < nt; ++u) {
+      const int sn = (sk == 2) ? 0 : sk + 1, sn2 = (sn == 2) ? 0 : sn + 1;
+      if (u == 0) phaseM(std::false_type{}, lds0 + sk * STAGE, 0u);       // interval 2u+1
+      else phaseM(std::true_type{}, lds0 + sk * STAGE, lds0 + sp * STAGE + TILE);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (u + 2 < nt) issue(u + 2, sn2);                                   // interval 2u+2
+      phaseV();
+      __builtin_amdgcn_s_barrier();
+      sp = sk; sk = sn;
+    }
+    {                                                                      // interval 2nt+1
+      const uint32_t vt = lds0 + sp * STAGE + TILE;
+      u32x4_t va[2];
+#pragma unroll
+      for (int i = 0; i < DN; ++i) {
+        va[0] = tr_frag<ROWB, 0>(vt + troff + i * 32); va[1] = tr_frag<ROWB, 1>(vt + troff + i * 32);
+        lds_wait();
+        if (ONES && i == DN - 1 && ones_lane) { va[0] = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u}; va[1] = va[0]; }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int f = 0; f < QW; ++f) Mma<bf16_t>::run(va[s], pb[s][f], ot[i][f]);
+      }
+    }
+  }
+
+  // ---- epilogue: normalise, store O rows, log-sum-exp (log2 domain)
+#pragma unroll
+  for (int f = 0; f < QW; ++f) {
+    float l;
+    if constexpr (ONES) {
+      l = __shfl(ot[DN - 1][f][LROW & 3], lq + 16 * (LROW >> 2), 64);     // row DH of O^T = sum_k P
+    } else {
+      l = l_run[f];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+    }
+    const float inv = 1.0f / l;
+    const int row = q0 + f * 16 + lq;
+    bf16_t* op = reinterpret_cast<bf16_t*>(p.O) + ((long)b * p.N + row) * p.ldo + (long)h * DH;
+#pragma unroll
+    for (int i = 0; i < DN; ++i) {
+      const int d0 = i * 16 + 4 * g;
+      if (d0 < DH) {
+        float v[4] = {ot[i][f][0] * inv, ot[i][f][1] * inv, ot[i][f][2] * inv, ot[i][f][3] * inv};
+        store4(op + d0, v);
+      }
+    }
+    if (p.LSE && g == 0) p.LSE[((long)b * p.H + h) * p.lse_stride + row] = m_run[f] + __builtin_amdgcn_logf(l);
+  }
+}
+
 // =============================================================================== dK / dV
 // TAIL: N is not a multiple of 64 (query masking)
 template <int DH, int KF, bool TAIL>
@@ -514,6 +824,29 @@ static int set_lds(K kern, int bytes) {
   return CL_OK;
 }
 
+int g_attn_variant = 0;    // probe hook: 1 = always the tile-synchronous kernels
+
+// ping-pong forward: N a multiple of 256 queries, whole 64-key tiles, at least half a chip of workgroups
+template <int DH>
+static bool launch_fwd_pp(const AttnFwdArgs& a, const void* V, long ldv, hipStream_t st, int* rc) {
+  if constexpr (DH == 40 || DH == 80) {
+    const int nqb = a.N / 256;
+    const long grid = (long)nqb * a.H * a.B;
+    if (g_attn_variant == 1 || a.N % 256 || a.Nkv % 64 || a.Nkv < 128 || grid < 128) return false;
+    constexpr int LDS = 3 * 2 * Geo<DH>::TILE + 16 * Geo<DH>::ROWB + 64;
+    static bool done = false;
+    if (!done) {
+      if (set_lds(&attn_fwd_pp_kernel<DH>, LDS)) { *rc = CL_ELAUNCH; return true; }
+      done = true;
+    }
+    const int remap = ((a.B * a.H) % 8 == 0) ? 1 : 0;
+    hipLaunchKernelGGL((attn_fwd_pp_kernel<DH>), dim3((unsigned)grid), dim3(512), LDS, st, a, V, ldv, nqb, remap);
+    *rc = (hipGetLastError() == hipSuccess) ? CL_OK : CL_ELAUNCH;
+    return true;
+  }
+  return false;
+}
+
 template <int DH, bool TAIL>
 static int launch_fwd_tr(const AttnFwdArgs& a, const void* V, long ldv, hipStream_t st) {
   constexpr int LDS = 2 * 2 * Geo<DH>::TILE + 64 + 16 * Geo<DH>::ROWB;
@@ -537,6 +870,8 @@ static int launch_fwd_tr(const AttnFwdArgs& a, const void* V, long ldv, hipStrea
 
 template <int DH>
 static int launch_fwd_tr_t(const AttnFwdArgs& a, const void* V, long ldv, hipStream_t st) {
+  int rc = CL_OK;
+  if (launch_fwd_pp<DH>(a, V, ldv, st, &rc)) return rc;
   return (a.Nkv % 64) ? launch_fwd_tr<DH, true>(a, V, ldv, st) : launch_fwd_tr<DH, false>(a, V, ldv, st);
 }
 

@@ -35,6 +35,7 @@ int cl_set_stream_workspace(void* stream, void* ptr, long bytes) {
   return gemm_set_stream_workspace(S(stream), ptr, bytes);
 }
 int cl_gemm_force_config(int cfg) { g_gemm_force_cfg = cfg; return CL_OK; }
+int cl_attention_force_variant(int v) { g_attn_variant = v; return CL_OK; }
 
 int cl_gemm(const cl_gemm_params* p, int dtype, void* stream) {
   if (!p) return CL_EINVAL;

@@ -59,6 +59,7 @@ _SIGS = {
     "cl_set_workspace": [_P, _L],
     "cl_set_stream_workspace": [_P, _P, _L],
     "cl_gemm_force_config": [_I],
+    "cl_attention_force_variant": [_I],
     "cl_gemm": [C.POINTER(GemmParams), _I, _P],
     "cl_lora_down": [_I, _P, _L, _P, _I, _P, _L, _I, _I, _P],
     "cl_lora_linear_fwd": [_I, _P, _L, _P, _P, _P, _L, _P, _I, _P, _L, _I, _P, _L, _I, _I, _I, _P],

@@ -1,0 +1,105 @@
+"""Attention kernels A/B on the GPU: correctness vs fp64 torch + HIP-event timing, for the tile-synchronous
+kernels (variant 1) and the ping-pong schedule (variant 0 = heuristic), through the C ABI.
+
+    python tests/tools/attn_bench.py [--bwd] [--out gpurun_out/attn_bench.json]
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from ctrlora_amd import hip   # noqa: E402
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def case(dh, N, Nkv, B, variants, bwd, check=True):
+    H = 8
+    inner = H * dh
+    g = torch.Generator().manual_seed(dh + N)
+    mk = lambda n, s=1.0: (torch.randn(B * n, inner, generator=g) * s).to(torch.bfloat16).cuda()
+    q, k, v, do = mk(N, 1.5), mk(Nkv, 1.5), mk(Nkv), mk(N)
+    scale = dh ** -0.5
+    rp = (N + 63) // 64 * 64
+    out = dict(shape=dict(dh=dh, N=N, Nkv=Nkv, B=B, H=H))
+    ref = None
+    if check:
+        split = lambda x, n: x.double().reshape(B, n, H, dh).permute(0, 2, 1, 3).requires_grad_(bwd)
+        qr, kr, vr = split(q, N), split(k, Nkv), split(v, Nkv)
+        s = torch.einsum("bhid,bhjd->bhij", qr, kr) * scale
+        orf = torch.einsum("bhij,bhjd->bhid", s.softmax(-1), vr)
+        back = lambda x, n: x.permute(0, 2, 1, 3).reshape(B * n, inner)
+        ref = dict(o=back(orf, N).detach(), lse=torch.logsumexp(s, -1).detach())
+        if bwd:
+            orf.backward(do.double().reshape(B, N, H, dh).permute(0, 2, 1, 3))
+            ref.update(dq=back(qr.grad, N), dk=back(kr.grad, Nkv), dv=back(vr.grad, Nkv))
+        del s, orf
+    flops_f = 4.0 * B * H * N * Nkv * dh
+    for name, var in variants:
+        hip.lib().cl_attention_force_variant(var)
+        o = torch.empty_like(q)
+        lse = torch.empty(B, H, rp, dtype=torch.float32, device="cuda")
+        fwd = lambda: hip.attention_fwd_v2(q, k, v, o, lse, B, H, N, Nkv, dh, scale)
+        fwd()
+        torch.cuda.synchronize()
+        r = {}
+        if ref is not None:
+            r["o_err"] = rel(o, ref["o"])
+            r["lse_err"] = rel(lse[:, :, :N] * 0.6931471805599453, ref["lse"])
+        ms = timeit(fwd)
+        r["fwd_us"] = round(ms * 1e3, 1)
+        r["fwd_tflops"] = round(flops_f / ms * 1e-9, 1)
+        if bwd:
+            delta = torch.empty_like(lse)
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            bw = lambda: hip.attention_bwd_v2(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, N, Nkv, dh, scale)
+            bw()
+            torch.cuda.synchronize()
+            if ref is not None:
+                r.update(dq_err=rel(dq, ref["dq"]), dk_err=rel(dk, ref["dk"]), dv_err=rel(dv, ref["dv"]))
+            ms = timeit(bw)
+            r["bwd_us"] = round(ms * 1e3, 1)
+            r["bwd_tflops"] = round(2.5 * flops_f / ms * 1e-9, 1)
+        out[name] = r
+    hip.lib().cl_attention_force_variant(0)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--bwd", action="store_true")
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    variants = [("sync", 1), ("pingpong", 0)]
+    res = []
+    for dh, N, Nkv, B in [(40, 4096, 4096, 8), (80, 1024, 1024, 8), (40, 4096, 4096, 32), (80, 1024, 1024, 32),
+                          (40, 1024, 1024, 2), (40, 256, 128, 8)]:
+        r = case(dh, N, Nkv, B, variants, args.bwd, check=(B <= 8))
+        print(json.dumps(r), flush=True)
+        res.append(r)
+    if args.out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        with open(args.out, "w") as f:
+            json.dump(res, f)
+
+
+if __name__ == "__main__":
+    main()
