@@ -59,6 +59,15 @@ class ControlNet(nn.Module, EngineHost):
         hint_layers.append(zero_module(conv_nd(dims, 256, model_channels, 3, padding=1)))
         self.input_hint_block = TimestepEmbedSequential(*hint_layers)
         self.middle_block_out = self.make_zero_conv(ch)
+        self._watch_state_loads()
+
+    def _on_state_loaded(self):
+        """Keep the executor (an optimizer may hold its flat master / gradient buffers): the bound trainable
+        Parameters wrote through to the masters during the load; frozen weights are re-packed in place."""
+        ex = self.__dict__.get("_exec")
+        if ex is not None:
+            ex.reload_frozen(self._executor_state())
+            self.__dict__["_bound_version"] = None
 
     def make_zero_conv(self, channels):
         return TimestepEmbedSequential(zero_module(conv_nd(self.dims, channels, channels, 1, padding=0)))
@@ -118,10 +127,14 @@ class ControlLDM(LatentDiffusion):
         return [self.control_model.executor()]
 
     def engine(self):
+        """The composed executor; rebuilt whenever one of the network roots replaced its executor (dtype change,
+        load_state_dict on the UNet, LoRA bank reloads)."""
+        unet_ex, ctrls = self.model.diffusion_model.executor(), self._control_executors()
         eng = self.__dict__.get("_engine")
-        if eng is None:
+        if (eng is None or eng.unet is not unet_ex or len(eng.controls) != len(ctrls)
+                or any(a is not b for a, b in zip(eng.controls, ctrls))):
             from ctrlora_amd.engine import CtrLoRAEngine
-            eng = CtrLoRAEngine.from_executors(self.model.diffusion_model.executor(), self._control_executors())
+            eng = CtrLoRAEngine.from_executors(unet_ex, ctrls)
             self.__dict__["_engine"] = eng
         return eng
 

@@ -64,6 +64,9 @@ class ControlNetInference(ControlNet):
     def invalidate_engine(self):
         self._bank_exec.clear()
 
+    def _on_state_loaded(self):
+        self._bank_exec.clear()      # inference banks carry no optimizer state: rebuilt lazily from bank_state()
+
     def bank_state(self, index: int):
         """State dict of bank `index` under ControlNetFinetune key names."""
         skip = ("loras_list.", "zero_convs_list.", "norms_list.", ".lora_layer.", ".conv_layer.", ".norm_layer.")
@@ -106,12 +109,6 @@ class ControlInferenceLDM(ControlLDM):
     def _executor_owners(self):
         return []
 
-    def engine(self):
-        eng = self.__dict__.get("_engine")
-        if eng is None or len(self.control_model._bank_exec) != self.control_model.lora_num:
-            self.__dict__.pop("_engine", None)
-            eng = super().engine()
-        return eng
 
     @torch.no_grad()
     def apply_model(self, x_noisy, t, conds, *args, **kwargs):

@@ -36,6 +36,9 @@ class ControlNetPretrain(ControlNet):
     def _executor_state(self):
         return {k: v for k, v in self.state_dict().items() if not k.startswith("loras_dict.")}
 
+    def _on_state_loaded(self):
+        self.invalidate_engine()
+
     def forward(self, hint, timesteps, context, **kwargs):
         return self._latent_forward(hint, timesteps, context)
 

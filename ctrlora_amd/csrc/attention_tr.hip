@@ -277,7 +277,10 @@ template <int N> __device__ __forceinline__ void lgkm_wait() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int DH>
+// LA = fragment-read lookahead of the matrix phase, in groups of 4 MFMAs (LDS latency under 8 reading waves is
+// several groups long); ABL = timing ablations for the probes (1: no exp2 in the vector phase, 2: no LDS reads in
+// the matrix phase -- results are then wrong by construction)
+template <int DH, int LA = 4, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnFwdArgs p, const void* __restrict__ V, long ldv,
                                                              int nqb, int remap) {
   using G = Geo<DH>;
@@ -363,31 +366,38 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnFwdArgs p, cons
   auto phaseM = [&](auto PREVc, uint32_t kt, uint32_t vt) {
     constexpr bool PREV = decltype(PREVc)::value;
     constexpr int NV = PREV ? DN : 0, NG = NV + 4;
-    u32x4_t va[2][2], ka[2][KSTEPS];
+    u32x4_t va[LA][2], ka[LA][KSTEPS];
+    auto cnt_of = [](int j) constexpr { return j < NV ? 4 : KSTEPS; };   // LDS instructions of group j
     auto read_group = [&](auto Jc) {
       constexpr int J = decltype(Jc)::value;
-      if constexpr (J < NV) {
-        va[J & 1][0] = tr_frag<ROWB, 0>(vt + troff + J * 32);
-        va[J & 1][1] = tr_frag<ROWB, 1>(vt + troff + J * 32);
+      if constexpr (ABL == 2) {
+        if constexpr (J < NV) { va[J % LA][0] = qf[0][0]; va[J % LA][1] = qf[1][0]; }
+        else if constexpr (J < NG) {
+#pragma unroll
+          for (int ks = 0; ks < KSTEPS; ++ks) ka[(J - NV) % LA][ks] = qf[0][ks];
+        }
+      } else if constexpr (J < NV) {
+        va[J % LA][0] = tr_frag<ROWB, 0>(vt + troff + J * 32);
+        va[J % LA][1] = tr_frag<ROWB, 1>(vt + troff + J * 32);
       } else if constexpr (J < NG) {
         constexpr int kf = J - NV;
         // chunks >= CPR read finite garbage that meets zeros of the Q fragment
         static_for<0, KSTEPS>([&](auto Kc) {
           constexpr int ks = decltype(Kc)::value;
-          ka[kf & 1][ks] = lds_read_b128_off<kf * 16 * ROWB + ks * 64>(kt + krow);
+          ka[kf % LA][ks] = lds_read_b128_off<kf * 16 * ROWB + ks * 64>(kt + krow);
         });
       }
     };
-    read_group(std::integral_constant<int, 0>{});
-    read_group(std::integral_constant<int, 1>{});
+    static_for<0, LA - 1>([&](auto Jc) { read_group(Jc); });
     static_for<0, NG>([&](auto Jc) {
       constexpr int J = decltype(Jc)::value;
-      // instructions of group J+1 may stay outstanding (LDS returns in order)
-      constexpr int next_cnt = (J + 1 >= NG) ? 0 : ((J + 1 < NV) ? 4 : KSTEPS);
-      lgkm_wait<next_cnt>();
+      read_group(std::integral_constant<int, J + LA - 1>{});       // its ring slot was consumed by group J-1
+      // groups J+1 .. J+LA-1 may stay outstanding (LDS returns in order)
+      constexpr int pending = [&]() constexpr { int n = 0; for (int k = J + 1; k < J + LA && k < NG; ++k) n += cnt_of(k); return n; }();
+      if constexpr (ABL != 2) lgkm_wait<(pending > 15 ? 15 : pending)>();
       if constexpr (J < NV) {
-        pin(va[J & 1][0]); pin(va[J & 1][1]);
-        u32x4_t a0 = va[J & 1][0], a1 = va[J & 1][1];
+        pin(va[J % LA][0]); pin(va[J % LA][1]);
+        u32x4_t a0 = va[J % LA][0], a1 = va[J % LA][1];
         if constexpr (ONES && J == DN - 1) {
           const uint32_t one2 = 0x3F803F80u;
           a0.x = ones_lane ? one2 : a0.x; a0.y = ones_lane ? one2 : a0.y; a0.z = ones_lane ? one2 : a0.z; a0.w = ones_lane ? one2 : a0.w;
@@ -400,16 +410,15 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnFwdArgs p, cons
       } else {
         constexpr int kf = J - NV;
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) pin(ka[kf & 1][ks]);
+        for (int ks = 0; ks < KSTEPS; ++ks) pin(ka[kf % LA][ks]);
 #pragma unroll
         for (int f = 0; f < QW; ++f) st[kf][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks)
 #pragma unroll
-          for (int f = 0; f < QW; ++f) Mma<bf16_t>::run(ka[kf & 1][ks], qf[f][ks], st[kf][f]);
+          for (int f = 0; f < QW; ++f) Mma<bf16_t>::run(ka[kf % LA][ks], qf[f][ks], st[kf][f]);
       }
       __builtin_amdgcn_sched_barrier(0);
-      read_group(std::integral_constant<int, J + 2>{});
     });
   };
 
@@ -448,7 +457,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnFwdArgs p, cons
       for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kf][f][r], sl2, -m_run[f]));
+          const float x = __builtin_fmaf(st[kf][f][r], sl2, -m_run[f]);
+          const float e = (ABL == 1) ? x : __builtin_amdgcn_exp2f(x);
           st[kf][f][r] = e;
           if constexpr (!ONES) ls += e;
         }
@@ -827,21 +837,35 @@ static int set_lds(K kern, int bytes) {
 int g_attn_variant = 0;    // probe hook: 1 = always the tile-synchronous kernels
 
 // ping-pong forward: N a multiple of 256 queries, whole 64-key tiles, at least half a chip of workgroups
+template <int DH, int LA, int ABL, bool ALONE = false>
+static int launch_fwd_pp_t(const AttnFwdArgs& a, const void* V, long ldv, hipStream_t st) {
+  // ALONE (probe): ask for more than half of the CU's LDS so that only one workgroup is resident per CU
+  constexpr int LDS = ALONE ? 96 * 1024 : 3 * 2 * Geo<DH>::TILE + 16 * Geo<DH>::ROWB + 64;
+  static bool done = false;
+  if (!done) {
+    if (set_lds(&attn_fwd_pp_kernel<DH, LA, ABL>, LDS)) return CL_ELAUNCH;
+    done = true;
+  }
+  const int nqb = a.N / 256;
+  const long grid = (long)nqb * a.H * a.B;
+  const int remap = ((a.B * a.H) % 8 == 0) ? 1 : 0;
+  hipLaunchKernelGGL((attn_fwd_pp_kernel<DH, LA, ABL>), dim3((unsigned)grid), dim3(512), LDS, st, a, V, ldv, nqb, remap);
+  CL_CHECK_LAUNCH();
+  return CL_OK;
+}
+
 template <int DH>
 static bool launch_fwd_pp(const AttnFwdArgs& a, const void* V, long ldv, hipStream_t st, int* rc) {
   if constexpr (DH == 40 || DH == 80) {
-    const int nqb = a.N / 256;
-    const long grid = (long)nqb * a.H * a.B;
+    const long grid = (long)(a.N / 256) * a.H * a.B;
     if (g_attn_variant == 1 || a.N % 256 || a.Nkv % 64 || a.Nkv < 128 || grid < 128) return false;
-    constexpr int LDS = 3 * 2 * Geo<DH>::TILE + 16 * Geo<DH>::ROWB + 64;
-    static bool done = false;
-    if (!done) {
-      if (set_lds(&attn_fwd_pp_kernel<DH>, LDS)) { *rc = CL_ELAUNCH; return true; }
-      done = true;
+    switch (g_attn_variant) {          // 2..4: A/B and ablation probes (tests/tools/attn_bench.py)
+      case 2: *rc = launch_fwd_pp_t<DH, 2, 0>(a, V, ldv, st); break;
+      case 3: *rc = launch_fwd_pp_t<DH, 4, 1>(a, V, ldv, st); break;
+      case 4: *rc = launch_fwd_pp_t<DH, 4, 2>(a, V, ldv, st); break;
+      case 5: *rc = launch_fwd_pp_t<DH, 4, 0, true>(a, V, ldv, st); break;
+      default: *rc = launch_fwd_pp_t<DH, 4, 0>(a, V, ldv, st); break;
     }
-    const int remap = ((a.B * a.H) % 8 == 0) ? 1 : 0;
-    hipLaunchKernelGGL((attn_fwd_pp_kernel<DH>), dim3((unsigned)grid), dim3(512), LDS, st, a, V, ldv, nqb, remap);
-    *rc = (hipGetLastError() == hipSuccess) ? CL_OK : CL_ELAUNCH;
     return true;
   }
   return false;

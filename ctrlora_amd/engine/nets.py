@@ -64,6 +64,13 @@ class _Builder:
         self.need_bwd, self.tr = need_bwd, trainables
         self.linears: List[LinearW] = []
         self.norms: List[NormW] = []
+        self.frozen: list = []        # (packed object, loader(sd)) for reload_frozen()
+
+    def reload_frozen(self, sd: Dict[str, torch.Tensor]):
+        """Re-pack every frozen tensor from `sd` (same key names) into the existing packed buffers."""
+        self.sd = sd
+        for fn in self.frozen:
+            fn()
 
     def _g(self, name):
         return self.sd[self.prefix + name]
@@ -81,11 +88,14 @@ class _Builder:
             tB = self.tr.declare(self.prefix + un, self._g(un).shape)
             L.attach_lora(tA, tB, self.device)
         self.linears.append(L)
+        self.frozen.append(lambda: L.load(self._g(name + ".weight"),
+                                          self._g(name + ".bias") if self._has(name + ".bias") else None))
         return L
 
     def fused(self, names: Sequence[str]) -> LinearW:
         W = torch.cat([self._g(n + ".weight") for n in names], dim=0)
         L = LinearW(W, None, self.dtype, self.device, self.need_bwd)
+        self.frozen.append(lambda: L.load(torch.cat([self._g(n + ".weight") for n in names], dim=0), None))
         return L
 
     def zero_conv(self, name: str) -> LinearW:
@@ -94,11 +104,15 @@ class _Builder:
             tW = self.tr.declare(self.prefix + name + ".weight", self._g(name + ".weight").shape)
             tb = self.tr.declare(self.prefix + name + ".bias", self._g(name + ".bias").shape)
             L.attach_trainable_weight(tW, tb)
+        else:
+            self.frozen.append(lambda: L.load(self._g(name + ".weight"), self._g(name + ".bias")))
         self.linears.append(L)
         return L
 
     def conv3(self, name: str) -> Conv3W:
-        return Conv3W(self._g(name + ".weight"), self._g(name + ".bias"), self.dtype, self.device, self.need_bwd)
+        cw = Conv3W(self._g(name + ".weight"), self._g(name + ".bias"), self.dtype, self.device, self.need_bwd)
+        self.frozen.append(lambda: cw.load(self._g(name + ".weight"), self._g(name + ".bias")))
+        return cw
 
     def norm(self, name: str) -> NormW:
         w = NormW(self._g(name + ".weight"), self._g(name + ".bias"), self.device)
@@ -106,6 +120,7 @@ class _Builder:
             w.attach(self.tr.declare(self.prefix + name + ".weight", self._g(name + ".weight").shape),
                      self.tr.declare(self.prefix + name + ".bias", self._g(name + ".bias").shape))
         self.norms.append(w)
+        self.frozen.append(lambda: w.load(self._g(name + ".weight"), self._g(name + ".bias")))
         return w
 
     def res(self, p: str, cin: int, cout: int) -> ResBlockE:
@@ -288,8 +303,12 @@ def _encoder_layers(b: _Builder, cfg: NetCfg, lora: bool, after_block=None):
 
 class ControlNetE:
     def __init__(self, sd, cfg: NetCfg, dtype, device, prefix: str = "", need_bwd: bool = True,
-                 trainables: Optional[TrainableSet] = None):
+                 trainables: Optional[TrainableSet] = None, layout_only: bool = False):
+        """layout_only: build the flat trainable layout (offsets, backward-ordered stage spans, the stage-completion
+        hook) without packing anything for the kernels -- what the data-parallel exchange needs; usable without a
+        GPU (the multi-process gloo tests).  Such an executor cannot run: fwd / bwd raise."""
         self.cfg, self.dtype, self.device = cfg, dtype, device
+        self.layout_only = layout_only
         self.tr = trainables if trainables is not None else TrainableSet()
         b = _Builder(sd, prefix, dtype, device, need_bwd, self.tr)
         self.lora = (prefix + "time_embed.0.lora_layer.down.weight") in sd
@@ -320,6 +339,18 @@ class ControlNetE:
         self.time_span = span(time_items)
         self.on_stage_done = None    # callable(start, end): that slice of flat_grad is final (DP overlap hook)
         self._b = b
+        if not layout_only:
+            self.repack()
+
+    def backward_stage_order(self):
+        """Spans of flat_grad in the order the backward pass finalises them (what `_done` reports)."""
+        nb = len(self.blocks)
+        return [self.stage_spans[nb]] + [self.stage_spans[k] for k in range(nb - 1, -1, -1)] + [self.time_span]
+
+    def reload_frozen(self, sd):
+        """module.load_state_dict() happened after this executor was built: refresh the packed frozen weights in
+        place (the trainables are views of the flat masters the Parameters write through) and re-pack."""
+        self._b.reload_frozen({k: v for k, v in sd.items()})
         self.repack()
 
     def repack(self):
@@ -359,10 +390,15 @@ class ControlNetE:
         self.fwd_zero(hs, sinks, scales, weight)
         return rec
 
+    def _runnable(self):
+        if self.layout_only:
+            raise RuntimeError("layout-only ControlNetE (no packed weights): it describes the trainable buffer, it cannot run")
+
     def fwd_trunk(self, ctx: Ctx, hint_tok, t, c, B, H, W, kv=None):
         """Encoder + middle block WITHOUT the zero convs (which need the UNet's skip tensors as residuals):
         this part is independent of the UNet encoder and may run concurrently with it on another stream.
         Returns (record or None, [h_k]) -- the 13 stage outputs the zero convs consume."""
+        self._runnable()
         semb, tsv = self.time.fwd(ctx, t)
         env = _Env(B, H, W, semb, c, c.shape[0] // B)
         env.kv = kv

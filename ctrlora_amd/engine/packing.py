@@ -92,6 +92,18 @@ class LinearW:
         self.tb: Optional[Trainable] = None
         self.dtype = dtype
 
+    def load(self, W: torch.Tensor, bias: Optional[torch.Tensor]):
+        """Refresh the packed copies of a FROZEN weight in place (module.load_state_dict after the executor was
+        built: the optimizer keeps pointing at the same executor / flat buffers)."""
+        W = W.reshape(W.shape[0], -1).to(device=self.W.device, dtype=torch.float32)
+        assert tuple(W.shape) == (self.N, self.K)
+        self.W.copy_(W)
+        if self.Wt is not None:
+            self.Wt.copy_(W.t())
+        if bias is not None and self.bias is not None and self.tb is None:
+            self.bias.copy_(bias.to(device=self.W.device, dtype=torch.float32))
+        self.invalidate_geglu()
+
     # ---- GEGLU-fused projection (no-grad forwards): rows permuted so that every 160-column tile of the
     # product holds 80 value columns followed by their 80 gate columns (csrc/gemm.h: ACT_GEGLU)
     def geglu_ok(self) -> bool:
@@ -145,18 +157,25 @@ class Conv3W:
     """3x3 conv in implicit-GEMM form; channels padded to multiples of 32 where needed."""
 
     def __init__(self, W: torch.Tensor, bias: torch.Tensor, dtype, device, need_bwd: bool):
-        W = W.to(device=device, dtype=torch.float32)
         O, I = W.shape[0], W.shape[1]
         self.O, self.I = O, I
         self.Op, self.Ip = rup(O, 32), rup(I, 32)
+        self.Wp = torch.empty(self.Op, 9 * self.Ip, dtype=dtype, device=device)
+        self.Wd = torch.empty(self.Ip, 9 * self.Op, dtype=dtype, device=device) if need_bwd else None
+        self.bias = torch.zeros(self.Op, dtype=torch.float32, device=device)
+        self.load(W, bias)
+
+    def load(self, W: torch.Tensor, bias: torch.Tensor):
+        """(Re)pack in place: [O][ky][kx][I] and the tap-flipped data-gradient form [I][2-ky][2-kx][O]."""
+        device = self.Wp.device
+        W = W.to(device=device, dtype=torch.float32)
+        assert W.shape[0] == self.O and W.shape[1] == self.I
         Wpad = torch.zeros(self.Op, self.Ip, 3, 3, dtype=torch.float32, device=device)
-        Wpad[:O, :I] = W
-        self.Wp = Wpad.permute(0, 2, 3, 1).reshape(self.Op, 9 * self.Ip).to(dtype).contiguous()
-        self.Wd = (Wpad.flip(2, 3).permute(1, 2, 3, 0).reshape(self.Ip, 9 * self.Op).to(dtype).contiguous()
-                   if need_bwd else None)
-        b = torch.zeros(self.Op, dtype=torch.float32, device=device)
-        b[:O] = bias.to(device=device, dtype=torch.float32)
-        self.bias = b
+        Wpad[:self.O, :self.I] = W
+        self.Wp.copy_(Wpad.permute(0, 2, 3, 1).reshape(self.Op, 9 * self.Ip))
+        if self.Wd is not None:
+            self.Wd.copy_(Wpad.flip(2, 3).permute(1, 2, 3, 0).reshape(self.Ip, 9 * self.Op))
+        self.bias[:self.O] = bias.to(device=device, dtype=torch.float32)
 
 
 class NormW:
@@ -168,6 +187,11 @@ class NormW:
 
     def attach(self, tg: Trainable, tb: Trainable):
         self.tg, self.tb = tg, tb
+
+    def load(self, gamma, beta):
+        if self.tg is None:      # trainable norms alias the flat masters (updated through the bound Parameters)
+            self.gamma.copy_(gamma.to(device=self.gamma.device, dtype=torch.float32))
+            self.beta.copy_(beta.to(device=self.beta.device, dtype=torch.float32))
 
     def repack(self):
         if self.tg is not None:

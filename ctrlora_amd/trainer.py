@@ -72,9 +72,23 @@ class Trainer:
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             backend = "nccl" if self.device.type == "cuda" else "gloo"
             dist.init_process_group(backend, **({"device_id": self.device} if backend == "nccl" else {}))
+        # what Lightning's DDP wrapper does at wrap time: every rank starts from rank 0's parameters and buffers
+        # (the LoRA down-projections are drawn from an unseeded N(0, 1/r) in every process)
+        self.broadcast_module_state(model)
         if hasattr(model, "control_model") and hasattr(model.control_model, "executor") and self.device.type == "cuda":
             from ctrlora_amd.parallel import GradAllReduce
             model.dp = GradAllReduce([model.control_model.executor()])
+
+    @staticmethod
+    def broadcast_module_state(model, src: int = 0):
+        """In-place broadcast of all parameters and buffers from rank `src` (no-op without a process group)."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        with torch.no_grad():
+            for t in list(model.parameters()) + list(model.buffers()):
+                if t.numel():
+                    dist.broadcast(t.data, src)
 
     def save_checkpoint(self, path):
         if not self.is_global_zero:
@@ -84,10 +98,14 @@ class Trainer:
         torch.save({"state_dict": self.model.state_dict(), "global_step": self.global_step,
                     "epoch": self.current_epoch, "optimizer_states": [opt_state]}, path)
 
-    def _restore(self, ckpt_path):
+    def _restore_model(self, ckpt_path):
+        """Model part of a resume: BEFORE the executors / optimizer are built (they snapshot the weights)."""
         ck = torch.load(ckpt_path, map_location="cpu", weights_only=False)
         self.model.load_state_dict(ck["state_dict"], strict=True)
         self.global_step, self.current_epoch = int(ck.get("global_step", 0)), int(ck.get("epoch", 0))
+        return ck
+
+    def _restore_optimizer(self, ck):
         st = (ck.get("optimizer_states") or [None])[0]
         if st is not None and hasattr(self.optimizer, "load_state_dict"):
             self.optimizer.load_state_dict(st)
@@ -100,11 +118,12 @@ class Trainer:
         model.to(self.device).train()
         if hasattr(model, "set_engine_dtype"):
             model.set_engine_dtype(self.engine_dtype())
+        ck = self._restore_model(ckpt_path) if ckpt_path else None
         self._init_distributed(model)
         opt = model.configure_optimizers()
         self.optimizer = opt[0] if isinstance(opt, (list, tuple)) else opt
-        if ckpt_path:
-            self._restore(ckpt_path)
+        if ck is not None:
+            self._restore_optimizer(ck)
         acc = self.accumulate_grad_batches
         dp = getattr(model, "dp", None)
         self.optimizer.zero_grad()

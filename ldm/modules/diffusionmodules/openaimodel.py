@@ -77,6 +77,15 @@ class EngineHost:
     def invalidate_engine(self):
         self.__dict__.pop("_exec", None)
 
+    def _watch_state_loads(self):
+        """The executor snapshots and packs the module's weights on first use; `load_state_dict` on this module or
+        on any parent (the gradio app swaps sd / cn checkpoints at run time, trainers resume) must not leave it on
+        the old weights."""
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._on_state_loaded())
+
+    def _on_state_loaded(self):
+        self.invalidate_engine()
+
     def _device(self):
         return next(self.parameters()).device
 
@@ -172,6 +181,7 @@ class UNetModel(nn.Module, EngineHost):
                 self.output_blocks.append(TimestepEmbedSequential(*layers))
         self.out = nn.Sequential(normalization(ch), nn.SiLU(),
                                  zero_module(conv_nd(dims, model_channels, out_channels, 3, padding=1)))
+        self._watch_state_loads()
 
     # ---- execution
     def executor(self):

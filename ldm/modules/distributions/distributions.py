@@ -14,7 +14,13 @@ class DiagonalGaussianDistribution(object):
             self.var = self.std = torch.zeros_like(self.mean)
 
     def sample(self):
-        # the reference draws on the CPU generator and copies to the device (:35-37)
+        # the reference draws on the CPU generator and copies to the device (:35-37).  Inside a hipGraph capture
+        # (the graphed DDIM loop re-samples the hint posterior every denoise step) a host draw + pageable
+        # host-to-device copy is illegal -- and would replay ONE frozen noise tensor; there the draw comes from the
+        # device generator, whose Philox offset torch advances on every replay: same distribution, fresh noise
+        # per step, a different random stream than the reference's (documented in INTEGRATION.md).
+        if self.mean.is_cuda and torch.cuda.is_current_stream_capturing():
+            return self.mean + self.std * torch.randn(self.mean.shape, device=self.mean.device, dtype=self.mean.dtype)
         return self.mean + self.std * torch.randn(self.mean.shape).to(device=self.parameters.device)
 
     def mode(self):

@@ -480,3 +480,58 @@ def test_lora_modules_standalone_on_gpu():
     assert rel_l2(y, g["y"]) < 1e-5                                  # vs the real reference's forward
     lin._fuse_lora()
     assert rel_l2(lin(g["x"].cuda()), g["y_fused"]) < 1e-5
+
+
+def test_graphed_ddim_with_image_hint_resamples_the_posterior_on_the_device():
+    """DDIMSampler's hipGraph path with a real (3-channel) condition image and a non-Identity first stage: the
+    VAE posterior of the hint is encoded once per run, but SAMPLED in every apply_model call (reference:
+    cldm_ctrlora_finetune.py:76-77 inside the denoising loop).  Inside the captured step the draw must come from
+    the device generator (a host draw + H2D copy is illegal during capture and would freeze one noise tensor):
+    consecutive replays see different hint latents, and the loop completes with finite samples."""
+    _need_gpu()
+    import bench
+    from cldm.ddim_hacked import DDIMSampler
+    from ldm.modules.distributions.distributions import DiagonalGaussianDistribution
+    from oracle import arch
+    cfg = arch.TINY
+    model = bench.build_model("inference/ctrlora_sd15_rank128_1lora.yaml", 0, tiny=True).cuda().eval()
+    model.set_engine_dtype(torch.float32)
+
+    class StubVAE(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv = torch.nn.Conv2d(3, 8, 8, stride=8)
+            self.calls = 0
+
+        def encode(self, x):
+            self.calls += 1
+            return DiagonalGaussianDistribution(self.conv(x))
+
+    vae = StubVAE().cuda()
+    model.first_stage_model = vae
+    seen = []
+    orig = model.get_first_stage_encoding
+
+    def spy(post):
+        z = orig(post)
+        seen.append(z)
+        return z
+
+    model.get_first_stage_encoding = spy
+    B, H, S = 2, 16, 6
+    g = torch.Generator().manual_seed(3)
+    img = torch.randn(B, 3, 8 * H, 8 * H, generator=g).cuda()
+    cond = {"c_concat": [img], "c_crossattn": [torch.randn(B, 77, cfg.context_dim, generator=g).cuda()]}
+    unc = {"c_concat": [img], "c_crossattn": [torch.randn(B, 77, cfg.context_dim, generator=g).cuda()]}
+    snaps = []
+    sampler = DDIMSampler(model)
+    assert sampler.use_graph
+    x, _ = sampler.sample(S, B, (4, H, H), cond, verbose=False, eta=0.0, unconditional_guidance_scale=7.5,
+                          unconditional_conditioning=unc, x_T=torch.randn(B, 4, H, H, generator=g).cuda(),
+                          img_callback=lambda p0, i: snaps.append(seen[-1].clone()))
+    assert torch.isfinite(x).all()
+    assert vae.calls == 1                                   # encoded once per run (hint cache)
+    assert len(snaps) == S
+    # snaps[1:] are the static hint-latent buffer of the captured step after each replay: fresh noise every time
+    for a, b in zip(snaps[1:-1], snaps[2:]):
+        assert not torch.equal(a, b)

@@ -141,3 +141,90 @@ def test_banked_grad_exchange_two_ranks_different_tasks_gloo():
         p.join(60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+# ------------------------------------------------------------------ DP-N == one large batch, on the real layout
+
+def _dp_equiv_worker(rank, world, port, q):
+    """Each rank: the oracle's gradients of ITS half of the batch, scattered into the engine's real flat gradient
+    buffer (ControlNetE layout: backward-ordered stages), stage completions reported in backward order to the real
+    GradAllReduce, then AdamW with grad_scale = 1 / world on the flat master buffer."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    try:
+        from ctrlora_amd.engine import ControlNetE, NetCfg
+        from ctrlora_amd.parallel import GradAllReduce
+        from ctrlora_amd.trainer import Trainer
+        from oracle import arch, ref_model as R
+        from tests.golden.make_golden import inputs_for
+        cfg = arch.TINY
+        ncfg = NetCfg(cfg.in_channels, cfg.out_channels, cfg.model_channels, cfg.channel_mult, cfg.num_res_blocks,
+                      cfg.attention_resolutions, cfg.num_heads, cfg.context_dim)
+        # ranks start from DIFFERENT trainables (unseeded LoRA init in every process) ...
+        sd_cn = arch.make_state(arch.controlnet_shapes(cfg), 40 + rank)
+        sd_un = arch.make_state(arch.unet_shapes(cfg), 40)
+        holder = torch.nn.ParameterDict({k.replace(".", "_"): torch.nn.Parameter(v.clone()) for k, v in sd_cn.items()})
+        # ... until the trainer's start-up broadcast makes them rank 0's
+        Trainer.broadcast_module_state(holder)
+        sd_cn = {k: holder[k.replace(".", "_")].detach().clone() for k in sd_cn}
+        ref0 = arch.make_state(arch.controlnet_shapes(cfg), 40)
+        same_start = all(torch.equal(sd_cn[k], ref0[k]) for k in sd_cn)
+        ex = ControlNetE(sd_cn, ncfg, torch.float32, torch.device("cpu"), layout_only=True)
+        dp = GradAllReduce([ex], bucket_bytes=64 << 10)
+        B = 2 * world
+        inp = inputs_for(cfg, B, 8, 77)
+        sl = slice(rank * 2, rank * 2 + 2)
+        sched = R.make_schedule()
+
+        def grads_of(rows):
+            sd = {k: v.clone().requires_grad_(arch.is_trainable(k)) for k, v in sd_cn.items()}
+            loss, _ = R.p_losses(sd, sd_un, cfg, sched, inp["z"][rows], inp["t"][rows], inp["ctx"][rows],
+                                 inp["hint_z"][rows], inp["noise"][rows])
+            loss.backward()
+            return float(loss), {k: v.grad for k, v in sd.items() if v.grad is not None}
+
+        loss_local, g_local = grads_of(sl)
+        for t in ex.tr.items:
+            t.grad.copy_(g_local[t.name])
+        for s, e in ex.backward_stage_order():        # what ControlNetE.bwd reports, in that order
+            ex.on_stage_done(s, e)
+        dp.on_backward_done()
+        dp.wait()
+        loss_full, g_full = grads_of(slice(0, B))
+        worst = max(float((t.grad / world - g_full[t.name]).norm() / (g_full[t.name].norm() + 1e-30)) for t in ex.tr.items)
+        # optimizer step on the flat master with the averaging folded into grad_scale
+        p_new, _, _ = R.adamw_step(ex.tr.flat, ex.tr.flat_grad / world, torch.zeros_like(ex.tr.flat),
+                                   torch.zeros_like(ex.tr.flat), 1, 1e-3)
+        gathered = [torch.empty_like(p_new) for _ in range(world)]
+        dist.all_gather(gathered, p_new)
+        in_sync = all(torch.equal(gathered[0], g) for g in gathered)
+        q.put((rank, same_start, worst, dp.launches, in_sync, len(ex.tr.items)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_dp2_equals_single_large_batch_on_the_engine_layout_gloo():
+    """SURVEY.md section 4 'distributed': DP-N loss / gradients == one process with the N-times larger batch.  Two
+    gloo ranks, the engine's real flat-buffer layout and stage spans, the real GradAllReduce (several buckets), the
+    trainer's start-up broadcast; the local backward is the oracle's (no GPU here).  After the exchange every rank
+    holds world * (full-batch gradient), and the AdamW'd masters are bit-identical across ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_equiv_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=540) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, same_start, worst, launches, in_sync, n in res:
+        assert same_start, "start-up broadcast did not equalise the trainables"
+        assert n == 246
+        assert worst < 2e-5, (rank, worst)
+        assert launches >= 2
+        assert in_sync

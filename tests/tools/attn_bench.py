@@ -83,16 +83,22 @@ def case(dh, N, Nkv, B, variants, bwd, check=True):
     return out
 
 
+NAMES = {0: "pingpong", 1: "sync", 2: "pp_la2", 3: "pp_noexp(ablation)", 4: "pp_nolds(ablation)", 5: "pp_1wg_per_cu"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--bwd", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--variants", default="1,0", help="comma list of cl_attention_force_variant values")
+    ap.add_argument("--shapes", default="40,4096,4096,8;80,1024,1024,8;40,4096,4096,32;80,1024,1024,32;40,1024,1024,2;40,256,128,8")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
-    variants = [("sync", 1), ("pingpong", 0)]
+    variants = [(NAMES.get(int(v), f"v{v}"), int(v)) for v in args.variants.split(",")]
     res = []
-    for dh, N, Nkv, B in [(40, 4096, 4096, 8), (80, 1024, 1024, 8), (40, 4096, 4096, 32), (80, 1024, 1024, 32),
-                          (40, 1024, 1024, 2), (40, 256, 128, 8)]:
-        r = case(dh, N, Nkv, B, variants, args.bwd, check=(B <= 8))
+    for sh in args.shapes.split(";"):
+        dh, N, Nkv, B = (int(x) for x in sh.split(","))
+        r = case(dh, N, Nkv, B, variants, args.bwd, check=(B <= 8 and not args.no_check))
         print(json.dumps(r), flush=True)
         res.append(r)
     if args.out:
