@@ -39,6 +39,10 @@ template <int DH> struct Geo {
   static constexpr int TI = 64 * CPR / 64;       // DMA instructions per tile (= CPR)
 };
 
+// Plain fp32 VALU instructions issue at 4 cycles per wave64 on gfx950 (measured: the softmax / dS arithmetic, not
+// the matrix pipe, bounds these kernels); v_pk_{fma,mul,add}_f32 do two lanes' worth per issue slot.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
 template <int IMM> __device__ __forceinline__ u32x2_t tr_read(uint32_t addr) {
   u32x2_t v;
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM) : "memory");
@@ -456,11 +460,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnFwdArgs p, cons
 #pragma unroll
       for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float x = __builtin_fmaf(st[kf][f][r], sl2, -m_run[f]);
-          const float e = (ABL == 1) ? x : __builtin_amdgcn_exp2f(x);
-          st[kf][f][r] = e;
-          if constexpr (!ONES) ls += e;
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const f32x2_t x = f32x2_t{st[kf][f][2 * h2], st[kf][f][2 * h2 + 1]} * sl2 - m_run[f];   // v_pk_fma_f32
+          const float e0 = (ABL == 1) ? x.x : __builtin_amdgcn_exp2f(x.x);
+          const float e1 = (ABL == 1) ? x.y : __builtin_amdgcn_exp2f(x.y);
+          st[kf][f][2 * h2] = e0; st[kf][f][2 * h2 + 1] = e1;
+          if constexpr (!ONES) ls += e0 + e1;
         }
       if constexpr (!ONES) l_run[f] += ls;
     }
@@ -653,13 +658,21 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_tr_kerne
           f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < KSTEPS; ++ks) { Mma<bf16_t>::run(qa[ks], kb[kf][ks], sc); Mma<bf16_t>::run(da[ks], vb[kf][ks], dp); }
+          // P = exp2(s * sl2 - lse), dS = P (dP - delta); the d_head^-0.5 factor of dS is applied once to dK in the
+          // epilogue (linear).  Two rows per packed instruction.
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], sl2, -lv[r]));
-            float dsv = pr * (dp[r] - dv[r]) * p.scale;
-            if constexpr (TAIL) { if (qrow + r >= p.N) { pr = 0.f; dsv = 0.f; } }   // lse / delta pads may hold NaN
-            ps[kf][qf][r] = pr;
-            ds[kf][qf][r] = dsv;
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const f32x2_t s2 = {sc[2 * h2], sc[2 * h2 + 1]}, l2 = {lv[2 * h2], lv[2 * h2 + 1]};
+            const f32x2_t x = s2 * sl2 - l2;
+            f32x2_t pr = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+            const f32x2_t dd = f32x2_t{dp[2 * h2], dp[2 * h2 + 1]} - f32x2_t{dv[2 * h2], dv[2 * h2 + 1]};
+            f32x2_t dsv = pr * dd;
+            if constexpr (TAIL) {   // lse / delta pads may hold NaN
+              if (qrow + 2 * h2 >= p.N) { pr.x = 0.f; dsv.x = 0.f; }
+              if (qrow + 2 * h2 + 1 >= p.N) { pr.y = 0.f; dsv.y = 0.f; }
+            }
+            ps[kf][qf][2 * h2] = pr.x; ps[kf][qf][2 * h2 + 1] = pr.y;
+            ds[kf][qf][2 * h2] = dsv.x; ds[kf][qf][2 * h2 + 1] = dsv.y;
           }
         }
       }
@@ -693,7 +706,7 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_tr_kerne
       for (int i = 0; i < DN; ++i) {
         const int d0 = i * 16 + 4 * g;
         if (d0 < DH) {
-          float a[4] = {dkt[kf][i][0], dkt[kf][i][1], dkt[kf][i][2], dkt[kf][i][3]};
+          float a[4] = {dkt[kf][i][0] * p.scale, dkt[kf][i][1] * p.scale, dkt[kf][i][2] * p.scale, dkt[kf][i][3] * p.scale};
           float c[4] = {dvt[kf][i][0], dvt[kf][i][1], dvt[kf][i][2], dvt[kf][i][3]};
           store4(dkp + d0, a);
           store4(dvp + d0, c);
@@ -782,11 +795,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_tr_kernel(AttnBwdArgs p) {
           f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < KSTEPS; ++ks) { Mma<bf16_t>::run(ka[ks], qb[f][ks], sc); Mma<bf16_t>::run(va[ks], ob[f][ks], dp); }
+          // dS^T = P (dP - delta), two keys per packed instruction; d_head^-0.5 goes onto dQ in the epilogue
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float dsv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], sl2, -lse_q[f])) * (dp[r] - dlt_q[f]) * p.scale;
-            if constexpr (TAIL) { if (kv0 + kf * 16 + 4 * g + r >= p.Nkv) dsv = 0.f; }
-            dst[f][kf][r] = dsv;
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const f32x2_t x = f32x2_t{sc[2 * h2], sc[2 * h2 + 1]} * sl2 - lse_q[f];
+            const f32x2_t pr = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+            f32x2_t dsv = pr * (f32x2_t{dp[2 * h2], dp[2 * h2 + 1]} - dlt_q[f]);
+            if constexpr (TAIL) {
+              if (kv0 + kf * 16 + 4 * g + 2 * h2 >= p.Nkv) dsv.x = 0.f;
+              if (kv0 + kf * 16 + 4 * g + 2 * h2 + 1 >= p.Nkv) dsv.y = 0.f;
+            }
+            dst[f][kf][2 * h2] = dsv.x; dst[f][kf][2 * h2 + 1] = dsv.y;
           }
         }
       }
@@ -817,9 +836,435 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_tr_kernel(AttnBwdArgs p) {
       for (int i = 0; i < DN; ++i) {
         const int d0 = i * 16 + 4 * g;
         if (d0 < DH) {
-          float a[4] = {dqt[f][i][0], dqt[f][i][1], dqt[f][i][2], dqt[f][i][3]};
+          float a[4] = {dqt[f][i][0] * p.scale, dqt[f][i][1] * p.scale, dqt[f][i][2] * p.scale, dqt[f][i][3] * p.scale};
           store4(dqp + d0, a);
         }
+      }
+    }
+  }
+}
+
+// =============================================================================== backward, ping-pong schedule
+// Same two-groups-one-phase-apart structure as attn_fwd_pp_kernel, for the two backward kernels.  The unit of a
+// phase is a HALF tile (32 of the 64 staged rows), which keeps the fp32 score registers at 32 per wave:
+//   dK/dV: wave owns 16 KF keys (K, V fragments in registers), tiles {Q, dO, lse, delta} of 64 queries
+//     M(h) = [dV^T += dO^T P, dK^T += Q^T dS of half h-1 (transpose reads)] + [S = Q K^T, dP = dO V^T of half h]
+//     V(h) = P = exp2(S sl2 - lse), dS = P (dP - delta)  (packed fp32), bf16 fragments for the next M
+//   dQ   : wave owns 16 QF queries (Q, dO fragments, lse, delta in registers), tiles {K, V} of 64 keys
+//     M(h) = [dQ^T += K^T dS^T of half h-1] + [S^T = K Q^T, dP^T = V dO^T of half h];  V(h) = dS^T
+// The d_head^-0.5 factor of dS is applied once, to dK / dQ, in the epilogue (linear).  3-stage tile ring: tile t is
+// read in intervals 4t .. 4t+5, tile t+3 is issued at the start of interval 4t+6 into its stage and drained (vmcnt 0)
+// before the barrier that ends interval 4t+7.  lse / delta blocks live behind the zeroed slack, so fragment
+// over-reads (chunks >= CPR meet zero operand entries) never see non-finite bit patterns.
+template <int DH, int KF, int LA = 3>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(AttnBwdArgs p, int nkb, int remap) {
+  using G = Geo<DH>;
+  constexpr int CPR = G::CPR, KSTEPS = G::KSTEPS, DN = G::DN, ROWB = G::ROWB, TILE = G::TILE;
+  constexpr int STAGE = 2 * TILE, SLACK = 16 * ROWB + 64, LOFF = 3 * STAGE + SLACK;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  const int g = lane >> 4, lq = lane & 15;
+  int bh, kbi;
+  {
+    const int id = blockIdx.x;
+    if (remap) { const int xcd = id & 7, slot = id >> 3; bh = xcd + 8 * (slot / nkb); kbi = slot - (slot / nkb) * nkb; }
+    else { bh = id / nkb; kbi = id - bh * nkb; }
+  }
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int kv_w = kbi * (128 * KF) + wave * (16 * KF);
+  const float sl2 = p.scale * 1.4426950408889634f;
+
+  for (int i = tid; i < SLACK / 4; i += 512) reinterpret_cast<uint32_t*>(smem + 3 * STAGE)[i] = 0u;
+
+  u32x4_t kb[KF][KSTEPS], vb[KF][KSTEPS];
+#pragma unroll
+  for (int kf = 0; kf < KF; ++kf) {
+    const int kr = kv_w + kf * 16 + lq;
+    const char* kp = (const char*)p.K + (((long)b * p.Nkv + kr) * p.ldk + (long)h * DH) * 2;
+    const char* vp = (const char*)p.V + (((long)b * p.Nkv + kr) * p.ldv + (long)h * DH) * 2;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int c = 4 * ks + g;
+      kb[kf][ks] = (c < CPR) ? *reinterpret_cast<const u32x4_t*>(kp + c * 16) : u32x4_t{0u, 0u, 0u, 0u};
+      vb[kf][ks] = (c < CPR) ? *reinterpret_cast<const u32x4_t*>(vp + c * 16) : u32x4_t{0u, 0u, 0u, 0u};
+    }
+  }
+  const char* qbase = (const char*)p.Q + ((long)b * p.N * p.ldq + (long)h * DH) * 2;
+  const char* dobase = (const char*)p.dO + ((long)b * p.N * p.lddo + (long)h * DH) * 2;
+  const float* lse = p.LSE + ((long)b * p.H + h) * p.lse_stride;
+  const float* dlt = p.Delta + ((long)b * p.H + h) * p.lse_stride;
+
+  f32x4_t dvt[KF][DN], dkt[KF][DN];
+#pragma unroll
+  for (int kf = 0; kf < KF; ++kf)
+#pragma unroll
+    for (int i = 0; i < DN; ++i) { dvt[kf][i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dkt[kf][i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+  f32x4_t sc[KF][2], dp[KF][2];
+  u32x4_t pb[KF], sb[KF];
+
+  constexpr int NJ = (CPR + 7) / 8;
+  int qoff[NJ], dooff[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = (wave + 8 * j) * 64 + lane, r = c / CPR, cc = (c - r * CPR) * 16;
+    qoff[j] = r * (int)(p.ldq * 2) + cc;
+    dooff[j] = r * (int)(p.lddo * 2) + cc;
+  }
+  auto issue = [&](int t, int stage) {
+    const char* qb = qbase + (long)t * 64 * p.ldq * 2;
+    const char* ob = dobase + (long)t * 64 * p.lddo * 2;
+    char* dst = smem + stage * STAGE;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      if (wave + 8 * j < CPR) {
+        glds16(qb + qoff[j], dst + (wave + 8 * j) * 1024);
+        glds16(ob + dooff[j], dst + TILE + (wave + 8 * j) * 1024);
+      }
+    if (wave == (CPR & 7) && lane < 32) {   // lse (lanes 0-15) and delta (16-31), 64 floats each
+      const float* src = lane < 16 ? lse + t * 64 + lane * 4 : dlt + t * 64 + (lane - 16) * 4;
+      glds16(src, smem + LOFF + stage * 512);
+    }
+  };
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const uint32_t rrow = lq * ROWB + g * 16;
+  const uint32_t troff = (4 * g + ((lane >> 2) & 3)) * ROWB + (lane & 3) * 8;
+  const int ntiles = p.N / 64, NH = 2 * ntiles;
+
+  // ---- matrix phase.  cur = stage base of the tile of half hh, par = which 32 rows; prv / parp: the same for half hh-1
+  auto phaseM = [&](auto PREVc, auto CURc, uint32_t cur, int par, uint32_t prv, int parp) {
+    constexpr bool PREV = decltype(PREVc)::value, CUR = decltype(CURc)::value;
+    constexpr int NV = PREV ? DN : 0, NA = CUR ? 2 : 0, NG = NV + NA;
+    u32x4_t bo[LA][2], aq[LA][KSTEPS], ad[LA][KSTEPS];
+    const uint32_t tq = prv + troff + parp * 32 * ROWB, to = tq + TILE;
+    const uint32_t rq = cur + rrow + par * 32 * ROWB, ro = rq + TILE;
+    auto cnt_of = [](int j) constexpr { return j < NV ? 4 : 2 * KSTEPS; };
+    auto read_group = [&](auto Jc) {
+      constexpr int J = decltype(Jc)::value;
+      if constexpr (J < NV) {
+        bo[J % LA][0] = tr_frag<ROWB, 0>(to + J * 32);
+        bo[J % LA][1] = tr_frag<ROWB, 0>(tq + J * 32);
+      } else if constexpr (J < NG) {
+        constexpr int qf2 = J - NV;
+        static_for<0, KSTEPS>([&](auto Kc) {
+          constexpr int ks = decltype(Kc)::value;
+          aq[qf2 % LA][ks] = lds_read_b128_off<qf2 * 16 * ROWB + ks * 64>(rq);
+          ad[qf2 % LA][ks] = lds_read_b128_off<qf2 * 16 * ROWB + ks * 64>(ro);
+        });
+      }
+    };
+    static_for<0, LA - 1>([&](auto Jc) { read_group(Jc); });
+    static_for<0, NG>([&](auto Jc) {
+      constexpr int J = decltype(Jc)::value;
+      read_group(std::integral_constant<int, J + LA - 1>{});
+      constexpr int pending = [&]() constexpr { int n = 0; for (int k = J + 1; k < J + LA && k < NG; ++k) n += cnt_of(k); return n; }();
+      lgkm_wait<(pending > 15 ? 15 : pending)>();
+      if constexpr (J < NV) {
+        pin(bo[J % LA][0]); pin(bo[J % LA][1]);
+#pragma unroll
+        for (int kf = 0; kf < KF; ++kf) {
+          Mma<bf16_t>::run(bo[J % LA][0], pb[kf], dvt[kf][J]);
+          Mma<bf16_t>::run(bo[J % LA][1], sb[kf], dkt[kf][J]);
+        }
+      } else {
+        constexpr int qf2 = J - NV;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) { pin(aq[qf2 % LA][ks]); pin(ad[qf2 % LA][ks]); }
+#pragma unroll
+        for (int kf = 0; kf < KF; ++kf) { sc[kf][qf2] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[kf][qf2] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+          for (int kf = 0; kf < KF; ++kf) {
+            Mma<bf16_t>::run(aq[qf2 % LA][ks], kb[kf][ks], sc[kf][qf2]);
+            Mma<bf16_t>::run(ad[qf2 % LA][ks], vb[kf][ks], dp[kf][qf2]);
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  // ---- vector phase: P and dS of the half (rows = queries 16 (2 par + qf2) + 4g + r, col = key lq) -> bf16 fragments
+  auto phaseV = [&](int stage, int par) {
+    const uint32_t aL = lds0 + LOFF + stage * 512 + (par * 32 + 4 * g) * 4;
+    u32x4_t l4[2], d4[2];
+    l4[0] = lds_read_b128_off<0>(aL); l4[1] = lds_read_b128_off<64>(aL);
+    d4[0] = lds_read_b128_off<256>(aL); d4[1] = lds_read_b128_off<256 + 64>(aL);
+    lgkm_wait<0>();
+    pin(l4[0]); pin(l4[1]); pin(d4[0]); pin(d4[1]);
+    f32x4_t ps[KF][2], ds[KF][2];
+#pragma unroll
+    for (int qf2 = 0; qf2 < 2; ++qf2) {
+      const f32x2_t la = {__uint_as_float(l4[qf2].x), __uint_as_float(l4[qf2].y)}, lb = {__uint_as_float(l4[qf2].z), __uint_as_float(l4[qf2].w)};
+      const f32x2_t na = {-__uint_as_float(d4[qf2].x), -__uint_as_float(d4[qf2].y)}, nb = {-__uint_as_float(d4[qf2].z), -__uint_as_float(d4[qf2].w)};
+#pragma unroll
+      for (int kf = 0; kf < KF; ++kf) {
+        const f32x2_t xa = f32x2_t{sc[kf][qf2][0], sc[kf][qf2][1]} * sl2 - la;
+        const f32x2_t xb = f32x2_t{sc[kf][qf2][2], sc[kf][qf2][3]} * sl2 - lb;
+        const f32x2_t pa = {__builtin_amdgcn_exp2f(xa.x), __builtin_amdgcn_exp2f(xa.y)};
+        const f32x2_t pc = {__builtin_amdgcn_exp2f(xb.x), __builtin_amdgcn_exp2f(xb.y)};
+        const f32x2_t da = pa * (f32x2_t{dp[kf][qf2][0], dp[kf][qf2][1]} + na);
+        const f32x2_t dc = pc * (f32x2_t{dp[kf][qf2][2], dp[kf][qf2][3]} + nb);
+        ps[kf][qf2] = f32x4_t{pa.x, pa.y, pc.x, pc.y};
+        ds[kf][qf2] = f32x4_t{da.x, da.y, dc.x, dc.y};
+      }
+    }
+#pragma unroll
+    for (int kf = 0; kf < KF; ++kf) { pb[kf] = PFrag<bf16_t>::make(ps[kf]); sb[kf] = PFrag<bf16_t>::make(ds[kf]); }
+  };
+
+  issue(0, 0);
+  if (ntiles > 1) issue(1, 1);
+  if (ntiles > 2) issue(2, 2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const auto T = std::true_type{};
+  const auto F = std::false_type{};
+  int stg = 0;                                     // ring stage of the tile of half hh
+  if (grp == 0) {
+    for (int hh = 0; hh < NH; ++hh) {
+      const int par = hh & 1, sn = (stg == 2) ? 0 : stg + 1, sp = (stg == 0) ? 2 : stg - 1;
+      if (par && hh >= 3 && (hh + 3) / 2 < ntiles) issue((hh + 3) / 2, sp);               // interval 2hh
+      const uint32_t cur = lds0 + stg * STAGE, prv = lds0 + (par ? stg : sp) * STAGE;
+      if (hh == 0) phaseM(F, T, cur, par, prv, par ^ 1); else phaseM(T, T, cur, par, prv, par ^ 1);
+      __builtin_amdgcn_s_barrier();
+      phaseV(stg, par);                                                                    // interval 2hh+1
+      if (par) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (par) stg = sn;
+    }
+    { const int sp = (stg == 0) ? 2 : stg - 1; phaseM(T, F, 0u, 0, lds0 + sp * STAGE, 1); }   // interval 2NH
+    __builtin_amdgcn_s_barrier();
+  } else {
+    __builtin_amdgcn_s_barrier();                                                          // interval 0: idle
+    for (int hh = 0; hh < NH; ++hh) {
+      const int par = hh & 1, sn = (stg == 2) ? 0 : stg + 1, sp = (stg == 0) ? 2 : stg - 1;
+      const uint32_t cur = lds0 + stg * STAGE, prv = lds0 + (par ? stg : sp) * STAGE;
+      if (hh == 0) phaseM(F, T, cur, par, prv, par ^ 1); else phaseM(T, T, cur, par, prv, par ^ 1);   // interval 2hh+1
+      if (par) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (!par && hh >= 2 && hh / 2 + 2 < ntiles) issue(hh / 2 + 2, sp);                   // interval 2hh+2
+      phaseV(stg, par);
+      __builtin_amdgcn_s_barrier();
+      if (par) stg = sn;
+    }
+    { const int sp = (stg == 0) ? 2 : stg - 1; phaseM(T, F, 0u, 0, lds0 + sp * STAGE, 1); }   // interval 2NH+1
+  }
+
+#pragma unroll
+  for (int kf = 0; kf < KF; ++kf) {
+    const int kr = kv_w + kf * 16 + lq;
+    bf16_t* dkp = reinterpret_cast<bf16_t*>(p.dK) + ((long)b * p.Nkv + kr) * p.lddk + (long)h * DH;
+    bf16_t* dvp = reinterpret_cast<bf16_t*>(p.dV) + ((long)b * p.Nkv + kr) * p.lddv + (long)h * DH;
+#pragma unroll
+    for (int i = 0; i < DN; ++i) {
+      const int d0 = i * 16 + 4 * g;
+      if (d0 < DH) {
+        float a[4] = {dkt[kf][i][0] * p.scale, dkt[kf][i][1] * p.scale, dkt[kf][i][2] * p.scale, dkt[kf][i][3] * p.scale};
+        float c[4] = {dvt[kf][i][0], dvt[kf][i][1], dvt[kf][i][2], dvt[kf][i][3]};
+        store4(dkp + d0, a);
+        store4(dvp + d0, c);
+      }
+    }
+  }
+}
+
+template <int DH, int QF, int LA = 3>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(AttnBwdArgs p, int nqb, int remap) {
+  using G = Geo<DH>;
+  constexpr int CPR = G::CPR, KSTEPS = G::KSTEPS, DN = G::DN, ROWB = G::ROWB, TILE = G::TILE;
+  constexpr int STAGE = 2 * TILE, SLACK = 16 * ROWB + 64;      // K tile, V tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  const int g = lane >> 4, lq = lane & 15;
+  int bh, qbi;
+  {
+    const int id = blockIdx.x;
+    if (remap) { const int xcd = id & 7, slot = id >> 3; bh = xcd + 8 * (slot / nqb); qbi = slot - (slot / nqb) * nqb; }
+    else { bh = id / nqb; qbi = id - bh * nqb; }
+  }
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int q_w = qbi * (128 * QF) + wave * (16 * QF);
+  const float sl2 = p.scale * 1.4426950408889634f;
+
+  for (int i = tid; i < SLACK / 4; i += 512) reinterpret_cast<uint32_t*>(smem + 3 * STAGE)[i] = 0u;
+
+  u32x4_t qb[QF][KSTEPS], ob[QF][KSTEPS];
+  float lse_q[QF], ndl_q[QF];
+#pragma unroll
+  for (int f = 0; f < QF; ++f) {
+    const int qr = q_w + f * 16 + lq;
+    const char* qp = (const char*)p.Q + (((long)b * p.N + qr) * p.ldq + (long)h * DH) * 2;
+    const char* op = (const char*)p.dO + (((long)b * p.N + qr) * p.lddo + (long)h * DH) * 2;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int c = 4 * ks + g;
+      qb[f][ks] = (c < CPR) ? *reinterpret_cast<const u32x4_t*>(qp + c * 16) : u32x4_t{0u, 0u, 0u, 0u};
+      ob[f][ks] = (c < CPR) ? *reinterpret_cast<const u32x4_t*>(op + c * 16) : u32x4_t{0u, 0u, 0u, 0u};
+    }
+    lse_q[f] = p.LSE[((long)b * p.H + h) * p.lse_stride + qr];
+    ndl_q[f] = -p.Delta[((long)b * p.H + h) * p.lse_stride + qr];
+  }
+  const char* kbase = (const char*)p.K + ((long)b * p.Nkv * p.ldk + (long)h * DH) * 2;
+  const char* vbase = (const char*)p.V + ((long)b * p.Nkv * p.ldv + (long)h * DH) * 2;
+
+  f32x4_t dqt[QF][DN];
+#pragma unroll
+  for (int f = 0; f < QF; ++f)
+#pragma unroll
+    for (int i = 0; i < DN; ++i) dqt[f][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  f32x4_t sc[QF][2], dp[QF][2];
+  u32x4_t sb[QF];
+
+  constexpr int NJ = (CPR + 7) / 8;
+  int koff[NJ], voff[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = (wave + 8 * j) * 64 + lane, r = c / CPR, cc = (c - r * CPR) * 16;
+    koff[j] = r * (int)(p.ldk * 2) + cc;
+    voff[j] = r * (int)(p.ldv * 2) + cc;
+  }
+  auto issue = [&](int t, int stage) {
+    const char* kb = kbase + (long)t * 64 * p.ldk * 2;
+    const char* vb = vbase + (long)t * 64 * p.ldv * 2;
+    char* dst = smem + stage * STAGE;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      if (wave + 8 * j < CPR) {
+        glds16(kb + koff[j], dst + (wave + 8 * j) * 1024);
+        glds16(vb + voff[j], dst + TILE + (wave + 8 * j) * 1024);
+      }
+  };
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const uint32_t rrow = lq * ROWB + g * 16;
+  const uint32_t troff = (4 * g + ((lane >> 2) & 3)) * ROWB + (lane & 3) * 8;
+  const int ntiles = p.Nkv / 64, NH = 2 * ntiles;
+
+  auto phaseM = [&](auto PREVc, auto CURc, uint32_t cur, int par, uint32_t prv, int parp) {
+    constexpr bool PREV = decltype(PREVc)::value, CUR = decltype(CURc)::value;
+    constexpr int NV = PREV ? 1 : 0, NA = CUR ? 2 : 0, NG = NV + NA;     // one transpose-read group (all DN fragments)
+    u32x4_t kc[DN], ak[LA][KSTEPS], av[LA][KSTEPS];
+    const uint32_t tk = prv + troff + parp * 32 * ROWB;
+    const uint32_t rk = cur + rrow + par * 32 * ROWB, rv = rk + TILE;
+    auto cnt_of = [](int j) constexpr { return j < NV ? 2 * DN : 2 * KSTEPS; };
+    auto read_group = [&](auto Jc) {
+      constexpr int J = decltype(Jc)::value;
+      if constexpr (J < NV) {
+        static_for<0, DN>([&](auto Ic) { constexpr int i = decltype(Ic)::value; kc[i] = tr_frag<ROWB, 0>(tk + i * 32); });
+      } else if constexpr (J < NG) {
+        constexpr int kf2 = J - NV;
+        static_for<0, KSTEPS>([&](auto Kc) {
+          constexpr int ks = decltype(Kc)::value;
+          ak[kf2 % LA][ks] = lds_read_b128_off<kf2 * 16 * ROWB + ks * 64>(rk);
+          av[kf2 % LA][ks] = lds_read_b128_off<kf2 * 16 * ROWB + ks * 64>(rv);
+        });
+      }
+    };
+    static_for<0, LA - 1>([&](auto Jc) { read_group(Jc); });
+    static_for<0, NG>([&](auto Jc) {
+      constexpr int J = decltype(Jc)::value;
+      read_group(std::integral_constant<int, J + LA - 1>{});
+      constexpr int pending = [&]() constexpr { int n = 0; for (int k = J + 1; k < J + LA && k < NG; ++k) n += cnt_of(k); return n; }();
+      lgkm_wait<(pending > 15 ? 15 : pending)>();
+      if constexpr (J < NV) {
+#pragma unroll
+        for (int i = 0; i < DN; ++i) pin(kc[i]);
+#pragma unroll
+        for (int i = 0; i < DN; ++i)
+#pragma unroll
+          for (int f = 0; f < QF; ++f) Mma<bf16_t>::run(kc[i], sb[f], dqt[f][i]);
+      } else {
+        constexpr int kf2 = J - NV;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) { pin(ak[kf2 % LA][ks]); pin(av[kf2 % LA][ks]); }
+#pragma unroll
+        for (int f = 0; f < QF; ++f) { sc[f][kf2] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[f][kf2] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+          for (int f = 0; f < QF; ++f) {
+            Mma<bf16_t>::run(ak[kf2 % LA][ks], qb[f][ks], sc[f][kf2]);
+            Mma<bf16_t>::run(av[kf2 % LA][ks], ob[f][ks], dp[f][kf2]);
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  // ---- vector phase: dS^T of the half (rows = keys 16 kf2 + 4g + r, col = query lq), registers only
+  auto phaseV = [&]() {
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+      f32x4_t dst[2];
+#pragma unroll
+      for (int kf2 = 0; kf2 < 2; ++kf2) {
+        const f32x2_t xa = f32x2_t{sc[f][kf2][0], sc[f][kf2][1]} * sl2 - lse_q[f];
+        const f32x2_t xb = f32x2_t{sc[f][kf2][2], sc[f][kf2][3]} * sl2 - lse_q[f];
+        const f32x2_t pa = {__builtin_amdgcn_exp2f(xa.x), __builtin_amdgcn_exp2f(xa.y)};
+        const f32x2_t pc = {__builtin_amdgcn_exp2f(xb.x), __builtin_amdgcn_exp2f(xb.y)};
+        const f32x2_t da = pa * (f32x2_t{dp[f][kf2][0], dp[f][kf2][1]} + ndl_q[f]);
+        const f32x2_t dc = pc * (f32x2_t{dp[f][kf2][2], dp[f][kf2][3]} + ndl_q[f]);
+        dst[kf2] = f32x4_t{da.x, da.y, dc.x, dc.y};
+      }
+      sb[f] = PFrag<bf16_t>::make(dst);
+    }
+  };
+
+  issue(0, 0);
+  if (ntiles > 1) issue(1, 1);
+  if (ntiles > 2) issue(2, 2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const auto T = std::true_type{};
+  const auto F = std::false_type{};
+  int stg = 0;
+  if (grp == 0) {
+    for (int hh = 0; hh < NH; ++hh) {
+      const int par = hh & 1, sn = (stg == 2) ? 0 : stg + 1, sp = (stg == 0) ? 2 : stg - 1;
+      if (par && hh >= 3 && (hh + 3) / 2 < ntiles) issue((hh + 3) / 2, sp);
+      const uint32_t cur = lds0 + stg * STAGE, prv = lds0 + (par ? stg : sp) * STAGE;
+      if (hh == 0) phaseM(F, T, cur, par, prv, par ^ 1); else phaseM(T, T, cur, par, prv, par ^ 1);
+      __builtin_amdgcn_s_barrier();
+      phaseV();
+      if (par) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (par) stg = sn;
+    }
+    { const int sp = (stg == 0) ? 2 : stg - 1; phaseM(T, F, 0u, 0, lds0 + sp * STAGE, 1); }
+    __builtin_amdgcn_s_barrier();
+  } else {
+    __builtin_amdgcn_s_barrier();
+    for (int hh = 0; hh < NH; ++hh) {
+      const int par = hh & 1, sn = (stg == 2) ? 0 : stg + 1, sp = (stg == 0) ? 2 : stg - 1;
+      const uint32_t cur = lds0 + stg * STAGE, prv = lds0 + (par ? stg : sp) * STAGE;
+      if (hh == 0) phaseM(F, T, cur, par, prv, par ^ 1); else phaseM(T, T, cur, par, prv, par ^ 1);
+      if (par) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (!par && hh >= 2 && hh / 2 + 2 < ntiles) issue(hh / 2 + 2, sp);
+      phaseV();
+      __builtin_amdgcn_s_barrier();
+      if (par) stg = sn;
+    }
+    { const int sp = (stg == 0) ? 2 : stg - 1; phaseM(T, F, 0u, 0, lds0 + sp * STAGE, 1); }
+  }
+
+#pragma unroll
+  for (int f = 0; f < QF; ++f) {
+    const int qrow = q_w + f * 16 + lq;
+    bf16_t* dqp = reinterpret_cast<bf16_t*>(p.dQ) + ((long)b * p.N + qrow) * p.lddq + (long)h * DH;
+#pragma unroll
+    for (int i = 0; i < DN; ++i) {
+      const int d0 = i * 16 + 4 * g;
+      if (d0 < DH) {
+        float a[4] = {dqt[f][i][0] * p.scale, dqt[f][i][1] * p.scale, dqt[f][i][2] * p.scale, dqt[f][i][3] * p.scale};
+        store4(dqp + d0, a);
       }
     }
   }
@@ -913,6 +1358,9 @@ int attn_fwd_tr(const AttnFwdArgs& a, const void* V, long ldv, hipStream_t st) {
 }
 
 template <int DH, bool TQ, bool TK>
+static int launch_bwd_tr_sync(const AttnBwdArgs& a, hipStream_t st, bool skip_dq);
+
+template <int DH, bool TQ, bool TK>
 static int launch_bwd_tr(const AttnBwdArgs& a, hipStream_t st) {
   constexpr int KF = DH <= 40 ? 2 : 1;     // key / query fragments per wave (register budget: <= 256 VGPRs)
   constexpr int LDS_DKV = 2 * (2 * Geo<DH>::TILE + 512) + 64 + 16 * Geo<DH>::ROWB;
@@ -926,6 +1374,48 @@ static int launch_bwd_tr(const AttnBwdArgs& a, hipStream_t st) {
   }
   int rc = attn_delta(a, st);
   if (rc) return rc;
+  if constexpr (!TQ && !TK && (DH == 40 || DH == 80)) {
+    // ping-pong kernels: whole 64-row tiles on both sides, >= 3 tiles in the loop direction, enough workgroups
+    constexpr int KFP = DH == 40 ? 2 : 1;
+    constexpr int LDSP = 3 * 2 * Geo<DH>::TILE + 16 * Geo<DH>::ROWB + 64 + 3 * 512;
+    static bool donep = false;
+    if (!donep) {
+      if (set_lds(&attn_bwd_dkv_pp_kernel<DH, KFP>, LDSP) || set_lds(&attn_bwd_dq_pp_kernel<DH, KFP>, LDSP)) return CL_ELAUNCH;
+      donep = true;
+    }
+    const int remap = ((a.B * a.H) % 8 == 0) ? 1 : 0;
+    bool dkv_done = false, dq_done = false;
+    if (g_attn_variant != 1 && a.dK && a.Nkv % (128 * KFP) == 0 && a.N >= 192) {
+      const int nkb = a.Nkv / (128 * KFP);
+      const long grid = (long)nkb * a.H * a.B;
+      if (grid >= 128) {
+        hipLaunchKernelGGL((attn_bwd_dkv_pp_kernel<DH, KFP>), dim3((unsigned)grid), dim3(512), LDSP, st, a, nkb, remap);
+        dkv_done = true;
+      }
+    }
+    if (g_attn_variant != 1 && a.N % (128 * KFP) == 0 && a.Nkv >= 192) {
+      const int nqb = a.N / (128 * KFP);
+      const long grid = (long)nqb * a.H * a.B;
+      if (grid >= 128) {
+        hipLaunchKernelGGL((attn_bwd_dq_pp_kernel<DH, KFP>), dim3((unsigned)grid), dim3(512), LDSP, st, a, nqb, remap);
+        dq_done = true;
+      }
+    }
+    if ((dkv_done || !a.dK) && dq_done) { CL_CHECK_LAUNCH(); return CL_OK; }
+    if (dkv_done || dq_done) {     // mixed: finish with the tile-synchronous kernel for the other half
+      AttnBwdArgs a2 = a;
+      if (dkv_done) { a2.dK = nullptr; a2.dV = nullptr; }
+      return launch_bwd_tr_sync<DH, TQ, TK>(a2, st, /*skip_dq=*/dq_done);
+    }
+  }
+  return launch_bwd_tr_sync<DH, TQ, TK>(a, st, false);
+}
+
+template <int DH, bool TQ, bool TK>
+static int launch_bwd_tr_sync(const AttnBwdArgs& a, hipStream_t st, bool skip_dq) {
+  constexpr int KF = DH <= 40 ? 2 : 1;
+  constexpr int LDS_DKV = 2 * (2 * Geo<DH>::TILE + 512) + 64 + 16 * Geo<DH>::ROWB;
+  constexpr int LDS_DQ = 2 * 2 * Geo<DH>::TILE + 64 + 16 * Geo<DH>::ROWB;
   if (a.dK) {
     // two key fragments per wave only when that still leaves enough workgroups to fill the chip
     const long blocks2 = (long)((a.Nkv + 64 * KF - 1) / (64 * KF)) * a.H * a.B;
@@ -937,6 +1427,7 @@ static int launch_bwd_tr(const AttnBwdArgs& a, hipStream_t st) {
       hipLaunchKernelGGL((attn_bwd_dkv_tr_kernel<DH, 1, TQ>), grid, dim3(256), LDS_DKV, st, a);
     }
   }
+  if (skip_dq) { CL_CHECK_LAUNCH(); return CL_OK; }
   const long qblocks2 = (long)((a.N + 64 * KF - 1) / (64 * KF)) * a.H * a.B;
   if (KF == 2 && qblocks2 >= 512) {
     dim3 grid((a.N + 127) / 128, a.H, a.B);

@@ -312,6 +312,34 @@ def test_attention_production_shapes_fwd_bwd(dh, N, Nkv, B):
     assert max(e_dq, e_dk, e_dv) < 1e-2
 
 
+def test_attention_schedules_agree_pingpong_vs_tile_synchronous():
+    """The two schedules of the bf16 attention kernels (ping-pong: two wave groups one phase apart, lazy running
+    maximum, MFMA-computed denominator; tile-synchronous: the round-1 kernels, still used for ragged shapes) must
+    give the same O / lse / dQ / dK / dV up to bf16 rounding, at N = 4096, d_head 40 and N = 1024, d_head 80."""
+    _need_gpu()
+    from ctrlora_amd import hip
+    for dh, N, B in ((40, 4096, 2), (80, 1024, 4)):
+        Hh, inner = 8, 8 * dh
+        g = torch.Generator().manual_seed(dh)
+        mk = lambda: _bf(torch.randn(B * N, inner, generator=g) * 1.3).cuda()
+        q, k, v, do = mk(), mk(), mk(), mk()
+        res = []
+        for variant in (1, 0):
+            hip.lib().cl_attention_force_variant(variant)
+            o = torch.empty_like(q)
+            lse = torch.empty(B, Hh, N, dtype=torch.float32, device="cuda")
+            delta = torch.empty_like(lse)
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            hip.attention_fwd_v2(q, k, v, o, lse, B, Hh, N, N, dh, dh ** -0.5)
+            hip.attention_bwd_v2(q, k, v, o, do, lse, delta, dq, dk, dv, B, Hh, N, N, dh, dh ** -0.5)
+            torch.cuda.synchronize()
+            res.append((o, lse, dq, dk, dv))
+        hip.lib().cl_attention_force_variant(0)
+        errs = [rel_l2(a, b) for a, b in zip(res[1], res[0])]
+        _record("attention_pp_vs_sync", dh=dh, N=N, o=errs[0], lse=errs[1], dq=errs[2], dk=errs[3], dv=errs[4])
+        assert errs[1] < 1e-4 and max(errs[0], errs[2], errs[3], errs[4]) < 6e-3, errs
+
+
 @pytest.mark.parametrize("M,K,N,r", [(32768, 320, 320, 128), (8192, 640, 640, 128), (2048, 1280, 1280, 128),
                                       (32768, 320, 2560, 128), (32768, 1280, 320, 128), (8 * 77, 768, 320, 128),
                                       (512, 1280, 1280, 128), (8, 1280, 1280, 128), (32768, 320, 320, 32)])
