@@ -15,7 +15,8 @@ Prints ONE JSON line (rank 0).  `value` = images/s over all ranks.  Also reporte
                 + data-gradients + LoRA/zero-conv weight-gradients, no recompute, no frozen dW) x images/s / 2.5 PF,
                 plus the dominant kernel (implicit-GEMM conv 320->320 @64x64) timed with HIP events on this stream.
   ddim          DDIM denoise steps/s (CFG 7.5, batch 16, hint latent encoded once) on the same silicon.
-  cpu_baseline  the oracle (CPU restatement of the reference) on the host cores, bounded sample.
+  cpu_baseline  the oracle (CPU restatement of the reference) on the host cores: one TIMED optimizer step of
+                BASELINE configs[0] (rank 32, bs 1) and, under ddim.cpu_baseline, two timed DDIM steps with CFG.
 """
 import argparse
 import json
@@ -99,7 +100,75 @@ def conv_kernel_probe(device, dtype, iters=30):
                 frac=round(flops / ms * 1e-9 / PEAK_BF16_TFLOPS, 4), traffic=traffic)
 
 
-def ddim_bench(device, dtype, B=16, S=50, tiny=False):
+def family_census(model, opt, data, reps=10):
+    """Time-weighted MFMA roofline of the two contraction kernel families, measured live: every hip.gemm /
+    attention call of ONE eager training step is recorded (shape signature + algorithmic FLOPs), then every unique
+    signature is re-launched in isolation on this stream between HIP events.  achieved = sum(FLOPs) / sum(time x calls):
+    the figure the step actually gets from the family, not its best shape."""
+    import collections
+    from ctrlora_amd import hip
+    calls = {"gemm": collections.OrderedDict(), "attention": collections.OrderedDict()}
+    o_gemm, o_af, o_ab = hip.gemm, hip.attention_fwd_v2, hip.attention_bwd_v2
+
+    def rec_gemm(a1, w1, out, **kw):
+        M = out.shape[0] if kw.get("M") is None else kw["M"]
+        N = out.shape[1] if kw.get("N") is None else kw["N"]
+        k1 = a1.shape[1] if kw.get("k1") is None else kw["k1"]
+        mode, a2 = kw.get("mode", hip.LINEAR), kw.get("a2")
+        k2 = 0 if a2 is None else a2.shape[1]
+        key = (mode, M, N, k1, k2, kw.get("conv"), kw.get("residual") is not None, bool(kw.get("out_f32", False)),
+               kw.get("act", 0))
+        if not kw.get("atomic", False):
+            fl = 2.0 * M * N * ((1 if mode == hip.LINEAR else 9) * k1 + k2)
+            e = calls["gemm"].setdefault(key, [0, fl, lambda: o_gemm(a1, w1, out, **kw)])
+            e[0] += 1
+        return o_gemm(a1, w1, out, **kw)
+
+    def rec_af(q, k, v, o, lse, B, H, N, Nkv, dh, scale):
+        e = calls["attention"].setdefault(("fwd", B, H, N, Nkv, dh), [0, 4.0 * B * H * N * Nkv * dh,
+                                                                   lambda: o_af(q, k, v, o, lse, B, H, N, Nkv, dh, scale)])
+        e[0] += 1
+        return o_af(q, k, v, o, lse, B, H, N, Nkv, dh, scale)
+
+    def rec_ab(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, N, Nkv, dh, scale):
+        nmm = 5 if dk is not None else 3          # S, dP, dQ (+ dK, dV): algorithmic, the two kernels recompute S / dP
+        e = calls["attention"].setdefault(("bwd", B, H, N, Nkv, dh, dk is not None), [
+            0, 2.0 * nmm * B * H * N * Nkv * dh,
+            lambda: o_ab(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, N, Nkv, dh, scale)])
+        e[0] += 1
+        return o_ab(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, N, Nkv, dh, scale)
+
+    hip.gemm, hip.attention_fwd_v2, hip.attention_bwd_v2 = rec_gemm, rec_af, rec_ab
+    try:
+        opt.zero_grad()
+        cond = {"c_crossattn": [data["ctx"][0]], "c_concat": [data["hint"][0]]}
+        model.engine_train_step(data["z"][0], cond, data["t"][0], data["noise"][0])
+        torch.cuda.synchronize()
+    finally:
+        hip.gemm, hip.attention_fwd_v2, hip.attention_bwd_v2 = o_gemm, o_af, o_ab
+    out = {}
+    for fam, tab in calls.items():
+        tot_us, tot_fl, n = 0.0, 0.0, 0
+        for key, (cnt, fl, run) in tab.items():
+            for _ in range(2):
+                run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / reps
+            tot_us += us * cnt; tot_fl += fl * cnt; n += cnt
+        if tot_us > 0:
+            tf = tot_fl / tot_us * 1e-6
+            out[fam] = dict(achieved=round(tf, 1), frac=round(tf / PEAK_BF16_TFLOPS, 4), unit="TFLOP/s",
+                            ms_per_step=round(tot_us * 1e-3, 2), launches_per_step=n, unique_shapes=len(tab),
+                            gflop_per_step=round(tot_fl * 1e-9, 1))
+    return out
+
+
+def ddim_bench(device, dtype, B=16, S=50, tiny=False, loops=5):
     from cldm.ddim_hacked import DDIMSampler
     model = build_model("inference/ctrlora_sd15_rank128_1lora.yaml", 0, tiny=tiny).to(device).eval()
     model.set_engine_dtype(dtype)
@@ -113,50 +182,80 @@ def ddim_bench(device, dtype, B=16, S=50, tiny=False):
     sampler = DDIMSampler(model)
     run = lambda s: sampler.sample(s, B, (4, H, H), cond, verbose=False, eta=0.0, x_T=x_T,
                                    unconditional_guidance_scale=7.5, unconditional_conditioning=unc)
-    run(2)
+    run(6)                                   # warm-up loop (kernel attribute set-up, allocator, capture path)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    out, _ = run(S)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    times = []
+    for _ in range(loops):
+        t0 = time.perf_counter()
+        out, _ = run(S)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
     assert torch.isfinite(out).all()
+    times.sort()
+    dt = times[len(times) // 2]              # median loop
     sps = S / dt
     return dict(metric="DDIM denoise steps/s (CFG 7.5, both passes, all B images)", value=round(sps, 3), batch=B, S=S,
-                ms_per_step=round(dt / S * 1e3, 2),
+                ms_per_step=round(dt / S * 1e3, 2), best=round(S / times[0], 3), loops=loops,
                 mfma_frac=round(DDIM_TFLOP_PER_STEP_IMAGE * B * sps / PEAK_BF16_TFLOPS, 4),
-                note="hint latent given (VAE encode hoisted out of the loop); cond+uncond batched")
+                note=f"median of {loops} full S={S} loops after a warm-up loop (best loop in `best`); each loop includes "
+                     "its own graph capture; hint latent given (VAE encode hoisted out of the loop); cond+uncond batched")
 
 
-def cpu_baseline(rank_lora, threads=32):
-    """Oracle (CPU restatement of the reference modules, oracle/ref_model.py) on the host cores, BOUNDED:
-    the fp32 forward of the training step's network (ControlNet r-LoRA + UNet, B=1, 512x512 = latent 64x64),
-    i.e. 1.103 of the step's 1.996 algorithmic TFLOP/image; the step rate is that
-    time scaled by the FLOP ratio.  (A full CPU fwd+bwd step takes minutes on this box -- measured 496 s
-    with every core oversubscribed -- which would not fit the bench's time budget.)"""
+def cpu_baseline(rank_lora=32, threads=32):
+    """The oracle (CPU restatement of the reference modules, oracle/ref_model.py) on the host cores, TIMED, not
+    extrapolated: ONE genuine optimizer step of BASELINE.json configs[0] -- ctrlora_finetune_sd15_rank32, bs = 1,
+    512x512 (latent 64x64), fp32: q_sample + ControlNet(r32) + UNet forward, autograd backward to the 246 trainable
+    tensors, AdamW on them -- and TWO DDIM denoise steps with classifier-free guidance (4 forwards) at bs = 1.
+    Bounded sample (~20-40 s of host work); the reference itself additionally recomputes activations
+    (checkpoint()) and forms ~0.9 G dead weight gradients, so it is slower than this port."""
     from oracle import arch, ref_model as R
     n_thr = max(1, min(threads, os.cpu_count() or 1))
     torch.set_num_threads(n_thr)
     cfg = arch.ArchCfg(lora_rank=rank_lora)
     sd_cn = arch.make_state(arch.controlnet_shapes(cfg), 0)
     sd_un = arch.make_state(arch.unet_shapes(cfg), 0)
+    train = [k for k in sd_cn if arch.is_trainable(k)]
+    for k in train:
+        sd_cn[k].requires_grad_(True)
     g = torch.Generator().manual_seed(0)
-    z, hint = (torch.randn(1, 4, 64, 64, generator=g) for _ in range(2))
-    ctx = torch.randn(1, 77, 768, generator=g)
+    z, hint, noise = (torch.randn(1, 4, 64, 64, generator=g) for _ in range(3))
+    ctx, ctx_u = torch.randn(1, 77, 768, generator=g), torch.randn(1, 77, 768, generator=g)
     t = torch.randint(0, 1000, (1,), generator=g)
-    reps = 3          # ~3.6 s each on the MI355X host (32 threads): ~11 s of CPU work in total
+    sched = R.make_schedule()
+    t0 = time.perf_counter()
+    loss, _ = R.p_losses(sd_cn, sd_un, cfg, sched, z, t, ctx, hint, noise)
+    loss.backward()
     with torch.no_grad():
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            eps = R.apply_model(sd_cn, sd_un, cfg, z, t, ctx, hint)
-        dt = (time.perf_counter() - t0) / reps
-    assert torch.isfinite(eps).all()
-    tf_step = TRAIN_TFLOP_PER_IMAGE.get(rank_lora, 1.996)
-    tf_fwd = 1.1034 if rank_lora == 128 else 1.0798
-    step_s = dt * tf_step / tf_fwd
-    return dict(value=round(1.0 / step_s, 5), unit="images/s", cores=n_thr, kind="port",
-                sample=f"oracle forward of ControlNet(r{rank_lora})+UNet, B=1, 512x512, fp32, {n_thr} threads: {dt:.1f} s (mean of {reps}) "
-                       f"for {tf_fwd} of the step's {tf_step} TFLOP/image; step time = forward time x FLOP ratio "
-                       f"({step_s:.1f} s/image); hint latent given (no VAE encode)")
+        for k in train:
+            p, _, _ = R.adamw_step(sd_cn[k], sd_cn[k].grad, torch.zeros_like(sd_cn[k]), torch.zeros_like(sd_cn[k]), 1, 1e-5)
+            sd_cn[k].copy_(p)
+    step_s = time.perf_counter() - t0
+    assert torch.isfinite(loss)
+
+    def eps_fn(x, tt, c):
+        with torch.no_grad():
+            return R.apply_model(sd_cn, sd_un, cfg, x, tt, ctx if c else ctx_u, hint)
+
+    S = 2
+    t0 = time.perf_counter()
+    x, _ = R.ddim_sample(eps_fn, sched, S, noise, scale=7.5, uncond=True)
+    ddim_s = (time.perf_counter() - t0) / S
+    assert torch.isfinite(x).all()
+    cpu = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
+    base = dict(cores=n_thr, kind="port", cpu=cpu)
+    train_b = dict(value=round(1.0 / step_s, 5), unit="images/s", **base,
+                   sample=f"ONE timed optimizer step of the oracle: ctrlora_finetune_sd15_rank{rank_lora}, bs 1, 512x512 "
+                          f"(latent 64x64), fp32, p_losses forward + autograd backward (246 trainable tensors) + AdamW, "
+                          f"{n_thr} threads: {step_s:.1f} s (hint latent given: no VAE / CLIP in the sample)")
+    ddim_b = dict(value=round(1.0 / ddim_s, 5), unit="denoise steps/s", **base,
+                  sample=f"{S} timed DDIM steps of the oracle with CFG 7.5 (2 forwards each), bs 1, latent 64x64, fp32, "
+                         f"{n_thr} threads: {ddim_s:.1f} s per step")
+    return train_b, ddim_b
 
 
 def main():
@@ -276,9 +375,22 @@ def main():
         roof["whole_step"] = {"achieved": roof["achieved"], "frac": roof["frac"], "basis": roof.pop("basis")}
         if not args.tiny and args.dtype == "bf16":   # rank 0 only; no collective inside
             dk = conv_kernel_probe(device, dtype)
-            # contract fields describe the dominant kernel; the whole-step figure stays alongside
-            roof.update(achieved=dk["achieved"], frac=dk["frac"], traffic=dk["traffic"], kernel=dk["kernel"],
-                        ms_per_launch=dk["ms"])
+            fam = family_census(model, opt, data)
+            # contract fields describe the dominant kernel FAMILY (implicit-GEMM conv + linear kernels of
+            # csrc/gemm.hip), time-weighted over every shape of the step; its best single shape and the attention
+            # family stay alongside, as does the whole-step figure
+            gf = fam.get("gemm")
+            if gf:
+                roof.update(achieved=gf["achieved"], frac=gf["frac"], traffic=None,
+                            kernel="gemm_fl / gemm kernel family (implicit-GEMM 3x3 conv + linear + LoRA-fused linear), "
+                                   "time-weighted over all shapes of one step",
+                            family=gf)
+            roof["best_shape"] = dict(kernel=dk["kernel"], achieved=dk["achieved"], frac=dk["frac"], ms_per_launch=dk["ms"],
+                                      traffic=dk["traffic"],
+                                      traffic_kind="static: rocprofv3 TCC_EA passes on this launch (profiles/dominant_kernel_traffic.json), "
+                                                   "not re-measured in this run")
+            if "attention" in fam:
+                roof["attention_family"] = fam["attention"]
         out["roofline"] = roof
     # DDIM leg: every rank samples its own batch (replicas, no collective); aggregate = sum over ranks
     ddim = None
@@ -304,7 +416,10 @@ def main():
         if ddim is not None:
             out["ddim"] = ddim
         if world == 1 and not args.no_cpu_baseline and not args.tiny:
-            out["cpu_baseline"] = cpu_baseline(args.rank_lora)
+            train_b, ddim_b = cpu_baseline()
+            out["cpu_baseline"] = train_b
+            if ddim is not None:
+                out["ddim"]["cpu_baseline"] = ddim_b
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

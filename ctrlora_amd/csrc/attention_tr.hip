@@ -1303,11 +1303,9 @@ template <int DH>
 static bool launch_fwd_pp(const AttnFwdArgs& a, const void* V, long ldv, hipStream_t st, int* rc) {
   if constexpr (DH == 40 || DH == 80) {
     const long grid = (long)(a.N / 256) * a.H * a.B;
-    if (g_attn_variant == 1 || a.N % 256 || a.Nkv % 64 || a.Nkv < 128 || grid < 128) return false;
-    switch (g_attn_variant) {          // 2..4: A/B and ablation probes (tests/tools/attn_bench.py)
+    if (g_attn_variant == 1 || a.N % 256 || a.Nkv % 64 || a.Nkv < 128 || grid < 256) return false;
+    switch (g_attn_variant) {          // 2, 5: A/B probes (tests/tools/attn_bench.py); 3 = ping-pong backward too
       case 2: *rc = launch_fwd_pp_t<DH, 2, 0>(a, V, ldv, st); break;
-      case 3: *rc = launch_fwd_pp_t<DH, 4, 1>(a, V, ldv, st); break;
-      case 4: *rc = launch_fwd_pp_t<DH, 4, 2>(a, V, ldv, st); break;
       case 5: *rc = launch_fwd_pp_t<DH, 4, 0, true>(a, V, ldv, st); break;
       default: *rc = launch_fwd_pp_t<DH, 4, 0>(a, V, ldv, st); break;
     }
@@ -1385,7 +1383,11 @@ static int launch_bwd_tr(const AttnBwdArgs& a, hipStream_t st) {
     }
     const int remap = ((a.B * a.H) % 8 == 0) ? 1 : 0;
     bool dkv_done = false, dq_done = false;
-    if (g_attn_variant != 1 && a.dK && a.Nkv % (128 * KFP) == 0 && a.N >= 192) {
+    // (measured on MI355X, profiles/r02_attention_ab.json: the ping-pong BACKWARD kernels are correct but not faster than
+    // the tile-synchronous ones -- one 8-wave workgroup per CU at 172-184 VGPRs, both pipes under 50 % -- so they are
+    // opt-in, variant 3, until the in-wave MFMA/VALU interleave replaces the barrier-phased form)
+    const bool want_pp = g_attn_variant == 3;
+    if (want_pp && a.dK && a.Nkv % (128 * KFP) == 0 && a.N >= 192) {
       const int nkb = a.Nkv / (128 * KFP);
       const long grid = (long)nkb * a.H * a.B;
       if (grid >= 128) {
@@ -1393,7 +1395,7 @@ static int launch_bwd_tr(const AttnBwdArgs& a, hipStream_t st) {
         dkv_done = true;
       }
     }
-    if (g_attn_variant != 1 && a.N % (128 * KFP) == 0 && a.Nkv >= 192) {
+    if (want_pp && a.N % (128 * KFP) == 0 && a.Nkv >= 192) {
       const int nqb = a.N / (128 * KFP);
       const long grid = (long)nqb * a.H * a.B;
       if (grid >= 128) {

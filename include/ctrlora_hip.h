@@ -50,7 +50,8 @@ int cl_set_workspace(void* device_ptr, long bytes);
 int cl_set_stream_workspace(void* stream, void* device_ptr, long bytes);
 /* tuning hook: force a tile configuration of csrc/gemm.hip (-1 = built-in heuristic) */
 int cl_gemm_force_config(int cfg);
-/* A/B probe hook for the attention schedules: 0 = heuristic (default), 1 = tile-synchronous kernels only */
+/* A/B probe hook for the attention schedules: 0 = default (ping-pong forward where it applies, tile-synchronous
+ * backward), 1 = tile-synchronous kernels only, 3 = ping-pong forward and backward */
 int cl_attention_force_variant(int variant);
 
 /* ---- dense contractions -------------------------------------------------------------

@@ -324,7 +324,7 @@ def test_attention_schedules_agree_pingpong_vs_tile_synchronous():
         mk = lambda: _bf(torch.randn(B * N, inner, generator=g) * 1.3).cuda()
         q, k, v, do = mk(), mk(), mk(), mk()
         res = []
-        for variant in (1, 0):
+        for variant in (1, 3):       # 1: tile-synchronous everywhere, 3: ping-pong forward AND backward
             hip.lib().cl_attention_force_variant(variant)
             o = torch.empty_like(q)
             lse = torch.empty(B, Hh, N, dtype=torch.float32, device="cuda")

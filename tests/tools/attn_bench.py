@@ -83,7 +83,7 @@ def case(dh, N, Nkv, B, variants, bwd, check=True):
     return out
 
 
-NAMES = {0: "pingpong", 1: "sync", 2: "pp_la2", 3: "pp_noexp(ablation)", 4: "pp_nolds(ablation)", 5: "pp_1wg_per_cu"}
+NAMES = {0: "default(fwd pingpong, bwd sync)", 1: "sync", 2: "fwd_pp_lookahead2", 3: "fwd+bwd pingpong", 5: "fwd_pp_1wg_per_cu"}
 
 
 def main():
