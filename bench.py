@@ -271,7 +271,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--ddim-only", action="store_true", help="profiling aid: run only the DDIM leg")
     ap.add_argument("--force-split-graphs", action="store_true",
-                    help="test aid: use the multi-rank structure (graph A | all-reduce | graph B) even with one rank")
+                    help="test aid: use the multi-rank structure (segment graphs with bucketed all-reduces in between, "
+                         "then the AdamW graph) even with one rank")
     ap.add_argument("--probe-only", action="store_true",
                     help="profiling aid: run only the dominant-kernel probe (the rocprofv3 --stats summary of this "
                          "command, profiles/r01_dominant_kernel_stats.csv, is what roofline.ms_per_launch is checked against)")
@@ -365,7 +366,9 @@ def main():
                                    f"512x512 (latent 64x64), per-GPU batch {B}, {args.dtype} storage / fp32 accumulate, "
                                    "synthetic latents + random-init weights, LoRA+zero-conv+norm trainables, fused AdamW",
                        "global_batch": world * B, "parallelism": f"dp{world}", "lora_rank": args.rank_lora,
-                       "launch": "eager" if args.no_graph else "hipGraph replay"},
+                       "launch": "eager" if args.no_graph else ("hipGraph replay" if graphed is None or graphed.mode == "one" else
+                                                                 f"hipGraph replay, {len(graphed.segments)} backward segments with the "
+                                                                 "LoRA-gradient all-reduce of each bucket overlapping the next segment")},
             "loss": round(final_loss, 5),
         }
         achieved = tf_img * ips / world          # per-GPU TFLOP/s

@@ -143,33 +143,58 @@ class FusedAdamW(torch.optim.Optimizer):
 class GraphedTrainStep:
     """One optimizer step of LoRA fine-tuning as hipGraph replays.
 
-    The eager step is ~2800 kernel launches driven from Python through ctypes; at < 50 ms per step the host
+    The eager step is ~1900 kernel launches driven from Python through ctypes; at ~40 ms per step the host
     becomes the bottleneck.  Everything in the step has static shapes and no host dependence (the optimizer's
-    step counter and hyper-parameters are device-resident), so it is captured once and replayed:
+    step counter and hyper-parameters are device-resident), so it is captured once and replayed.
 
-        graph A : zero_grad -> p_losses forward -> hand-written backward      (all ranks, no collectives)
-        eager   : all-reduce of the flat LoRA gradient buffer over RCCL        (world_size > 1 only)
-        graph B : fused AdamW + re-pack of the trainables
+    One rank:      ONE graph = zero_grad -> p_losses forward -> hand-written backward -> fused AdamW + re-pack.
+    Data parallel: the backward is cut at ControlNet stage boundaries into SEGMENT graphs -- a new segment starts
+                   whenever the gradient slice finalised so far (the flat buffer is laid out in backward-completion
+                   order) has reached `bucket_bytes`:
 
-    With one rank, A and B are a single graph.  Inputs are copied into static buffers before each replay.
-    `model` is a ControlFinetuneLDM-like module (p_losses / dp / control_model), `opt` its FusedAdamW.
+        graph S0 : zero_grad, forward, UNet-decoder backward, ControlNet middle + deepest stages
+        RCCL     : async all-reduce of flat_grad[bucket 0]            } runs on RCCL's stream while
+        graph S1 : the next ControlNet stages                          } graph S1 is executing
+        RCCL     : async all-reduce of flat_grad[bucket 1]  ...
+        graph SN : remaining stages; then every rank waits for its collectives
+        graph B  : fused AdamW (grad_scale = 1 / world) + re-pack
+
+    so the LoRA-only gradient exchange overlaps the remaining backward as in the eager path, with collectives kept
+    OUT of the captured regions.  `split_graphs`: None = segmented iff world > 1; "segmented" / True force that
+    structure on one rank (tests); "two" = the old A | all-reduce | B form; False = one graph.
+    `model` is a ControlFinetuneLDM-like module (engine_train_step or p_losses / dp / control_model), `opt` its
+    FusedAdamW.
     """
 
-    def __init__(self, model, opt, z, cond_txt, hint, t, noise, warmup: int = 2, split_graphs=None):
+    def __init__(self, model, opt, z, cond_txt, hint, t, noise, warmup: int = 2, split_graphs=None,
+                 bucket_bytes: int = 32 << 20, reduce_fn=None):
         import torch.distributed as dist
         self.model, self.opt = model, opt
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.dist = dist
-        # two graphs with the all-reduce in between whenever there is more than one rank (or when forced, to
-        # exercise that structure on a single GPU)
-        split = (self.world > 1) if split_graphs is None else bool(split_graphs)
+        if split_graphs is None:
+            mode = "segmented" if self.world > 1 else "one"
+        elif split_graphs in ("segmented", True):
+            mode = "segmented"
+        elif split_graphs == "two":
+            mode = "two"
+        else:
+            mode = "one"
+        self.mode = mode
         self.s_z, self.s_ctx, self.s_hint = z.clone(), cond_txt.clone(), hint.clone()
         self.s_t, self.s_noise = t.clone(), noise.clone()
         self.loss = None
         self.loss3 = None
         dp = model.dp
         if dp is not None:
-            dp.enabled = False          # no collectives inside the captured region
+            dp.enabled = False          # no collectives inside the captured regions: this class issues them itself
+        # reduce_fn(tensor_slice) -> work handle with .wait() or None; default: RCCL SUM all-reduce, asynchronous
+        if reduce_fn is None:
+            def reduce_fn(buf):
+                if dist.is_initialized() and self.world > 1:
+                    return dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+                return None
+        self._reduce_fn = reduce_fn
 
         direct = getattr(model, "engine_train_step", None)
 
@@ -185,10 +210,11 @@ class GraphedTrainStep:
             loss.backward()
             return loss.detach()
 
-        def reduce_grads():
-            if split and dist.is_initialized():
-                for ex in opt.executors:
-                    dist.all_reduce(ex.tr.flat_grad, op=dist.ReduceOp.SUM)
+        def reduce_all():
+            works = [self._reduce_fn(ex.tr.flat_grad) for ex in opt.executors]
+            for w in works:
+                if w is not None:
+                    w.wait()
 
         hook, opt.pre_step_hook = opt.pre_step_hook, None
         self._hook = hook
@@ -196,30 +222,105 @@ class GraphedTrainStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                fwd_bwd(); reduce_grads(); opt.step()
+                fwd_bwd()
+                if mode != "one":
+                    reduce_all()
+                opt.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.g_a = torch.cuda.CUDAGraph()
-        if not split:
-            with torch.cuda.graph(self.g_a):
+        self.segments = []               # [(graph, executor index or None, lo, hi)]
+        self.g_b = None
+        if mode == "one":
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
                 self.loss = fwd_bwd()
                 opt.step()
-            self.g_b = None
-        else:
-            with torch.cuda.graph(self.g_a):
+            self.segments.append((g, None, 0, 0))
+        elif mode == "two":
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
                 self.loss = fwd_bwd()
+            self.segments.append((g, "all", 0, 0))
             self.g_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_b, pool=self.g_a.pool()):
+            with torch.cuda.graph(self.g_b, pool=g.pool()):
                 opt.step()
-        self._reduce = reduce_grads
+        else:
+            self._capture_segments(fwd_bwd, max(1, bucket_bytes // 4))
+            self.g_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_b, pool=self._pool):
+                opt.step()
         self.warmup_steps = warmup
+
+    def _capture_segments(self, fwd_bwd, bucket_elems):
+        """Capture forward + backward as consecutive graphs that end where a gradient bucket is complete.  The
+        executors' stage-completion hook (ControlNetE._done -> on_stage_done(start, end), called after the stage's last
+        kernel was enqueued) closes the running capture and opens the next one in the same memory pool."""
+        opt = self.opt
+        execs = list(opt.executors)
+        saved_hooks = [ex.on_stage_done for ex in execs]
+        self._pool = torch.cuda.graph_pool_handle()
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        state = {"g": None, "lo": {id(ex): 0 for ex in execs}, "hi": {id(ex): 0 for ex in execs}}
+
+        def begin():
+            state["g"] = torch.cuda.CUDAGraph()
+            state["g"].capture_begin(pool=self._pool)
+
+        def end(tag, lo, hi):
+            state["g"].capture_end()
+            self.segments.append((state["g"], tag, lo, hi))
+            state["g"] = None
+
+        def make_hook(i, ex):
+            def on_stage(start, stop):
+                k = id(ex)
+                if start != state["hi"][k]:
+                    return                                  # out-of-order report: left to the final flush
+                state["hi"][k] = stop
+                if stop - state["lo"][k] >= bucket_elems and stop < ex.tr.numel:
+                    end(i, state["lo"][k], stop)
+                    state["lo"][k] = stop
+                    begin()
+            return on_stage
+
+        for i, ex in enumerate(execs):
+            ex.on_stage_done = make_hook(i, ex)
+        try:
+            torch.cuda.synchronize()
+            with torch.cuda.stream(stream):
+                begin()
+                self.loss = fwd_bwd()
+                # whatever has not been handed out yet (the tail of every bank) goes with the last segment
+                g_last = state["g"]
+                g_last.capture_end()
+                tails = [(i, state["lo"][id(ex)], ex.tr.numel) for i, ex in enumerate(execs) if state["lo"][id(ex)] < ex.tr.numel]
+                self.segments.append((g_last, "tails", tails, 0))
+            torch.cuda.current_stream().wait_stream(stream)
+            torch.cuda.synchronize()
+        finally:
+            for ex, h in zip(execs, saved_hooks):
+                ex.on_stage_done = h
 
     def __call__(self, z, cond_txt, hint, t, noise):
         self.s_z.copy_(z); self.s_ctx.copy_(cond_txt); self.s_hint.copy_(hint)
         self.s_t.copy_(t); self.s_noise.copy_(noise)
         self.opt.sync_hyper()
-        self.g_a.replay()
+        execs = self.opt.executors
+        works = []
+        for g, tag, lo, hi in self.segments:
+            g.replay()
+            if tag is None:
+                continue
+            if tag == "all":
+                works += [self._reduce_fn(ex.tr.flat_grad) for ex in execs]
+            elif tag == "tails":
+                works += [self._reduce_fn(execs[i].tr.flat_grad[a:b]) for i, a, b in lo]
+            else:
+                works.append(self._reduce_fn(execs[tag].tr.flat_grad[lo:hi]))   # overlaps the next segment's replay
+        for w in works:
+            if w is not None:
+                w.wait()
         if self.g_b is not None:
-            self._reduce()
             self.g_b.replay()
         return self.loss

@@ -535,3 +535,85 @@ def test_graphed_ddim_with_image_hint_resamples_the_posterior_on_the_device():
     # snaps[1:] are the static hint-latent buffer of the captured step after each replay: fresh noise every time
     for a, b in zip(snaps[1:-1], snaps[2:]):
         assert not torch.equal(a, b)
+
+
+def test_segmented_graph_step_hands_out_every_gradient_slice_once_and_matches_eager():
+    """Data-parallel form of GraphedTrainStep on ONE GPU: the backward is captured as segment graphs that end where a
+    gradient bucket is complete; between replays the bucket's slice of the flat gradient buffer is handed to the
+    reduction (here a recording stand-in for the RCCL all-reduce).  Every element must be handed out exactly once,
+    in several buckets, and the trajectory must equal eager steps."""
+    _need_gpu()
+    import bench
+    from ctrlora_amd.train import GraphedTrainStep
+    from oracle import arch
+    cfg = arch.TINY
+    inp = _inputs(cfg, 2, 16, 8)
+    cu = lambda v: v.cuda()
+
+    def make():
+        m = bench.build_model("ctrlora_finetune_sd15_rank128.yaml", 0, tiny=True).cuda().train()
+        m.set_engine_dtype(torch.float32)
+        m.learning_rate = 1e-3
+        return m, m.configure_optimizers()
+
+    ma, oa = make()
+    cond = {"c_crossattn": [cu(inp["ctx"])], "c_concat": [cu(inp["hint_z"])]}
+    losses = []
+    for _ in range(3):
+        oa.zero_grad()
+        loss, _ = ma.p_losses(cu(inp["z"]), cond, cu(inp["t"]), noise=cu(inp["noise"]))
+        loss.backward()
+        oa.step()
+        losses.append(float(loss))
+    mb, ob = make()
+    ex = mb.control_model.executor()
+    handed = []
+
+    def fake_reduce(buf):           # what dist.all_reduce would see; world size 1 -> values unchanged
+        off = (buf.data_ptr() - ex.tr.flat_grad.data_ptr()) // 4
+        handed.append((off, off + buf.numel()))
+        return None
+
+    g = GraphedTrainStep(mb, ob, cu(inp["z"]), cu(inp["ctx"]), cu(inp["hint_z"]), cu(inp["t"]), cu(inp["noise"]),
+                         warmup=1, split_graphs="segmented", bucket_bytes=256 << 10, reduce_fn=fake_reduce)
+    assert g.mode == "segmented" and len(g.segments) >= 3
+    handed.clear()
+    l2 = float(g(cu(inp["z"]), cu(inp["ctx"]), cu(inp["hint_z"]), cu(inp["t"]), cu(inp["noise"])))
+    spans = sorted(handed)
+    assert spans[0][0] == 0 and spans[-1][1] == ex.tr.numel
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:])), spans        # contiguous, no overlap, no gap
+    assert handed == spans                                                   # handed out in backward-completion order
+    l3 = float(g(cu(inp["z"]), cu(inp["ctx"]), cu(inp["hint_z"]), cu(inp["t"]), cu(inp["noise"])))
+    assert abs(l2 - losses[1]) < 1e-4 * abs(losses[1]) and abs(l3 - losses[2]) < 1e-4 * abs(losses[2])
+
+
+def test_dp_virtual_ranks_equal_one_large_batch_on_the_engine():
+    """DP-N == single process with the N-times batch.  Two 'virtual ranks' on one GPU: the
+    engine's gradients of two half batches, summed and scaled by 1/2 (what the all-reduce + grad_scale do), equal
+    the gradients of the full batch; the loss is the mean of the two."""
+    _need_gpu()
+    from ctrlora_amd.engine import CtrLoRAEngine
+    from oracle import arch
+    cfg = arch.TINY
+    inp = _inputs(cfg, 4, 16, 21)
+    sd_cn = arch.make_state(arch.controlnet_shapes(cfg), 21)
+    sd_un = arch.make_state(arch.unet_shapes(cfg), 21)
+    eng = CtrLoRAEngine(sd_un, [sd_cn], _netcfg(cfg), dtype=torch.float32, device="cuda")
+    cu = lambda v: v.cuda()
+
+    def run(rows):
+        eps = eng.forward(cu(inp["z"][rows]), cu(inp["t"][rows]), cu(inp["ctx"][rows]), [cu(inp["hint_z"][rows])], record=True)
+        eng.zero_grad()
+        nz = cu(inp["noise"][rows])
+        eng.backward(2.0 * (eps - nz) / eps.numel())
+        torch.cuda.synchronize()
+        return float(((eps - nz) ** 2).mean()), eng.controls[0].tr.flat_grad.clone()
+
+    l0, g0 = run(slice(0, 2))
+    l1, g1 = run(slice(2, 4))
+    lf, gf = run(slice(0, 4))
+    assert abs(0.5 * (l0 + l1) - lf) < 1e-5 * lf
+    assert rel_l2(0.5 * (g0 + g1), gf) < 1e-5
+    worst = max(rel_l2(0.5 * (g0 + g1)[t.offset:t.offset + t.master.numel()], gf[t.offset:t.offset + t.master.numel()])
+                for t in eng.controls[0].tr.items)
+    assert worst < 5e-5
