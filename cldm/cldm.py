@@ -121,6 +121,9 @@ class ControlLDM(LatentDiffusion):
         for m in (self.model.diffusion_model, self.control_model):
             m.engine_dtype = dtype
             m.invalidate_engine()
+        if hasattr(self.first_stage_model, "invalidate_engine"):
+            self.first_stage_model.engine_dtype = dtype
+            self.first_stage_model.invalidate_engine()
         self.__dict__.pop("_engine", None)
 
     def _control_executors(self):

@@ -124,7 +124,7 @@ int cl_conv3x3_fwd(int dtype, int mode, const void* x, long ldx, const void* Wp,
                    int Cout, const void* zero_page, void* stream) {
   GemmParams g = base_params();
   int Hout = Hin, Wout = Win;
-  if (mode == GEMM_CONV_S2) { Hout = Hin / 2; Wout = Win / 2; }
+  if (mode == GEMM_CONV_S2 || mode == GEMM_CONV_S2A) { Hout = Hin / 2; Wout = Win / 2; }
   else if (mode == GEMM_CONV_UP2 || mode == GEMM_CONV_T2) { Hout = 2 * Hin; Wout = 2 * Win; }
   else if (mode != GEMM_CONV_S1) return CL_EINVAL;
   g.mode = mode; g.A1 = x; g.lda1 = ldx; g.K1 = Cin; g.W1 = Wp; g.ldw1 = 9L * Cin;
@@ -247,6 +247,7 @@ int cl_ddim_step(const float* x, const float* e_c, const float* e_u, const float
 int cl_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) { return adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, S(stream)); }
 
 int cl_p_losses_mse(const float* eps, const float* target, float* d_eps, const long* t, const float* lvlb, float* out, float* per_sample, float* scratch, int B, long per_sample_elems, float gscale, float w_simple, float w_elbo, void* stream) { return plosses_mse(eps, target, d_eps, t, lvlb, out, per_sample, scratch, B, per_sample_elems, gscale, w_simple, w_elbo, S(stream)); }
+int cl_softmax_rows(int dtype, const float* Sm, long lds_, void* P, long ldp, long M, int N, float scale, void* stream) { return softmax_rows(dtype, Sm, lds_, P, ldp, M, N, scale, S(stream)); }
 int cl_zero(void* p, long nbytes, void* stream) { return zero_bytes(p, nbytes, S(stream)); }
 int cl_tick(int* counter, void* stream) { return tick(counter, S(stream)); }
 int cl_adamw_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, int* step, void* stream) { return adamw_dev(p, g, m, v, n, hyper, step, S(stream)); }

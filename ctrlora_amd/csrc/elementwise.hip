@@ -198,6 +198,55 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ eps,
   if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv);
 }
 
+// ---------------------------------------------------------------- row softmax (VAE mid-block attention)
+// one workgroup per row; N <= 256 * 32: the row lives in registers (16-byte loads), fp32 math, exp2 with the
+// scale folded in
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, long lds_, T* __restrict__ P,
+                                                           long ldp, int N, float scale) {
+  __shared__ float red[8];
+  const float* s = S + (long)blockIdx.x * lds_;
+  T* o = P + (long)blockIdx.x * ldp;
+  constexpr int MAXV = 8;                       // 8 x float4 per thread = 8192 columns
+  float4 v[MAXV];
+  const float sl2 = scale * 1.4426950408889634f;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (i * 256 + threadIdx.x) * 4;
+    if (c < N) {
+      v[i] = *reinterpret_cast<const float4*>(s + c);
+      mx = fmaxf(mx, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+    }
+  }
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * sl2;
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (i * 256 + threadIdx.x) * 4;
+    if (c < N) {
+      v[i].x = __builtin_amdgcn_exp2f(v[i].x * sl2 - mx); v[i].y = __builtin_amdgcn_exp2f(v[i].y * sl2 - mx);
+      v[i].z = __builtin_amdgcn_exp2f(v[i].z * sl2 - mx); v[i].w = __builtin_amdgcn_exp2f(v[i].w * sl2 - mx);
+      sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  sum = wave_sum(sum);
+  if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = sum;
+  __syncthreads();
+  const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (i * 256 + threadIdx.x) * 4;
+    if (c < N) {
+      const float w[4] = {v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv};
+      store4(o + c, w);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- p_losses reduction (ddpm.py:902-918)
 // Deterministic (no float atomics): block (chunk, b) reduces one slice of sample b into scratch[b][chunk] and
 // writes d_eps; the finishing block sums the slices in a fixed order:
@@ -537,6 +586,12 @@ int plosses_mse(const float* eps, const float* target, float* d_eps, const long*
   const float gmul = 2.0f * gscale * w_simple / ((float)per * (float)B);
   hipLaunchKernelGGL(plosses_partial_kernel, dim3(PL_CHUNKS, B), dim3(256), 0, st, eps, target, d_eps, scratch, per, gmul);
   hipLaunchKernelGGL(plosses_finish_kernel, dim3(1), dim3(64), 0, st, scratch, t, lvlb, out, per_sample, B, per, w_simple, w_elbo);
+  CL_CHECK_LAUNCH(); return CL_OK;
+}
+int softmax_rows(int dtype, const float* S, long lds_, void* P, long ldp, long M, int N, float scale, hipStream_t st) {
+  if (N % 4 || N > 8192 || lds_ % 4 || ldp % 4 || M <= 0) return CL_EINVAL;
+  if (dtype == CL_BF16) hipLaunchKernelGGL((softmax_rows_kernel<bf16_t>), dim3((unsigned)M), dim3(256), 0, st, S, lds_, (bf16_t*)P, ldp, N, scale);
+  else hipLaunchKernelGGL((softmax_rows_kernel<float>), dim3((unsigned)M), dim3(256), 0, st, S, lds_, (float*)P, ldp, N, scale);
   CL_CHECK_LAUNCH(); return CL_OK;
 }
 int zero_bytes(void* p, long nbytes, hipStream_t st) {

@@ -10,6 +10,7 @@ enum GemmMode {
   GEMM_CONV_S2 = 2,  // 3x3, stride 2, pad 1 (Downsample, openaimodel.py:150)
   GEMM_CONV_UP2 = 3, // 3x3 over the nearest-x2 upsampled input (Upsample, openaimodel.py:115-117)
   GEMM_CONV_T2 = 4,  // 3x3 over the zero-stuffed x2 grid (= data-gradient of GEMM_CONV_S2)
+  GEMM_CONV_S2A = 5, // 3x3, stride 2, pad (0,1,0,1): the VAE encoder's Downsample (ldm/modules/diffusionmodules/model.py:80-84)
 };
 
 enum GemmAct {

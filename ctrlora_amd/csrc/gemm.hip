@@ -295,11 +295,12 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_kernel(GemmParams p, i
     } else {
       const int tap = kt / cpt, cc = kt - tap * cpt;
       const int ky = tap / 3, kx = tap - ky * 3;
-      const int sy = (p.mode == GEMM_CONV_S2) ? 2 : 1;
+      const int sy = (p.mode == GEMM_CONV_S2 || p.mode == GEMM_CONV_S2A) ? 2 : 1;
+      const int po = (p.mode == GEMM_CONV_S2A) ? 0 : 1;     // left / top padding
       const bool virt = (p.mode == GEMM_CONV_UP2) | (p.mode == GEMM_CONV_T2);
 #pragma unroll
       for (int j = 0; j < AJ; ++j) {
-        const int vy = ay[j] * sy + ky - 1, vx = ax[j] * sy + kx - 1;
+        const int vy = ay[j] * sy + ky - po, vx = ax[j] * sy + kx - po;
         bool ok; int iy, ix;
         if (virt) {
           ok = ((unsigned)vy < (unsigned)(2 * p.Hin)) & ((unsigned)vx < (unsigned)(2 * p.Win));
@@ -566,11 +567,12 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p
       for (int j = 0; j < AJ; ++j) { glds16(cur[j], As + (j * NW + wave) * 1024); cur[j] += 128; }
     } else {
       const int ky = tap / 3, kx = tap - ky * 3;
-      const int sy = (p.mode == GEMM_CONV_S2) ? 2 : 1;
+      const int sy = (p.mode == GEMM_CONV_S2 || p.mode == GEMM_CONV_S2A) ? 2 : 1;
+      const int po = (p.mode == GEMM_CONV_S2A) ? 0 : 1;     // left / top padding
       const bool virt = (p.mode == GEMM_CONV_UP2) | (p.mode == GEMM_CONV_T2);
 #pragma unroll
       for (int j = 0; j < AJ; ++j) {
-        const int vy = ay[j] * sy + ky - 1, vx = ax[j] * sy + kx - 1;
+        const int vy = ay[j] * sy + ky - po, vx = ax[j] * sy + kx - po;
         bool ok; int iy, ix;
         if (virt) {
           ok = ((unsigned)vy < (unsigned)(2 * p.Hin)) & ((unsigned)vx < (unsigned)(2 * p.Win));

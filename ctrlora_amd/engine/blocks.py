@@ -173,7 +173,7 @@ class LayerNormOp:
 
 def conv3_fwd(ctx: Ctx, cw: Conv3W, x, B, Hin, Win, mode=hip.CONV_S1, out=None, rowbias=None, residual=None,
               out_f32=False):
-    if mode == hip.CONV_S2:
+    if mode in (hip.CONV_S2, hip.CONV_S2A):
         Ho, Wo = Hin // 2, Win // 2
     elif mode == hip.CONV_UP2:
         Ho, Wo = 2 * Hin, 2 * Win

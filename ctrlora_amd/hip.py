@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libctrlora_hip.so")
 
 BF16, F32 = 0, 1
-LINEAR, CONV_S1, CONV_S2, CONV_UP2, CONV_T2 = 0, 1, 2, 3, 4
+LINEAR, CONV_S1, CONV_S2, CONV_UP2, CONV_T2, CONV_S2A = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
 
 
@@ -98,6 +98,7 @@ _SIGS = {
     "cl_mse_loss": [_P, _P, _P, _P, _L, _F, _P],
     "cl_p_losses_mse": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _P],
     "cl_zero": [_P, _L, _P],
+    "cl_softmax_rows": [_I, _P, _L, _P, _L, _L, _I, _F, _P],
     "cl_ddim_step": [_P, _P, _P, _P, _P, _I, _F, _P, _P, _L, _P],
     "cl_tick": [_P, _P],
     "cl_adamw_dev": [_P, _P, _P, _P, _L, _P, _P, _P],
@@ -450,6 +451,14 @@ def p_losses_mse(eps, target, d_eps, t, lvlb, out3, scratch, gscale=1.0, w_simpl
                                ptr(per_sample), scratch.data_ptr(), B, eps.numel() // B, gscale, w_simple, w_elbo,
                                stream()), "cl_p_losses_mse")
     return out3
+
+
+def softmax_rows(scores_f32, probs, scale=1.0):
+    """probs[M,N] (engine dtype) = softmax(scores_f32[M,N] * scale) per row."""
+    M, N = scores_f32.shape
+    _chk(lib().cl_softmax_rows(dt(probs), scores_f32.data_ptr(), ld(scores_f32), probs.data_ptr(), ld(probs), M, N, scale,
+                               stream()), "cl_softmax_rows")
+    return probs
 
 
 def zero_(t):

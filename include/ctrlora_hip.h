@@ -64,7 +64,9 @@ enum cl_gemm_mode {
   CL_GEMM_CONV_S1 = 1,  /* A1 = NHWC [B,Hin,Win,K1]; 3x3 stride 1 pad 1                      */
   CL_GEMM_CONV_S2 = 2,  /* 3x3 stride 2 pad 1                                                */
   CL_GEMM_CONV_UP2 = 3, /* 3x3 over nearest-x2 upsampled input                               */
-  CL_GEMM_CONV_T2 = 4   /* 3x3 over zero-stuffed x2 grid: data-gradient of CL_GEMM_CONV_S2   */
+  CL_GEMM_CONV_T2 = 4,  /* 3x3 over zero-stuffed x2 grid: data-gradient of CL_GEMM_CONV_S2   */
+  CL_GEMM_CONV_S2A = 5  /* 3x3 stride 2, pad (0,1,0,1): AutoencoderKL's Downsample
+                           (ldm/modules/diffusionmodules/model.py:80-84)                        */
 };
 
 typedef struct cl_gemm_params {
@@ -212,6 +214,10 @@ int cl_repack(int dtype, const float* flat, const long* desc, const int* tile_pr
               int total_tiles, void* stream);
 /* timestep_embedding (util.py:154-174); freqs = the fp32 table exp(-ln(1e4) * arange(half)/half) */
 int cl_timestep_embedding(int dtype, const long* t, const float* freqs, void* out, long ldo, int B, int half, void* stream);
+
+/* Row softmax for the VAE's single-head attention (ldm/modules/diffusionmodules/model.py:183-186): fp32 scores
+ * S [M, N] (row stride lds) -> `dtype` probabilities P [M, N] (row stride ldp), P = softmax(S * scale) per row. */
+int cl_softmax_rows(int dtype, const float* S, long lds, void* P, long ldp, long M, int N, float scale, void* stream);
 
 /* ---- diffusion bookkeeping ------------------------------------------------------------ */
 /* DDPM.q_sample (ddpm.py:356-359): out = sqrt_ac[t_b] * z + sqrt_1mac[t_b] * noise */

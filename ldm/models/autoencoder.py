@@ -1,8 +1,9 @@
 """AutoencoderKL (API of ldm/models/autoencoder.py:11-119 + ldm/modules/diffusionmodules/model.py).
 
-The frozen SD VAE is SURVEY.md row 8(f1) "next": it is not on the hand-written path yet and runs
-as ordinary PyTorch modules (MIOpen).  Same module tree / state-dict keys as the reference so the SD
-checkpoint loads; benchmarks and parity tests feed 4-channel latents and never call it.
+Same module tree / state-dict keys as the reference so the SD checkpoint loads.  On a GPU, under no_grad (the first
+stage is frozen), encode / decode run on the HIP engine (ctrlora_amd/engine/vae.py: the implicit-GEMM convs, GroupNorm
++ swish, the single-head 512-channel attention as two MFMA GEMMs around a row softmax) -- SURVEY.md row 8(f1); the
+plain torch modules below remain the CPU path and the definition of the parameter tree.
 """
 import torch
 import torch.nn as nn
@@ -168,11 +169,43 @@ class AutoencoderKL(nn.Module):
         self.quant_conv = nn.Conv2d(2 * ddconfig["z_channels"], 2 * embed_dim, 1)
         self.post_quant_conv = nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
         self.embed_dim = embed_dim
+        self.ddconfig = dict(ddconfig)
+        self.engine_dtype = None          # torch.bfloat16 (default) / torch.float32 (parity mode); set by ControlLDM
+        self.use_engine = True            # False: the plain torch modules below (CPU, or A/B against MIOpen)
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_engine())
+
+    # ---- HIP engine (ctrlora_amd/engine/vae.py): packed once from this module's own (frozen) parameters
+    def invalidate_engine(self):
+        self.__dict__.pop("_enc", None)
+        self.__dict__.pop("_dec", None)
+
+    def _engine(self, which: str):
+        ex = self.__dict__.get("_" + which)
+        if ex is None:
+            import os
+            from ctrlora_amd.engine.vae import VAEDecoderE, VAEEncoderE
+            dtype = self.engine_dtype
+            if dtype is None:
+                env = os.environ.get("CTRLORA_ENGINE_DTYPE", "bf16").lower()
+                dtype = torch.float32 if env in ("f32", "fp32", "float32") else torch.bfloat16
+            dev = next(self.parameters()).device
+            cls = VAEEncoderE if which == "enc" else VAEDecoderE
+            ex = cls({k: v for k, v in self.state_dict().items()}, self.ddconfig, dtype, dev)
+            self.__dict__["_" + which] = ex
+        return ex
+
+    def _on_engine(self, x):
+        return (self.use_engine and x.is_cuda and not torch.is_grad_enabled() and not self.ddconfig.get("attn_resolutions")
+                and x.shape[-1] % 8 == 0 and x.shape[-2] % 8 == 0)
 
     def encode(self, x):
+        if self._on_engine(x) and (x.shape[-1] * x.shape[-2]) % 2048 == 0:
+            return DiagonalGaussianDistribution(self._engine("enc")(x))
         return DiagonalGaussianDistribution(self.quant_conv(self.encoder(x)))
 
     def decode(self, z):
+        if self._on_engine(z) and (z.shape[-1] * z.shape[-2]) % 32 == 0:
+            return self._engine("dec")(z)
         return self.decoder(self.post_quant_conv(z))
 
     def forward(self, input, sample_posterior=True):
