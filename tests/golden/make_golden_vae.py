@@ -29,7 +29,7 @@ def test_image(B, H, W):
     y = torch.linspace(-1, 1, H).view(1, 1, H, 1)
     x = torch.linspace(-1, 1, W).view(1, 1, 1, W)
     b = torch.arange(B, dtype=torch.float32).view(B, 1, 1, 1)
-    base = torch.cat([torch.sin(3.1 * x + 2.0 * y + b), torch.cos(5.3 * x * y - b), torch.sin(7.0 * (x * x + y * y))], 1)
+    base = torch.cat([torch.sin(3.1 * x + 2.0 * y + b), torch.cos(5.3 * x * y - b), torch.sin(7.0 * (x * x + y * y)).expand(B, -1, -1, -1)], 1)
     edges = ((torch.sin(9.0 * x + b) * torch.cos(11.0 * y) > 0.3).float() * 2 - 1)
     return (0.6 * base + 0.4 * edges).clamp(-1, 1).contiguous()
 

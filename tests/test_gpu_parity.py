@@ -531,7 +531,7 @@ def test_graphed_ddim_with_image_hint_resamples_the_posterior_on_the_device():
                           img_callback=lambda p0, i: snaps.append(seen[-1].clone()))
     assert torch.isfinite(x).all()
     assert vae.calls == 1                                   # encoded once per run (hint cache)
-    assert len(snaps) == S
+    assert len(snaps) == len(sampler.ddim_timesteps)      # 7 for S = 6: range(0, 1000, 1000 // 6), as the reference
     # snaps[1:] are the static hint-latent buffer of the captured step after each replay: fresh noise every time
     for a, b in zip(snaps[1:-1], snaps[2:]):
         assert not torch.equal(a, b)
