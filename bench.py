@@ -36,12 +36,15 @@ DDIM_TFLOP_PER_STEP_IMAGE = 2.207
 PEAK_BF16_TFLOPS = 2500.0
 
 
-def build_model(config, seed, rank_override=None, tiny=False):
-    """The drop-in path: YAML -> instantiate_from_config, VAE / CLIP replaced by Identity (synthetic latents)."""
+def build_model(config, seed, rank_override=None, tiny=False, mutate=None):
+    """The drop-in path: YAML -> instantiate_from_config, VAE / CLIP replaced by Identity (synthetic latents).
+    `mutate(params)` may edit the YAML's model params before instantiation (tests)."""
     from ldm.util import instantiate_from_config
     with open(os.path.join(ROOT, "configs", config)) as f:
         cfg = yaml.safe_load(f)["model"]
     p = cfg["params"]
+    if mutate is not None:
+        mutate(p)
     p["first_stage_config"] = {"target": "torch.nn.Identity"}
     p["cond_stage_config"] = {"target": "torch.nn.Identity"}
     if tiny:

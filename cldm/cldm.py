@@ -151,7 +151,7 @@ class ControlLDM(LatentDiffusion):
                     # a foreign optimizer ran zero_grad(set_to_none=True): gradients were cleared -> re-attach
                     ex.tr.flat_grad.zero_()
                     for p, t in zip(bound, ex.tr.items):
-                        p.grad = t.grad
+                        p.grad = t.param_view(t.grad)
                 ver = trainables_version(bound)
                 if owner.__dict__.get("_bound_version") != ver:
                     ex.repack()

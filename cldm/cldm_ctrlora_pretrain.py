@@ -1,8 +1,9 @@
 """Multi-task Base-ControlNet pre-training classes (API of cldm/cldm_ctrlora_pretrain.py).
 
-Module tree, `loras_dict` banks, `switch_lora(task)` and the forward / sampling path are provided.
-Pre-TRAINING optimises every ControlNet weight (:174-182), i.e. needs weight gradients for all convs
-and linears; that is SURVEY.md 8(f3) "next" work and raises NotImplementedError for now.
+Module tree, `loras_dict` banks, `switch_lora(task)`, the forward / sampling path and the TRAINING path: pre-training
+optimises every ControlNet weight (:174-182), so the engine forms the weight gradient of every conv (one tap at a time,
+gathered inside the weight-gradient kernel's addressing), linear, bias and norm next to the task's LoRA factors; the
+base weights live in one flat fp32 buffer, each task's LoRA bank in its own (ctrlora_amd.train.PretrainAdamW).
 """
 import torch
 import torch.nn as nn
@@ -23,24 +24,105 @@ class ControlNetPretrain(ControlNet):
             task: nn.ModuleList([LoRALinearLayer(m.in_features, m.out_features, rank=lora_rank) for m in linears])
             for task in self.tasks})
         self._lora_linears = swap_linears(self, lambda m: None, skip=("loras_dict",))
+        ids = {id(m): n for n, m in self.named_modules()}
+        self._lora_names = [ids[id(m)] for m in self._lora_linears]
         self._task = None
 
     def switch_lora(self, task: str):
+        """:68-76 -- point every LoRACompatibleLinear at the task's bank.  The executor is kept (an optimizer may hold
+        its flat buffers): the engine swaps the active LoRA bank and re-packs only the LoRA factors."""
         assert task in self.tasks
         for lin, lora in zip(self._lora_linears, self.loras_dict[task]):
             lin.set_lora_layer(lora)
         if task != self._task:
             self._task = task
-            self.invalidate_engine()
+            ex = self.__dict__.get("_exec")
+            if ex is not None:
+                ex.switch_bank(self.bank(task))
 
     def _executor_state(self):
         return {k: v for k, v in self.state_dict().items() if not k.startswith("loras_dict.")}
 
     def _on_state_loaded(self):
-        self.invalidate_engine()
+        ex = self.__dict__.get("_exec")
+        if ex is not None:       # every tensor of the executor is a bound trainable: the load wrote through to the masters
+            ex.repack()
+
+    # ---- engine: base weights trainable (one flat buffer), one flat LoRA bank per task
+    def executor(self):
+        ex = self.__dict__.get("_exec")
+        if ex is None:
+            from ctrlora_amd.engine import ControlNetE
+            from ctrlora_amd.train import bind_trainables
+            if self._task is None:
+                self.switch_lora(self.tasks[0])
+            ex = ControlNetE(self._executor_state(), self.net_cfg(), self._engine_dtype(), self._device(), train_all=True)
+            self.__dict__["_exec"] = ex
+            self.__dict__["_banks"] = {self._task: ex.tr_lora}
+            self.__dict__["_bound"] = bind_trainables(self, ex)
+            self._bind_bank(self._task)
+        return ex
+
+    def _bank_params(self, task):
+        out = {}
+        for name, lora in zip(self._lora_names, self.loras_dict[task]):
+            out[f"{name}.lora_layer.down.weight"] = lora.down.weight
+            out[f"{name}.lora_layer.up.weight"] = lora.up.weight
+        return out
+
+    def _bind_bank(self, task):
+        from ctrlora_amd.train import bind_bank
+        bind_bank(self._bank_params(task), self.__dict__["_banks"][task])
+
+    def bank(self, task):
+        """The task's LoRA bank as a flat trainable set (created from the module's loras_dict[task] on first use)."""
+        self.executor()
+        banks = self.__dict__["_banks"]
+        ts = banks.get(task)
+        if ts is None:
+            from ctrlora_amd.engine.packing import TrainableSet
+            proto = next(iter(banks.values()))
+            ts = TrainableSet()
+            for t in proto.items:
+                ts.declare(t.name, t.shape)
+            ts.materialize({k: v.detach() for k, v in self._bank_params(task).items()}, self._device())
+            banks[task] = ts
+            self._bind_bank(task)
+        return ts
+
+    def invalidate_engine(self):
+        if self.__dict__.get("_exec") is not None:
+            # the flat buffers back the nn.Parameters: give them their own storage again before dropping the executor
+            with torch.no_grad():
+                for p in self.parameters():
+                    p.data = p.data.clone()
+                    p.grad = None
+        for k in ("_exec", "_banks", "_bound", "_bound_version"):
+            self.__dict__.pop(k, None)
 
     def forward(self, hint, timesteps, context, **kwargs):
         return self._latent_forward(hint, timesteps, context)
+
+
+class _PretrainDP:
+    """Gradient exchange of multi-task pre-training (ctrlora_amd.parallel.BankedGradAllReduce) behind the hooks the
+    training glue calls: the shared buffer and the banks live anywhere this step are summed over ranks."""
+
+    def __init__(self, cm):
+        from ctrlora_amd.parallel import BankedGradAllReduce
+        ex = cm.executor()
+        self.cm = cm
+        self.inner = BankedGradAllReduce([ex.tr.flat_grad], {t: cm.bank(t).flat_grad for t in cm.tasks})
+        self.world_size = self.inner.world_size
+        self.enabled = True
+        self.live = []
+
+    def on_backward_done(self):
+        if self.enabled:
+            self.live = self.inner.exchange([self.cm._task])
+
+    def wait(self):
+        pass
 
 
 class ControlPretrainLDM(ControlLDM):
@@ -58,16 +140,43 @@ class ControlPretrainLDM(ControlLDM):
         return x, c_dict
 
     def apply_model(self, x_noisy, t, cond, *args, **kwargs):
+        """:95-111 -- the task named in the batch selects the LoRA bank; training back-propagates into EVERY ControlNet
+        parameter (base weights + that bank)."""
         assert isinstance(cond, dict)
-        cond_txt = torch.cat(cond["c_crossattn"], 1)
+        cc = cond["c_crossattn"]
+        cond_txt = cc[0] if len(cc) == 1 else torch.cat(cc, 1)
         if cond["c_concat"] is None:
             return self._run(x_noisy, t, cond_txt, None)
         self.control_model.switch_lora(cond["task"])
-        self.__dict__.pop("_engine", None)
         if torch.is_grad_enabled() and self.training:
-            raise NotImplementedError("Base-ControlNet pre-training (all ControlNet weights trainable) is not built "
-                                      "yet; LoRA fine-tuning and sampling are (see DESIGN.md, scope)")
+            opt = self.__dict__.get("_opt")
+            if opt is not None:
+                opt.mark_used(cond["task"])
+            if self.dp is not None and isinstance(self.dp, _PretrainDP):
+                for t in self.dp.live:               # banks other ranks trained last step: they carry gradients now
+                    if opt is not None:
+                        opt.mark_used(t)
         return self._run(x_noisy, t, cond_txt, [self._hint_latent(cond)])
 
+    def init_data_parallel(self):
+        """Install the bank-sparse gradient exchange (call after torch.distributed is initialised)."""
+        self.dp = _PretrainDP(self.control_model)
+        return self.dp
+
     def configure_optimizers(self):
-        raise NotImplementedError("Base-ControlNet pre-training is SURVEY.md 8(f3) 'next' work")
+        """:174-182 -- AdamW over list(control_model.parameters()) (base ControlNet + every task's LoRA bank)."""
+        import os
+        from ctrlora_amd.train import PretrainAdamW
+        cm = self.control_model
+        ex = cm.executor()
+        banks = {t: cm.bank(t) for t in cm.tasks}
+        params = list(cm.parameters())
+        print(f"Optimizable params: {sum(p.numel() for p in params) / 1e6:.1f}M")
+        os.makedirs("./tmp", exist_ok=True)
+        with open("./tmp/pretrain_trainable_params.txt", "w") as f:
+            for n, _ in cm.named_parameters():
+                f.write(n + "\n")
+        world = 1 if self.dp is None else self.dp.world_size
+        opt = PretrainAdamW(params, ex, banks, lr=self.learning_rate, grad_scale=1.0 / world)
+        self.__dict__["_opt"] = opt
+        return opt

@@ -21,7 +21,7 @@ static GemmParams base_params() {
 
 extern "C" {
 
-int cl_abi_version(void) { return 3; }
+int cl_abi_version(void) { return 4; }
 int cl_last_hip_error(void) { return g_last_hip_error; }
 const char* cl_last_hip_error_string(void) { return hipGetErrorString((hipError_t)g_last_hip_error); }
 
@@ -247,6 +247,7 @@ int cl_ddim_step(const float* x, const float* e_c, const float* e_u, const float
 int cl_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) { return adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, S(stream)); }
 
 int cl_p_losses_mse(const float* eps, const float* target, float* d_eps, const long* t, const float* lvlb, float* out, float* per_sample, float* scratch, int B, long per_sample_elems, float gscale, float w_simple, float w_elbo, void* stream) { return plosses_mse(eps, target, d_eps, t, lvlb, out, per_sample, scratch, B, per_sample_elems, gscale, w_simple, w_elbo, S(stream)); }
+int cl_conv_tap_gather(int dtype, const void* x, long ldx, void* out, long ldo, int B, int Hin, int Win, int Hout, int Wout, int C, int tap, int stride, int pad, void* stream) { return conv_tap_gather(dtype, x, ldx, out, ldo, B, Hin, Win, Hout, Wout, C, tap, stride, pad, S(stream)); }
 int cl_softmax_rows(int dtype, const float* Sm, long lds_, void* P, long ldp, long M, int N, float scale, void* stream) { return softmax_rows(dtype, Sm, lds_, P, ldp, M, N, scale, S(stream)); }
 int cl_zero(void* p, long nbytes, void* stream) { return zero_bytes(p, nbytes, S(stream)); }
 int cl_tick(int* counter, void* stream) { return tick(counter, S(stream)); }

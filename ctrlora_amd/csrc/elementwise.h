@@ -21,6 +21,8 @@ int plosses_mse(const float* eps, const float* target, float* d_eps, const long*
                 float* per_sample, float* scratch, int B, long per, float gscale, float w_simple, float w_elbo,
                 hipStream_t st);
 int zero_bytes(void* p, long nbytes, hipStream_t st);
+int conv_tap_gather(int dtype, const void* x, long ldx, void* out, long ldo, int B, int Hin, int Win, int Hout, int Wout,
+                    int C, int tap, int stride, int pad, hipStream_t st);
 int softmax_rows(int dtype, const float* S, long lds_, void* P, long ldp, long M, int N, float scale, hipStream_t st);
 int ddim_step(const float* x, const float* e_c, const float* e_u, const float* noise, const float* coef, int index,
               float scale, float* x_prev, float* pred_x0, long n, hipStream_t st);

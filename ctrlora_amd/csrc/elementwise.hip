@@ -198,6 +198,24 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ eps,
   if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv);
 }
 
+// ---------------------------------------------------------------- 3x3-conv tap gather (fp32 parity mode of the conv dW)
+// out[m, :] = x[pixel(m, tap), :] or 0 outside the image, m = (b, oy, ox): the shifted operand of one tap of a conv
+// weight gradient.  The bf16 path does this inside wgrad_tn_kernel's DMA addressing; the fp32 parity mode, whose
+// weight-gradient kernel wants explicit transposes anyway, materialises it.
+template <typename T>
+__global__ void conv_tap_gather_kernel(const T* __restrict__ x, long ldx, T* __restrict__ out, long ldo, int Hin, int Win,
+                                       int Hout, int Wout, int C8, int tap, int stride, int pad, long total) {
+  const int ky = tap / 3, kx = tap - 3 * ky;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / C8; const int c = (int)(i - m * C8) * 8;
+    const int ox = (int)(m % Wout); const long t2 = m / Wout; const int oy = (int)(t2 % Hout); const long ob = t2 / Hout;
+    const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
+    float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win) load8(x + ((ob * Hin + iy) * Win + ix) * ldx + c, f);
+    store8(out + m * ldo + c, f);
+  }
+}
+
 // ---------------------------------------------------------------- row softmax (VAE mid-block attention)
 // one workgroup per row; N <= 256 * 32: the row lives in registers (16-byte loads), fp32 math, exp2 with the
 // scale folded in
@@ -588,6 +606,14 @@ int plosses_mse(const float* eps, const float* target, float* d_eps, const long*
   hipLaunchKernelGGL(plosses_finish_kernel, dim3(1), dim3(64), 0, st, scratch, t, lvlb, out, per_sample, B, per, w_simple, w_elbo);
   CL_CHECK_LAUNCH(); return CL_OK;
 }
+int conv_tap_gather(int dtype, const void* x, long ldx, void* out, long ldo, int B, int Hin, int Win, int Hout, int Wout,
+                    int C, int tap, int stride, int pad, hipStream_t st) {
+  if (C % 8 || ldx % 8 || ldo % 8 || tap < 0 || tap > 8) return CL_EINVAL;
+  const long total = (long)B * Hout * Wout * (C / 8);
+  if (dtype == CL_BF16) hipLaunchKernelGGL((conv_tap_gather_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, st, (const bf16_t*)x, ldx, (bf16_t*)out, ldo, Hin, Win, Hout, Wout, C / 8, tap, stride, pad, total);
+  else hipLaunchKernelGGL((conv_tap_gather_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, st, (const float*)x, ldx, (float*)out, ldo, Hin, Win, Hout, Wout, C / 8, tap, stride, pad, total);
+  CL_CHECK_LAUNCH(); return CL_OK;
+}
 int softmax_rows(int dtype, const float* S, long lds_, void* P, long ldp, long M, int N, float scale, hipStream_t st) {
   if (N % 4 || N > 8192 || lds_ % 4 || ldp % 4 || M <= 0) return CL_EINVAL;
   if (dtype == CL_BF16) hipLaunchKernelGGL((softmax_rows_kernel<bf16_t>), dim3((unsigned)M), dim3(256), 0, st, S, lds_, (bf16_t*)P, ldp, N, scale);
@@ -654,7 +680,8 @@ int pack2d(int dtype, const float* in, long ldi, void* out, long ldo, long R, in
 // gradient).  Round 0 issued one pack + one transpose launch per matrix (~500 launches / 2.6 ms per
 // step); this is ONE launch over a device-resident descriptor table: workgroup -> (matrix, 32x32 tile)
 // by binary search in the tile prefix, fp32 tile in, straight and transposed tiles out.
-//   desc[i] = {src offset (floats) in the flat master, rows << 32 | cols, dst pointer, dst^T pointer (or 0)}
+//   desc[i] = {src offset (floats) in the flat master, rows << 32 | cols, dst pointer, dst^T pointer (or 0),
+//              src row stride, dst row stride, dst^T row stride (0 = dense), reserved}
 template <typename T>
 __global__ __launch_bounds__(256) void repack_kernel(const float* __restrict__ flat, const long* __restrict__ desc,
                                                      const int* __restrict__ tile_prefix, int ndesc) {
@@ -665,11 +692,12 @@ __global__ __launch_bounds__(256) void repack_kernel(const float* __restrict__ f
     const int mid = (lo + hi) >> 1;
     if (tile_prefix[mid + 1] > blk) hi = mid; else lo = mid + 1;
   }
-  const long* d = desc + (long)lo * 4;
+  const long* d = desc + (long)lo * 8;
   const long src = d[0];
   const int R = (int)(d[1] >> 32), C = (int)(d[1] & 0xffffffff);
   T* dst = reinterpret_cast<T*>(d[2]);
   T* dstT = reinterpret_cast<T*>(d[3]);
+  const long lds_ = d[4] ? d[4] : C, ldd = d[5] ? d[5] : C, ldt = d[6] ? d[6] : R;
   const int t = blk - tile_prefix[lo];
   const int tc = (C + 31) / 32;
   const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
@@ -677,16 +705,16 @@ __global__ __launch_bounds__(256) void repack_kernel(const float* __restrict__ f
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = r0 + ty + 8 * i, c = c0 + tx;
-    const float v = (r < R && c < C) ? flat[src + (long)r * C + c] : 0.f;
+    const float v = (r < R && c < C) ? flat[src + (long)r * lds_ + c] : 0.f;
     tile[ty + 8 * i][tx] = v;
-    if (dst && r < R && c < C) dst[(long)r * C + c] = from_f<T>(v);
+    if (dst && r < R && c < C) dst[(long)r * ldd + c] = from_f<T>(v);
   }
   if (!dstT) return;
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = c0 + ty + 8 * i, r = r0 + tx;
-    if (r < R && c < C) dstT[(long)c * R + r] = from_f<T>(tile[tx][ty + 8 * i]);
+    if (r < R && c < C) dstT[(long)c * ldt + r] = from_f<T>(tile[tx][ty + 8 * i]);
   }
 }
 

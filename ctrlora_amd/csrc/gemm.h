@@ -54,7 +54,13 @@ int gemm_set_stream_workspace(hipStream_t st, void* p, long bytes);
 int launch_wgrad_tn(const void* dy, long lddy, const void* x, long ldx, float* dW, long lddw, int M, int N, int K,
                     float alpha, const void* zero_page, hipStream_t stream);
 // grouped form: many (dy, x, dW) problems in one launch (+ one reduce launch)
-struct WgradDesc { const void* dy; long lddy; const void* x; long ldx; float* dW; long lddw; int M, N, K; float alpha; };
+// tap >= 0: x is an NHWC activation [B*Hin*Win, K] and row m = (b, oy, ox) of dy pairs with the input pixel
+// (oy*stride + tap/3 - pad, ox*stride + tap%3 - pad) (zero outside the image): one tap of a 3x3 conv's weight gradient,
+// dW pointing at that tap's [N, K] slice of a [N][9][K] gradient (lddw = 9 K).  tap < 0: plain dy^T x.
+struct WgradDesc {
+  const void* dy; long lddy; const void* x; long ldx; float* dW; long lddw; int M, N, K; float alpha;
+  int tap, Hin, Win, Hout, Wout, stride, pad, reserved;
+};
 int launch_wgrad_tn_group(const WgradDesc* probs, int n, const void* zero_page, hipStream_t stream);
 extern int g_wgrad_blocks, g_wgrad_min_steps, g_wgrad_ring;
 extern int g_fl128_split_want, g_tiny_m_minsub;

@@ -44,6 +44,9 @@ struct WgradProb {
   int tiles_k, tiles, per, splits;   // k-tiles per row of tiles, tiles, 32-row steps per split, splits
   int blk0;                          // first workgroup id of this problem
   int red0;                          // first reduce-kernel workgroup id of this problem
+  int tap;                           // >= 0: 3x3-conv tap mode (x rows gathered through the conv geometry)
+  short Hin, Win, Hout, Wout;        // conv geometry (<= 32767)
+  short stride, pad;
 };
 constexpr int WGRAD_MAX_PROBS = 24;
 struct WgradGroup { int n; int pad; WgradProb p[WGRAD_MAX_PROBS]; };
@@ -102,7 +105,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const WgradGroup grp, 
       const long m = (long)step * 32 + rowi[j];
       const bool ok = m < M;                                          // rows past M contribute zeros
       glds16(ok ? sdy[j] + m * lddy * 2 : zsrc, base + (2 * wave + j) * 1024);
-      glds16(ok ? sx[j] + m * ldx * 2 : zsrc, base + TILE + (2 * wave + j) * 1024);
+      if (P.tap < 0) {                                                 // (wave-uniform)
+        glds16(ok ? sx[j] + m * ldx * 2 : zsrc, base + TILE + (2 * wave + j) * 1024);
+      } else {   // conv tap: dy row (b, oy, ox) pairs with input pixel (oy s + ky - pad, ox s + kx - pad)
+        const int mi = (int)m, ox = mi % P.Wout, t2 = mi / P.Wout, oy = t2 % P.Hout, ob = t2 / P.Hout;
+        const int ky = P.tap / 3, kx = P.tap - 3 * ky;
+        const int iy = oy * P.stride + ky - P.pad, ix = ox * P.stride + kx - P.pad;
+        const bool okx = ok & ((unsigned)iy < (unsigned)P.Hin) & ((unsigned)ix < (unsigned)P.Win);
+        const long xr = ((long)ob * P.Hin + iy) * P.Win + ix;
+        glds16(okx ? sx[j] + xr * ldx * 2 : zsrc, base + TILE + (2 * wave + j) * 1024);
+      }
     }
   };
 
@@ -255,6 +267,9 @@ int launch_wgrad_tn_group(const WgradDesc* probs, int n, const void* zero_page, 
     if (d.N % 8 || d.K % 8 || d.lddy % 8 || d.ldx % 8 || d.lddw % 4 || d.N < 8 || d.K < 8 ||
         (reinterpret_cast<uintptr_t>(d.dW) & 15))
       return CL_EINVAL;
+    if (d.tap > 8 || (d.tap >= 0 && (d.Hin <= 0 || d.Win <= 0 || d.Hout <= 0 || d.Wout <= 0 || d.Hin > 32767 || d.Win > 32767 ||
+                                     d.stride < 1 || d.stride > 2 || d.M % (d.Hout * d.Wout))))
+      return CL_EINVAL;
     tiles_all += (long)((d.N + 127) / 128) * ((d.K + 127) / 128);
   }
   if (tiles_all == 0) return CL_OK;
@@ -292,6 +307,8 @@ int launch_wgrad_tn_group(const WgradDesc* probs, int n, const void* zero_page, 
     P.lddy = d.lddy; P.ldx = d.ldx; P.lddw = d.lddw; P.M = d.M; P.N = d.N; P.K = d.K; P.alpha = d.alpha;
     P.tiles_k = tk; P.tiles = tn * tk; P.per = pp; P.splits = splits;
     P.blk0 = nblocks; P.red0 = nred;
+    P.tap = d.tap; P.Hin = (short)d.Hin; P.Win = (short)d.Win; P.Hout = (short)d.Hout; P.Wout = (short)d.Wout;
+    P.stride = (short)d.stride; P.pad = (short)d.pad;
     nblocks += tn * tk * splits;
     if (splits > 1) nred += (int)(((long)d.N * (d.K / 4) + 255) / 256);
     ws_used += (need + 255) & ~255L;
@@ -302,8 +319,8 @@ int launch_wgrad_tn_group(const WgradDesc* probs, int n, const void* zero_page, 
 
 int launch_wgrad_tn(const void* dy, long lddy, const void* x, long ldx, float* dW, long lddw, int M, int N, int K,
                     float alpha, const void* zero_page, hipStream_t stream) {
-  WgradDesc d; d.dy = dy; d.lddy = lddy; d.x = x; d.ldx = ldx; d.dW = dW; d.lddw = lddw; d.M = M; d.N = N; d.K = K;
-  d.alpha = alpha;
+  WgradDesc d{}; d.dy = dy; d.lddy = lddy; d.x = x; d.ldx = ldx; d.dW = dW; d.lddw = lddw; d.M = M; d.N = N; d.K = K;
+  d.alpha = alpha; d.tap = -1;
   return launch_wgrad_tn_group(&d, 1, zero_page, stream);
 }
 

@@ -38,8 +38,8 @@ class Ctx:
         # queued weight-gradient problems (dy, x, dW, scale): flushed as ONE grouped launch per block
         self._wq: list = []
 
-    def queue_wgrad(self, dy, x, dW, scale=1.0):
-        self._wq.append((dy, x, dW, scale))        # keeps dy / x alive until the flush
+    def queue_wgrad(self, dy, x, dW, scale=1.0, conv=None):
+        self._wq.append((dy, x, dW, scale, conv))  # keeps dy / x alive until the flush
         if len(self._wq) >= 24:
             self.flush_wgrad()
 
@@ -118,6 +118,34 @@ def linear_bwd_lora(ctx: Ctx, L: LinearW, x, t, dy, u):
         return
     hip.weight_grad(ctx.transposed(dy), ctx.transposed(t), L.tB.grad)
     hip.weight_grad(ctx.transposed(u), ctx.transposed(x), L.tA.grad)
+
+
+def base_bwd_weight(ctx: Ctx, L: LinearW, x, dy):
+    """Base-ControlNet pre-training: dW += dy^T x, db += colsum(dy) of a linear whose dense weight trains (no-op for
+    frozen weights).  The zero convs keep their own call (dense_bwd_weight, with the control scale)."""
+    if L.tW is None:
+        return
+    dense_bwd_weight(ctx, L, x, dy, 1, dy.shape[0], 1.0)
+
+
+def conv3_bwd_weight(ctx: Ctx, cw: Conv3W, x, dy, B, Hin, Win, mode=hip.CONV_S1):
+    """dW[o][tap][i] += sum_m dy[m, o] x[pixel(m, tap), i] for the nine taps, db += colsum(dy)  (trainable convs only).
+    x: the conv's NHWC input [B*Hin*Win, Ip]; dy on the output grid."""
+    if cw.tW is None:
+        return
+    stride = 2 if mode == hip.CONV_S2 else 1
+    assert mode in (hip.CONV_S1, hip.CONV_S2)
+    Ho, Wo = Hin // stride, Win // stride
+    g = cw.tW.grad.view(cw.O, 9 * cw.Ip)
+    for t in range(9):
+        gs = g[:, t * cw.Ip:(t + 1) * cw.Ip]
+        if ctx.dtype == torch.bfloat16:
+            ctx.queue_wgrad(dy, x, gs, 1.0, conv=(t, Hin, Win, Ho, Wo, stride, 1))
+        else:     # fp32 parity mode: materialise the shifted operand, explicit transposes
+            xs = ctx.new(B * Ho * Wo, cw.Ip)
+            hip.conv_tap_gather(x, xs, B, Hin, Win, Ho, Wo, t, stride, 1)
+            hip.weight_grad(ctx.transposed(dy), ctx.transposed(xs), gs)
+    hip.colsum(dy, cw.tb.grad.view(1, cw.O), 1, dy.shape[0], 1.0)
 
 
 def dense_bwd_weight(ctx: Ctx, L: LinearW, x, dy, B: int, HW: int, scale: float = 1.0):
@@ -230,19 +258,23 @@ class ResBlockE:
         h1, st1 = self.gn1.fwd(ctx, x, B, HW)
         e_out, t_e = linear_fwd(ctx, self.emb, semb)                      # [B, cout]
         h2 = conv3_fwd(ctx, self.conv1, h1, B, H, W, rowbias=e_out)       # + bias + emb (openaimodel.py:272)
-        del h1
+        keep = ctx.record and self.conv1.tW is not None                   # conv inputs: operands of the conv dW
+        if not keep:
+            del h1
         h3, st2 = self.gn2.fwd(ctx, h2, B, HW)
         if self.skip is not None:
             out, _ = linear_fwd(ctx, self.skip, x, out=out)
             conv3_fwd(ctx, self.conv2, h3, B, H, W, out=out, residual=out)  # skip(x) + h  (:274)
         else:
             out = conv3_fwd(ctx, self.conv2, h3, B, H, W, out=out, residual=x)
-        saved = (x, st1, h2, st2, semb, t_e) if ctx.record else None
+        saved = (x, st1, h2, st2, semb, t_e, (h1, h3) if keep else None) if ctx.record else None
         return out, saved
 
     def bwd(self, ctx: Ctx, dout, saved, B, H, W, dsemb=None, need_emb_grads=False, out=None):
-        x, st1, h2, st2, semb, t_e = saved
+        x, st1, h2, st2, semb, t_e, conv_in = saved
         HW = H * W
+        if conv_in is not None:
+            conv3_bwd_weight(ctx, self.conv2, conv_in[1], dout, B, H, W)
         dh3 = conv3_bwd_data(ctx, self.conv2, dout, B, H, W)
         dh2 = self.gn2.bwd(ctx, h2, dh3, st2, B, HW)
         del dh3
@@ -254,9 +286,13 @@ class ResBlockE:
             hip.pack2d(de32, de)
             _, u = linear_bwd_data(ctx, self.emb, de, out=dsemb, accum=dsemb)
             linear_bwd_lora(ctx, self.emb, semb, t_e, de, u)
+            base_bwd_weight(ctx, self.emb, semb, de)
+        if conv_in is not None:
+            conv3_bwd_weight(ctx, self.conv1, conv_in[0], dh2, B, H, W)
         dh1 = conv3_bwd_data(ctx, self.conv1, dh2, B, H, W)
         del dh2
         if self.skip is not None:
+            base_bwd_weight(ctx, self.skip, x, dout)
             dskip, _ = linear_bwd_data(ctx, self.skip, dout)
         else:
             dskip = dout
@@ -328,6 +364,7 @@ class AttnE:
         inner, H = self.inner, self.heads
         da, uo = linear_bwd_data(ctx, self.o, dout)
         linear_bwd_lora(ctx, self.o, a, to_, dout, uo)
+        base_bwd_weight(ctx, self.o, a, dout)
         delta = torch.empty_like(lse)
         want_kv = self.is_self or self.need_kv_grad
         if self.is_self and self.fused_qkv is not None:
@@ -359,15 +396,21 @@ class AttnE:
             linear_bwd_lora(ctx, self.k, xn, tk, dk, uk)
             _, uv = linear_bwd_data(ctx, self.v, dv, out=dxn, accum=dxn)
             linear_bwd_lora(ctx, self.v, xn, tv, dv, uv)
+            for L, d in ((self.q, dq), (self.k, dk), (self.v, dv)):
+                base_bwd_weight(ctx, L, xn, d)
             return dxn
         dxn, uq = linear_bwd_data(ctx, self.q, dq, accum=accum_xn)
         linear_bwd_lora(ctx, self.q, xn, tq, dq, uq)
+        base_bwd_weight(ctx, self.q, xn, dq)
         if want_kv and self.k.r:
             # context is an input (no data gradient needed), only the LoRA factors of to_k / to_v train
             uk = ctx.new(B * Nkv, self.k.r); hip.gemm(dk, self.k.Bt, uk)
             linear_bwd_lora(ctx, self.k, c, tk, dk, uk)
             uv = ctx.new(B * Nkv, self.v.r); hip.gemm(dv, self.v.Bt, uv)
             linear_bwd_lora(ctx, self.v, c, tv, dv, uv)
+        if want_kv:
+            base_bwd_weight(ctx, self.k, c, dk)
+            base_bwd_weight(ctx, self.v, c, dv)
         return dxn
 
 
@@ -387,7 +430,8 @@ class SpatialTransformerE:
         N = H * W
         xn, st0 = self.norm.fwd(ctx, x, B, N)
         h0, _ = linear_fwd(ctx, self.proj_in, xn)                    # 1x1 conv == per-token linear
-        del xn
+        if not (ctx.record and self.proj_in.tW is not None):         # operand of proj_in's dW when it trains
+            xn = None
         n1, s1 = self.ln1.fwd(ctx, h0)
         h1, sv1 = self.attn1.fwd(ctx, n1, None, B, N, N, residual=h0)
         n2, s2 = self.ln2.fwd(ctx, h1)
@@ -411,21 +455,24 @@ class SpatialTransformerE:
             hip.geglu_fwd(p, gg)
         h3, tf = linear_fwd(ctx, self.ff_out, gg, residual=h2)
         out, _ = linear_fwd(ctx, self.proj_out, h3, out=out, residual=x)
-        saved = (x, st0, h0, s1, sv1, h1, s2, sv2, h2, s3, n3, p, tp, gg, tf, h3) if ctx.record else None
+        saved = (x, st0, h0, s1, sv1, h1, s2, sv2, h2, s3, n3, p, tp, gg, tf, h3, xn) if ctx.record else None
         return out, saved
 
     def bwd(self, ctx: Ctx, dout, saved, B, H, W, Nkv, out=None):
-        x, st0, h0, s1, sv1, h1, s2, sv2, h2, s3, n3, p, tp, gg, tf, h3 = saved
+        x, st0, h0, s1, sv1, h1, s2, sv2, h2, s3, n3, p, tp, gg, tf, h3, xn = saved
         N = H * W
+        base_bwd_weight(ctx, self.proj_out, h3, dout)
         dh, _ = linear_bwd_data(ctx, self.proj_out, dout)           # d h3 ; (x_in residual: + dout at the end)
         # feed-forward
         dgg, uf = linear_bwd_data(ctx, self.ff_out, dh)
         linear_bwd_lora(ctx, self.ff_out, gg, tf, dh, uf)
+        base_bwd_weight(ctx, self.ff_out, gg, dh)
         dp = ctx.new(B * N, 8 * self.C)
         hip.geglu_bwd(p, dgg, dp)
         del dgg
         dn3, up = linear_bwd_data(ctx, self.ff_proj, dp)
         linear_bwd_lora(ctx, self.ff_proj, n3, tp, dp, up)
+        base_bwd_weight(ctx, self.ff_proj, n3, dp)
         del dp
         dh = self.ln3.bwd(ctx, h2, dn3, s3, accum=dh)                # d h2
         ctx.drop_transposes()
@@ -437,6 +484,8 @@ class SpatialTransformerE:
         dn1 = self.attn1.bwd(ctx, dh, sv1, B, N, N)
         dh = self.ln1.bwd(ctx, h0, dn1, s1, accum=dh)                # d h0
         ctx.drop_transposes()
+        if xn is not None:
+            base_bwd_weight(ctx, self.proj_in, xn, dh)
         dxn, _ = linear_bwd_data(ctx, self.proj_in, dh)
         dx = self.norm.bwd(ctx, x, dxn, st0, B, N, accum=dout, out=out)
         return dx

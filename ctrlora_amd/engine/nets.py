@@ -23,8 +23,8 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from .. import hip
-from .blocks import (AttnE, Ctx, ResBlockE, SpatialTransformerE, conv3_bwd_data, conv3_fwd, dense_bwd_weight,
-                     linear_bwd_data, linear_bwd_lora, linear_fwd)
+from .blocks import (AttnE, Ctx, ResBlockE, SpatialTransformerE, base_bwd_weight, conv3_bwd_data, conv3_bwd_weight,
+                     conv3_fwd, dense_bwd_weight, linear_bwd_data, linear_bwd_lora, linear_fwd)
 from .packing import Conv3W, LinearW, NormW, TrainableSet, rup
 
 
@@ -59,11 +59,16 @@ def is_trainable_name(n: str) -> bool:
 
 class _Builder:
     def __init__(self, sd: Dict[str, torch.Tensor], prefix: str, dtype, device, need_bwd: bool,
-                 trainables: Optional[TrainableSet]):
+                 trainables: Optional[TrainableSet], lora_set: Optional[TrainableSet] = None, train_all: bool = False):
         self.sd, self.prefix, self.dtype, self.device = sd, prefix, dtype, device
         self.need_bwd, self.tr = need_bwd, trainables
+        # train_all (Base-ControlNet pre-training, cldm_ctrlora_pretrain.py:174-182): every weight / bias / norm of
+        # the network is declared in `trainables`; the LoRA factors go to `lora_set` (one set per task bank)
+        self.tr_lora = lora_set if lora_set is not None else trainables
+        self.train_all = train_all
         self.linears: List[LinearW] = []
         self.norms: List[NormW] = []
+        self.convs: List[Conv3W] = []
         self.frozen: list = []        # (packed object, loader(sd)) for reload_frozen()
 
     def reload_frozen(self, sd: Dict[str, torch.Tensor]):
@@ -82,14 +87,19 @@ class _Builder:
         L = LinearW(self._g(name + ".weight"), self._g(name + ".bias") if self._has(name + ".bias") else None,
                     self.dtype, self.device, self.need_bwd)
         dn = name + ".lora_layer.down.weight"
+        if self.train_all:
+            tW = self.tr.declare(self.prefix + name + ".weight", (L.N, L.K))
+            tb = self.tr.declare(self.prefix + name + ".bias", (L.N,)) if self._has(name + ".bias") else None
+            L.attach_trainable_weight(tW, tb)
         if self._has(dn):
-            tA = self.tr.declare(self.prefix + dn, self._g(dn).shape)
+            tA = self.tr_lora.declare(self.prefix + dn, self._g(dn).shape)
             un = name + ".lora_layer.up.weight"
-            tB = self.tr.declare(self.prefix + un, self._g(un).shape)
+            tB = self.tr_lora.declare(self.prefix + un, self._g(un).shape)
             L.attach_lora(tA, tB, self.device)
         self.linears.append(L)
-        self.frozen.append(lambda: L.load(self._g(name + ".weight"),
-                                          self._g(name + ".bias") if self._has(name + ".bias") else None))
+        if not self.train_all:
+            self.frozen.append(lambda: L.load(self._g(name + ".weight"),
+                                              self._g(name + ".bias") if self._has(name + ".bias") else None))
         return L
 
     def fused(self, names: Sequence[str]) -> LinearW:
@@ -111,12 +121,18 @@ class _Builder:
 
     def conv3(self, name: str) -> Conv3W:
         cw = Conv3W(self._g(name + ".weight"), self._g(name + ".bias"), self.dtype, self.device, self.need_bwd)
-        self.frozen.append(lambda: cw.load(self._g(name + ".weight"), self._g(name + ".bias")))
+        if self.train_all:
+            tW = self.tr.declare(self.prefix + name + ".weight", (cw.O, 9 * cw.Ip), conv=(cw.O, cw.I, cw.Ip))
+            tb = self.tr.declare(self.prefix + name + ".bias", (cw.O,))
+            cw.attach_trainable(tW, tb)
+            self.convs.append(cw)
+        else:
+            self.frozen.append(lambda: cw.load(self._g(name + ".weight"), self._g(name + ".bias")))
         return cw
 
     def norm(self, name: str) -> NormW:
         w = NormW(self._g(name + ".weight"), self._g(name + ".bias"), self.device)
-        if self.tr is not None and is_trainable_name(name):
+        if self.tr is not None and (self.train_all or is_trainable_name(name)):
             w.attach(self.tr.declare(self.prefix + name + ".weight", self._g(name + ".weight").shape),
                      self.tr.declare(self.prefix + name + ".bias", self._g(name + ".bias").shape))
         self.norms.append(w)
@@ -203,14 +219,17 @@ class _Conv:
 
     def fwd(self, ctx, x, env, out=None):
         y = conv3_fwd(ctx, self.cw, x, env.B, env.H, env.W, mode=self.mode, out=out)
+        saved = (x, env.H, env.W) if (ctx.record and self.cw.tW is not None) else ()
         if self.mode == hip.CONV_S2:
             env.H //= 2; env.W //= 2
         elif self.mode == hip.CONV_UP2:
             env.H *= 2; env.W *= 2
-        return y, ()
+        return y, saved
 
     def bwd(self, ctx, dy, saved, env, out=None):
         # env.H/W are the spatial dims of dy (the conv's output grid)
+        if saved:
+            conv3_bwd_weight(ctx, self.cw, saved[0], dy, env.B, saved[1], saved[2], mode=self.mode)
         dx = conv3_bwd_data(ctx, self.cw, dy, env.B, env.H, env.W, fwd_mode=self.mode, out=out)
         if self.mode == hip.CONV_S2:
             env.H *= 2; env.W *= 2
@@ -259,10 +278,12 @@ class _TimeEmbed:
         demb = ctx.new(*emb.shape); hip.silu_bwd(emb, dsemb, demb)
         dh, u2 = linear_bwd_data(ctx, self.l2, demb)
         linear_bwd_lora(ctx, self.l2, h, t2, demb, u2)
+        base_bwd_weight(ctx, self.l2, h, demb)
         dte0 = ctx.new(*te0.shape); hip.silu_bwd(te0, dh, dte0)
         if self.l0.r:
             u0 = ctx.new(dte0.shape[0], self.l0.r); hip.gemm(dte0, self.l0.Bt, u0)
             linear_bwd_lora(ctx, self.l0, temb, t0, dte0, u0)
+        base_bwd_weight(ctx, self.l0, temb, dte0)
         ctx.drop_transposes()
 
 
@@ -303,14 +324,18 @@ def _encoder_layers(b: _Builder, cfg: NetCfg, lora: bool, after_block=None):
 
 class ControlNetE:
     def __init__(self, sd, cfg: NetCfg, dtype, device, prefix: str = "", need_bwd: bool = True,
-                 trainables: Optional[TrainableSet] = None, layout_only: bool = False):
+                 trainables: Optional[TrainableSet] = None, layout_only: bool = False, train_all: bool = False,
+                 lora_set: Optional[TrainableSet] = None):
         """layout_only: build the flat trainable layout (offsets, backward-ordered stage spans, the stage-completion
         hook) without packing anything for the kernels -- what the data-parallel exchange needs; usable without a
         GPU (the multi-process gloo tests).  Such an executor cannot run: fwd / bwd raise."""
         self.cfg, self.dtype, self.device = cfg, dtype, device
         self.layout_only = layout_only
         self.tr = trainables if trainables is not None else TrainableSet()
-        b = _Builder(sd, prefix, dtype, device, need_bwd, self.tr)
+        self.train_all = train_all
+        # pre-training: base weights in self.tr, the active task's LoRA bank in self.tr_lora (switch_bank swaps it)
+        self.tr_lora = (lora_set if lora_set is not None else TrainableSet()) if train_all else self.tr
+        b = _Builder(sd, prefix, dtype, device, need_bwd, self.tr, self.tr_lora, train_all)
         self.lora = (prefix + "time_embed.0.lora_layer.down.weight") in sd
         self.time = _TimeEmbed(b, cfg)
         marks = [len(self.tr.items)]          # stage boundaries in declaration (= forward) order
@@ -327,6 +352,8 @@ class ControlNetE:
         # flat buffer in backward-completion order: middle stage first, time_embed last
         self.tr.items.reverse()
         self.tr.materialize({k: v for k, v in sd.items()}, device)
+        if train_all and self.tr_lora.flat is None:
+            self.tr_lora.materialize({k: v for k, v in sd.items()}, device)
 
         def span(items):
             if not items:
@@ -353,34 +380,64 @@ class ControlNetE:
         self._b.reload_frozen({k: v for k, v in sd.items()})
         self.repack()
 
-    def repack(self):
-        """Refresh the packed (storage dtype, both orientations) copies of every trainable matrix from the
-        flat fp32 masters: ONE kernel over a device-resident descriptor table (built on first use)."""
-        tab = self.__dict__.get("_repack_tab")
+    def switch_bank(self, lora_set: TrainableSet):
+        """Pre-training: make `lora_set` (same names / shapes, its own flat master + gradient buffers) the active LoRA
+        bank (ControlNetPretrain.switch_lora, cldm_ctrlora_pretrain.py:68-76) and re-pack the LoRA copies from it."""
+        assert self.train_all
+        if lora_set is self.tr_lora:
+            return
+        for L in self._b.linears:
+            if L.tA is not None:
+                L.tA, L.tB = lora_set.by_name[L.tA.name], lora_set.by_name[L.tB.name]
+        self.tr_lora = lora_set
+        self.repack(only=lora_set)
+
+    def _repack_table(self, ts: TrainableSet):
+        key = id(ts)
+        tabs = self.__dict__.setdefault("_repack_tabs", {})
+        tab = tabs.get(key)
         if tab is None:
             rows, prefix = [], [0]
 
-            def add(t, R, C, dst, dstT):
-                rows.append([t.offset, (R << 32) | C, 0 if dst is None else dst.data_ptr(),
-                             0 if dstT is None else dstT.data_ptr()])
+            def add(row):
+                R, C = row[1] >> 32, row[1] & 0xffffffff
+                rows.append(row)
                 prefix.append(prefix[-1] + ((R + 31) // 32) * ((C + 31) // 32))
 
+            def mat(t, R, C, dst, dstT):
+                add([t.offset, (R << 32) | C, 0 if dst is None else dst.data_ptr(), 0 if dstT is None else dstT.data_ptr(),
+                     0, 0, 0, 0])
+
             for L in self._b.linears:
-                if L.tA is not None:
-                    add(L.tA, L.r, L.K, L.A, L.At)
-                    add(L.tB, L.N, L.r, L.B, L.Bt)
-                if L.tW is not None:
-                    add(L.tW, L.N, L.K, L.W, L.Wt)
-                    if L.tb is not None:
-                        L.bias = L.tb.master
-            for n in self._b.norms:
-                n.repack()      # views of the masters: nothing to copy
-            tab = (torch.tensor(rows, dtype=torch.int64, device=self.device),
+                if L.tA is not None and ts.by_name.get(L.tA.name) is L.tA:
+                    mat(L.tA, L.r, L.K, L.A, L.At)
+                    mat(L.tB, L.N, L.r, L.B, L.Bt)
+                if L.tW is not None and ts.by_name.get(L.tW.name) is L.tW:
+                    mat(L.tW, L.N, L.K, L.W, L.Wt)
+            for cw in self._b.convs:
+                if ts.by_name.get(cw.tW.name) is cw.tW:
+                    for row in cw.repack_rows():
+                        add(row)
+            tab = (torch.tensor(rows, dtype=torch.int64, device=self.device).reshape(-1, 8) if rows else None,
                    torch.tensor(prefix, dtype=torch.int32, device=self.device), len(rows), prefix[-1])
-            self.__dict__["_repack_tab"] = tab
-        desc, prefix, n, tiles = tab
-        if n:
-            hip.repack(self.dtype, self.tr.flat, desc, prefix, n, tiles)
+            tabs[key] = tab
+        return tab
+
+    def repack(self, only: Optional[TrainableSet] = None):
+        """Refresh the packed (storage dtype, both orientations) copies of every trainable matrix from the flat fp32
+        masters: ONE kernel per flat buffer over a device-resident descriptor table (built on first use)."""
+        for L in self._b.linears:
+            if L.tW is not None and L.tb is not None:
+                L.bias = L.tb.master
+        for cw in self._b.convs:
+            cw.bias = cw.tb.master
+        for n in self._b.norms:
+            n.repack()      # views of the masters: nothing to copy
+        sets = [only] if only is not None else ([self.tr] if self.tr_lora is self.tr else [self.tr, self.tr_lora])
+        for ts in sets:
+            desc, prefix, n, tiles = self._repack_table(ts)
+            if n:
+                hip.repack(self.dtype, ts.flat, desc, prefix, n, tiles)
         for L in self._b.linears:
             L.invalidate_geglu()     # permuted (GEGLU-fused) copies are rebuilt lazily from the fresh B
 
@@ -411,7 +468,7 @@ class ControlNetE:
         h, sv = _run_fwd(ctx, self.mid, h, env)
         saved.append(sv); dims.append((env.H, env.W))
         hs.append(h)
-        return ((tsv, semb, saved, hs, dims, c) if ctx.record else None), hs
+        return ((tsv, semb, saved, hs, dims, c, hint_tok) if ctx.record else None), hs
 
     def fwd_zero(self, hs, sinks, scales, weight=1.0):
         for k, h in enumerate(hs):
@@ -423,7 +480,7 @@ class ControlNetE:
         hip.gemm(h, z.W, out, bias=z.bias, alpha=alpha, residual=res, beta=1.0 if res is not None else 0.0)
 
     def bwd(self, ctx: Ctx, record, dsinks, scales, weight, B):
-        tsv, semb, saved, hs, dims, c = record
+        tsv, semb, saved, hs, dims, c, hint_tok = record
         env = _Env(B, 0, 0, semb, c, c.shape[0] // B)
         env.emb_grads = True
         env.dsemb = ctx.zeros(B, self.cfg.time_embed_dim)
@@ -437,9 +494,11 @@ class ControlNetE:
             env.H, env.W = dims[k]
             # stage 0: the input conv is frozen and the hint needs no gradient -> weight grads only
             dh = self._zero_bwd(ctx, k, hs[k], dsinks[k], scales[k] * weight, dh, B, env.H * env.W,
-                                need_dx=k > 0)
+                                need_dx=k > 0 or self.train_all)
             if k > 0:
                 dh = _run_bwd(ctx, self.blocks[k], dh, saved[k], env)
+            elif self.train_all:      # pre-training also trains the input conv: weight gradient only (the hint needs none)
+                conv3_bwd_weight(ctx, self.blocks[0][0].cw, hint_tok, dh, B, env.H, env.W)
             self._done(ctx, self.stage_spans[k])
         self.time.bwd(ctx, env.dsemb, tsv)
         self._done(ctx, self.time_span)

@@ -31,10 +31,27 @@ def rup(x: int, m: int) -> int:
 @dataclass
 class Trainable:
     name: str
-    shape: Tuple[int, ...]
+    shape: Tuple[int, ...]                  # shape of the MASTER storage (conv3 layout: [O, 9 * I_pad])
     offset: int = 0
     master: Optional[torch.Tensor] = None   # fp32 view into the flat master buffer
     grad: Optional[torch.Tensor] = None     # fp32 view into the flat grad buffer
+    conv: Optional[Tuple[int, int, int]] = None   # (O, I, I_pad): 3x3 conv weight kept as [O][ky][kx][I_pad]
+
+    def to_master(self, w: torch.Tensor) -> torch.Tensor:
+        """State-dict tensor -> master layout."""
+        if self.conv is None:
+            return w.reshape(self.shape)
+        O, I, Ip = self.conv
+        m = torch.zeros(O, 3, 3, Ip, dtype=torch.float32, device=w.device)
+        m[..., :I] = w.permute(0, 2, 3, 1)
+        return m.reshape(O, 9 * Ip)
+
+    def param_view(self, flat_view: torch.Tensor) -> torch.Tensor:
+        """View of master / grad storage in the nn.Parameter's (state-dict) shape."""
+        if self.conv is None:
+            return flat_view
+        O, I, Ip = self.conv
+        return flat_view.view(O, 3, 3, Ip)[..., :I].permute(0, 3, 1, 2)
 
 
 class TrainableSet:
@@ -47,8 +64,8 @@ class TrainableSet:
         self.flat_grad: Optional[torch.Tensor] = None
         self.numel = 0
 
-    def declare(self, name: str, shape) -> Trainable:
-        t = Trainable(name, tuple(shape))
+    def declare(self, name: str, shape, conv=None) -> Trainable:
+        t = Trainable(name, tuple(shape), conv=conv)
         self.items.append(t)
         self.by_name[name] = t
         return t
@@ -70,7 +87,7 @@ class TrainableSet:
                 n *= s
             t.master = self.flat[t.offset:t.offset + n].view(t.shape)
             t.grad = self.flat_grad[t.offset:t.offset + n].view(t.shape)
-            t.master.copy_(sd[t.name].to(device=device, dtype=torch.float32).reshape(t.shape))
+            t.master.copy_(t.to_master(sd[t.name].to(device=device, dtype=torch.float32)))
 
 
 class LinearW:
@@ -163,7 +180,23 @@ class Conv3W:
         self.Wp = torch.empty(self.Op, 9 * self.Ip, dtype=dtype, device=device)
         self.Wd = torch.empty(self.Ip, 9 * self.Op, dtype=dtype, device=device) if need_bwd else None
         self.bias = torch.zeros(self.Op, dtype=torch.float32, device=device)
+        self.tW: Optional[Trainable] = None     # trainable weight (Base-ControlNet pre-training), master [O][9][Ip]
+        self.tb: Optional[Trainable] = None
         self.load(W, bias)
+
+    def attach_trainable(self, tW: Trainable, tb: Trainable):
+        assert self.O == self.Op, "trainable 3x3 convs have O % 32 == 0"
+        self.tW, self.tb = tW, tb
+
+    def repack_rows(self):
+        """cl_repack descriptor rows (8 longs each) refreshing Wp / Wd from the master [O][9][Ip]."""
+        es = self.Wp.element_size()
+        rows = [[self.tW.offset, (self.O << 32) | (9 * self.Ip), self.Wp.data_ptr(), 0, 0, 0, 0, 0]]
+        if self.Wd is not None:
+            for t in range(9):     # Wd[i][8 - t][o] = W[o][t][i]
+                rows.append([self.tW.offset + t * self.Ip, (self.O << 32) | self.Ip, 0,
+                             self.Wd.data_ptr() + (8 - t) * self.Op * es, 9 * self.Ip, 0, 9 * self.Op, 0])
+        return rows
 
     def load(self, W: torch.Tensor, bias: torch.Tensor):
         """(Re)pack in place: [O][ky][kx][I] and the tap-flipped data-gradient form [I][2-ky][2-kx][O]."""

@@ -29,7 +29,8 @@ class HipError(RuntimeError):
 class WgradDesc(C.Structure):
     _fields_ = [("dy", C.c_void_p), ("lddy", C.c_long), ("x", C.c_void_p), ("ldx", C.c_long),
                 ("dW", C.c_void_p), ("lddw", C.c_long), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
-                ("scale", C.c_float)]
+                ("scale", C.c_float), ("tap", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("Hout", C.c_int),
+                ("Wout", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("reserved", C.c_int)]
 
 
 class GemmParams(C.Structure):
@@ -99,6 +100,7 @@ _SIGS = {
     "cl_p_losses_mse": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _P],
     "cl_zero": [_P, _L, _P],
     "cl_softmax_rows": [_I, _P, _L, _P, _L, _L, _I, _F, _P],
+    "cl_conv_tap_gather": [_I, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "cl_ddim_step": [_P, _P, _P, _P, _P, _I, _F, _P, _P, _L, _P],
     "cl_tick": [_P, _P],
     "cl_adamw_dev": [_P, _P, _P, _P, _L, _P, _P, _P],
@@ -253,17 +255,22 @@ def weight_grad(dyT, xT, dW, scale=1.0):
 
 
 def weight_grad_tn_group(problems):
-    """problems: list of (dy [M,N] bf16, x [M,K] bf16, dW [N,K] fp32, scale): ONE launch for all of them."""
+    """problems: list of (dy [M,N] bf16, x [M,K] bf16, dW [N,K] fp32, scale[, conv]): ONE launch for all of them.
+    conv = (tap, Hin, Win, Hout, Wout, stride, pad): one tap of a 3x3 conv's weight gradient (x = NHWC input)."""
     n = len(problems)
     if n == 0:
         return
     if _workspace is None:
         ensure_workspace(problems[0][0].device)
     arr = (WgradDesc * n)()
-    for d, (dy, x, dW, scale) in zip(arr, problems):
+    for d, prob in zip(arr, problems):
+        dy, x, dW, scale = prob[:4]
         d.dy = dy.data_ptr(); d.lddy = ld(dy); d.x = x.data_ptr(); d.ldx = ld(x)
         d.dW = dW.data_ptr(); d.lddw = ld(dW); d.M = dy.shape[0]; d.N = dy.shape[1]; d.K = x.shape[1]
         d.scale = scale
+        d.tap = -1
+        if len(prob) > 4 and prob[4] is not None:
+            d.tap, d.Hin, d.Win, d.Hout, d.Wout, d.stride, d.pad = prob[4]
     _chk(lib().cl_weight_grad_tn_group(BF16, n, C.cast(arr, C.c_void_p), zero_page(problems[0][0].device).data_ptr(),
                                        stream()), "cl_weight_grad_tn_group")
 
@@ -451,6 +458,12 @@ def p_losses_mse(eps, target, d_eps, t, lvlb, out3, scratch, gscale=1.0, w_simpl
                                ptr(per_sample), scratch.data_ptr(), B, eps.numel() // B, gscale, w_simple, w_elbo,
                                stream()), "cl_p_losses_mse")
     return out3
+
+
+def conv_tap_gather(x, out, B, Hin, Win, Hout, Wout, tap, stride, pad):
+    _chk(lib().cl_conv_tap_gather(dt(x), x.data_ptr(), ld(x), out.data_ptr(), ld(out), B, Hin, Win, Hout, Wout, x.shape[1], tap,
+                                  stride, pad, stream()), "cl_conv_tap_gather")
+    return out
 
 
 def softmax_rows(scores_f32, probs, scale=1.0):

@@ -25,6 +25,18 @@ def bind_trainables(module: torch.nn.Module, executor) -> List[torch.nn.Paramete
     out = []
     for t in executor.tr.items:
         p = params[t.name]
+        p.data = t.param_view(t.master)        # conv weights: a permuted view of the [O][9][I] master storage
+        p.grad = t.param_view(t.grad)
+        p.requires_grad_(True)
+        out.append(p)
+    return out
+
+
+def bind_bank(params_by_name, bank) -> List[torch.nn.Parameter]:
+    """Point one LoRA bank's nn.Parameters (name -> Parameter, names as in the bank's TrainableSet) at its flat buffers."""
+    out = []
+    for t in bank.items:
+        p = params_by_name[t.name]
         p.data = t.master
         p.grad = t.grad
         p.requires_grad_(True)
@@ -138,6 +150,85 @@ class FusedAdamW(torch.optim.Optimizer):
             dst.copy_(src)
         for dst, src in zip(self._v, sd["v"]):
             dst.copy_(src)
+
+
+class PretrainAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW over ALL ControlNet parameters as the reference's multi-task pre-training uses it
+    (cldm/cldm_ctrlora_pretrain.py:174-182, torch 1.13 / Lightning 1.5 semantics), on the engine's flat buffers:
+
+      * the shared (base) parameters are updated every step;
+      * a task's LoRA bank joins the update the first time it receives a gradient (before that its .grad is None and
+        torch skips it); from then on it is updated EVERY step -- with a zero gradient when another task ran, because
+        `optimizer.zero_grad()` of that torch version zero-fills instead of setting None: weight decay and the decaying
+        first moment keep moving it.  Each bank therefore has its own step counter (bias correction).
+
+    `mark_used(task)` is called by the model when a task's bank took part in a backward pass."""
+
+    def __init__(self, params, executor, banks, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
+        super().__init__(list(params), dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.executor, self.banks = executor, dict(banks)
+        self.executors = [executor]
+        self.grad_scale = grad_scale
+        dev = executor.tr.flat.device
+        self._hyper = torch.zeros(6, dtype=torch.float32, device=dev)
+        self._hyper_host = None
+        mk = lambda ts: dict(m=torch.zeros_like(ts.flat), v=torch.zeros_like(ts.flat),
+                             step=torch.zeros(1, dtype=torch.int32, device=dev))
+        self._base = mk(executor.tr)
+        self._bank_state = {k: mk(ts) for k, ts in self.banks.items()}
+        self.active = []                 # tasks whose bank has received a gradient at least once, in order of first use
+        self.pre_step_hook = None
+        self.sync_hyper()
+
+    def sync_hyper(self):
+        g = self.param_groups[0]
+        cur = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+               float(self.grad_scale))
+        if cur != self._hyper_host:
+            self._hyper.copy_(torch.tensor(cur, dtype=torch.float32))
+            self._hyper_host = cur
+
+    def mark_used(self, task):
+        if task not in self.active:
+            self.active.append(task)
+
+    @property
+    def _step(self) -> int:
+        return int(self._base["step"].item())
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        if self.pre_step_hook is not None:
+            self.pre_step_hook()
+        self.sync_hyper()
+        ex = self.executor
+        hip.tick(self._base["step"])
+        hip.adamw_dev(ex.tr.flat, ex.tr.flat_grad, self._base["m"], self._base["v"], self._hyper, self._base["step"])
+        for task in self.active:
+            ts, st = self.banks[task], self._bank_state[task]
+            hip.tick(st["step"])
+            hip.adamw_dev(ts.flat, ts.flat_grad, st["m"], st["v"], self._hyper, st["step"])
+        ex.repack()
+        return loss
+
+    def zero_grad(self, set_to_none: bool = False):
+        hip.zero_(self.executor.tr.flat_grad)
+        for task in self.active:
+            hip.zero_(self.banks[task].flat_grad)
+
+    def state_dict(self):
+        pack = lambda st: dict(m=st["m"].clone(), v=st["v"].clone(), step=int(st["step"].item()))
+        return dict(base=pack(self._base), banks={k: pack(v) for k, v in self._bank_state.items()}, active=list(self.active),
+                    param_groups=[{k: v for k, v in g.items() if k != "params"} for g in self.param_groups])
+
+    def load_state_dict(self, sd):
+        def unpack(st, src):
+            st["m"].copy_(src["m"]); st["v"].copy_(src["v"]); st["step"].fill_(int(src["step"]))
+        unpack(self._base, sd["base"])
+        for k, src in sd["banks"].items():
+            unpack(self._bank_state[k], src)
+        self.active = list(sd["active"])
 
 
 class GraphedTrainStep:

@@ -128,6 +128,11 @@ typedef struct cl_wgrad_desc {
   const void* x; long ldx;        /* [M, K] row-major bf16 */
   float* dW; long lddw;           /* [N, K] fp32, accumulated */
   int M, N, K; float scale;
+  /* tap >= 0: ONE TAP of a 3x3 convolution's weight gradient (Base-ControlNet pre-training trains the conv weights,
+   * cldm/cldm_ctrlora_pretrain.py:174-182).  x is then the NHWC input [B*Hin*Win, K]; row m = (b, oy, ox) of dy pairs
+   * with input pixel (oy*stride + tap/3 - pad, ox*stride + tap%3 - pad), zero outside the image; dW points at the tap's
+   * [N, K] slice of a [N][3][3][K] gradient (lddw = 9 K).  tap = -1: plain dy^T x (the other fields are ignored). */
+  int tap, Hin, Win, Hout, Wout, stride, pad, reserved;
 } cl_wgrad_desc;
 int cl_weight_grad_tn_group(int dtype, int n, const cl_wgrad_desc* descs, const void* zero_page, void* stream);
 
@@ -207,14 +212,21 @@ int cl_colsum(int dtype, const void* in, long ldi, float* out, long ldo, int B, 
 int cl_pool2x2(int dtype, const void* in, long ldi, void* out, long ldo, int B, int H, int W, int C, int accumulate, void* stream);
 int cl_pack2d(int dtype, const float* in, long ldi, void* out, long ldo, long R, int C, int Cpad, void* stream);
 /* One-launch refresh of the engine's storage-dtype copies of all trainable matrices from the flat fp32
- * master buffer after an optimizer step.  desc = device table of 4 longs per matrix {src offset in floats,
- * rows << 32 | cols, dst [rows][cols] or 0, dst^T [cols][rows] or 0}; tile_prefix[i] = number of 32x32
+ * master buffer after an optimizer step.  desc = device table of 8 longs per matrix {src offset in floats,
+ * rows << 32 | cols, dst [rows][cols] or 0, dst^T [cols][rows] or 0, source row stride (0 = cols), dst row stride
+ * (0 = cols), dst^T row stride (0 = rows), reserved}; the strides let one 3x3-conv weight [O][9][I] be re-packed tap
+ * by tap into [O][9][I_pad] and the tap-flipped data-gradient form [I][9][O_pad].  tile_prefix[i] = number of 32x32
  * tiles before matrix i (ndesc + 1 entries). */
 int cl_repack(int dtype, const float* flat, const long* desc, const int* tile_prefix, int ndesc,
               int total_tiles, void* stream);
 /* timestep_embedding (util.py:154-174); freqs = the fp32 table exp(-ln(1e4) * arange(half)/half) */
 int cl_timestep_embedding(int dtype, const long* t, const float* freqs, void* out, long ldo, int B, int half, void* stream);
 
+/* out[m, :] = x[pixel(m, tap), :] (zero outside the image), m = (b, oy, ox), pixel = (oy*stride + tap/3 - pad,
+ * ox*stride + tap%3 - pad): the shifted operand of one tap of a 3x3 conv weight gradient, materialised (fp32 parity
+ * mode; the bf16 weight-gradient kernel gathers in its own addressing, see cl_wgrad_desc.tap). */
+int cl_conv_tap_gather(int dtype, const void* x, long ldx, void* out, long ldo, int B, int Hin, int Win, int Hout,
+                       int Wout, int C, int tap, int stride, int pad, void* stream);
 /* Row softmax for the VAE's single-head attention (ldm/modules/diffusionmodules/model.py:183-186): fp32 scores
  * S [M, N] (row stride lds) -> `dtype` probabilities P [M, N] (row stride ldp), P = softmax(S * scale) per row. */
 int cl_softmax_rows(int dtype, const float* S, long lds, void* P, long ldp, long M, int N, float scale, void* stream);
