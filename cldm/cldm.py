@@ -81,7 +81,8 @@ class ControlNet(nn.Module, EngineHost):
         if ex is None:
             from ctrlora_amd.engine import ControlNetE
             from ctrlora_amd.train import bind_trainables
-            ex = ControlNetE(self._executor_state(), self.net_cfg(), self._engine_dtype(), self._device())
+            ex = ControlNetE(self._executor_state(), self.net_cfg(), self._engine_dtype(), self._device(),
+                             train_all=bool(getattr(self, "train_all_weights", False)))
             self.__dict__["_exec"] = ex
             self.__dict__["_bound"] = bind_trainables(self, ex)
         return ex
@@ -215,6 +216,35 @@ class ControlLDM(LatentDiffusion):
             control = control[:bs]
         control = control.to(self.device).permute(0, 3, 1, 2).to(memory_format=torch.contiguous_format).float()
         return x, dict(c_crossattn=[c], c_concat=[control])
+
+    @torch.no_grad()
+    def get_unconditional_conditioning(self, N):
+        return self.get_learned_conditioning([""] * N)
+
+    @torch.no_grad()
+    def log_images(self, batch, N=4, n_row=2, sample=False, ddim_steps=50, ddim_eta=0.0, unconditional_guidance_scale=9.0,
+                   **kwargs):
+        """What ImageLogger writes during training (cldm/cldm.py:359-411, cldm_ctrlora_pretrain.py:113-172): the VAE
+        reconstruction of the target, the condition image, the caption, and DDIM samples with classifier-free guidance,
+        all through the engine (sample_log -> DDIMSampler, decode_first_stage)."""
+        from ldm.util import log_txt_as_img
+        z, c = self.get_input(batch, self.first_stage_key, bs=N)
+        N = min(z.shape[0], N)
+        c_cat, c_txt = c["c_concat"][0][:N], c["c_crossattn"][0][:N]
+        extra = {k: v for k, v in c.items() if k not in ("c_concat", "c_crossattn")}      # 'task' when pre-training
+        log = {"reconstruction": self.decode_first_stage(z[:N]), "control": c_cat * 2.0 - 1.0,
+               "conditioning": log_txt_as_img((512, 512), list(batch[self.cond_stage_key])[:N], size=16)}
+        cond = dict(c_concat=[c_cat], c_crossattn=[c_txt], **extra)
+        if sample:
+            samples, _ = self.sample_log(cond=cond, batch_size=N, ddim=True, ddim_steps=ddim_steps, eta=ddim_eta)
+            log["samples"] = self.decode_first_stage(samples)
+        if unconditional_guidance_scale > 1.0:
+            uc = dict(c_concat=[c_cat], c_crossattn=[self.get_unconditional_conditioning(N)], **extra)
+            samples, _ = self.sample_log(cond=cond, batch_size=N, ddim=True, ddim_steps=ddim_steps, eta=ddim_eta,
+                                         unconditional_guidance_scale=unconditional_guidance_scale,
+                                         unconditional_conditioning=uc)
+            log[f"samples_cfg_scale_{unconditional_guidance_scale:.2f}"] = self.decode_first_stage(samples)
+        return log
 
     def apply_model(self, x_noisy, t, cond, *args, **kwargs):
         raise NotImplementedError("vanilla ControlLDM (image hint) is a comparison baseline; use the CtrLoRA LDMs")

@@ -39,9 +39,9 @@ class ControlNetFinetune(ControlNet):
         del self.input_hint_block                                     # :19
         if ft_with_lora:
             swap_linears(self, lambda m: LoRALinearLayer(m.in_features, m.out_features, rank=lora_rank))
-        else:
-            raise NotImplementedError("ft_with_lora=False (full fine-tuning of the ControlNet) needs weight "
-                                      "gradients for every conv/linear: not part of the LoRA hot path yet")
+        # ft_with_lora=False (configs/ctrlora_finetune_sd15_full.yaml): plain linears, EVERY ControlNet parameter trains
+        # (:100-103) -- the engine then forms all weight gradients, as in pre-training
+        self.train_all_weights = not ft_with_lora
 
     def forward(self, hint, timesteps, context, **kwargs):
         """13 zero-conv outputs for a 4-channel latent hint (:40-54)."""
@@ -98,7 +98,10 @@ class ControlFinetuneLDM(ControlLDM):
         names = []
         for n, _ in cm.named_parameters():
             assert "input_hint" not in n
-            if "lora_layer" in n:
+            if not cm.ft_with_lora:
+                assert "lora_layer" not in n
+                names.append(n)
+            elif "lora_layer" in n:
                 names.append(n)
             elif ("zero_convs" in n or "middle_block_out" in n) and cm.zero_trainable:
                 names.append(n)
@@ -109,7 +112,7 @@ class ControlFinetuneLDM(ControlLDM):
     def configure_optimizers(self):
         from ctrlora_amd.train import FusedAdamW
         cm = self.control_model
-        if not (cm.zero_trainable and cm.norm_trainable):
+        if cm.ft_with_lora and not (cm.zero_trainable and cm.norm_trainable):
             raise NotImplementedError("the engine trains LoRA + zero convs + norm layers together "
                                       "(every shipped config sets both flags)")
         names = self.trainable_names()

@@ -75,7 +75,9 @@ class Trainer:
         # what Lightning's DDP wrapper does at wrap time: every rank starts from rank 0's parameters and buffers
         # (the LoRA down-projections are drawn from an unseeded N(0, 1/r) in every process)
         self.broadcast_module_state(model)
-        if hasattr(model, "control_model") and hasattr(model.control_model, "executor") and self.device.type == "cuda":
+        if callable(getattr(model, "init_data_parallel", None)) and self.device.type == "cuda":
+            model.init_data_parallel()           # pre-training: bank-sparse exchange (base buffer + live LoRA banks)
+        elif hasattr(model, "control_model") and hasattr(model.control_model, "executor") and self.device.type == "cuda":
             from ctrlora_amd.parallel import GradAllReduce
             model.dp = GradAllReduce([model.control_model.executor()])
 

@@ -35,3 +35,20 @@ def instantiate_from_config(config):
             return None
         raise KeyError("Expected key `target` to instantiate.")
     return get_obj_from_str(config["target"])(**config.get("params", dict()))
+
+
+def log_txt_as_img(wh, xc, size=10):
+    """Render a list of captions as images, (B, 3, H, W) in [-1, 1] (ldm/util.py:12-33; PIL's built-in font instead of the
+    reference's bundled TTF)."""
+    import numpy as np
+    import torch
+    from PIL import Image, ImageDraw, ImageFont
+    out = []
+    for cap in xc:
+        txt = Image.new("RGB", wh, color="white")
+        draw = ImageDraw.Draw(txt)
+        nc = int(40 * (wh[0] / 256))
+        lines = "\n".join(str(cap)[i:i + nc] for i in range(0, len(str(cap)), nc))
+        draw.text((0, 0), lines, fill="black", font=ImageFont.load_default())
+        out.append(np.array(txt).transpose(2, 0, 1) / 127.5 - 1.0)
+    return torch.tensor(np.stack(out), dtype=torch.float32)

@@ -89,10 +89,12 @@ def main(argv=None):
     from cldm.model import create_model, load_state_dict
     args = get_parser().parse_args(argv)
     if args.multigen20m:
-        raise NotImplementedError("the MultiGen-20M reader (datasets/multigen20m.py) is not part of this repo; "
-                                  "use the CustomDataset layout")
-    from datasets.custom_dataset import CustomDataset
-    dataset = CustomDataset(args.dataroot)
+        from datasets.multigen20m import MultiGen20M
+        dataset = MultiGen20M(path_json=os.path.join(args.dataroot, "json_files", f"aesthetics_plus_all_group_{args.task}_all.json"),
+                              path_meta=args.dataroot, task=args.task, drop_rate=0.0, random_cropping=False)
+    else:
+        from datasets.custom_dataset import CustomDataset
+        dataset = CustomDataset(args.dataroot)
     if args.n_samples < len(dataset):
         dataset = Subset(dataset, range(args.n_samples))
     print("Dataset size:", len(dataset))

@@ -6,8 +6,7 @@
         --cn_ckpt ./ckpts/ctrlora-basecn/ctrlora_sd15_basecn700k.ckpt --bs 8 --precision 16 --max_steps 1000
 
 One process per GPU (the reference lets Lightning spawn them: strategy='ddp', devices=-1); `--precision 32` runs the
-fp32 parity mode of the engine, 16 / bf16 the bf16-storage mode.  `--multigen20m` needs the MultiGen-20M reader,
-which is not part of this repo.
+fp32 parity mode of the engine, 16 / bf16 the bf16-storage mode.
 """
 import argparse
 import datetime
@@ -75,10 +74,12 @@ def init_weights(model, sd_weights: dict, control_weights: dict, report_dir: str
 def build_dataloader(args, world_size: int, rank: int):
     from torch.utils.data import DataLoader, DistributedSampler, Subset
     if args.multigen20m:
-        raise NotImplementedError("the MultiGen-20M reader (datasets/multigen20m.py) is not part of this repo; "
-                                  "use the CustomDataset layout")
-    from datasets.custom_dataset import CustomDataset
-    dataset = CustomDataset(args.dataroot, drop_rate=args.drop_rate)
+        from datasets.multigen20m import MultiGen20M
+        dataset = MultiGen20M(path_json=os.path.join(args.dataroot, "json_files", f"aesthetics_plus_all_group_{args.task}_all.json"),
+                              path_meta=args.dataroot, task=args.task, drop_rate=args.drop_rate)
+    else:
+        from datasets.custom_dataset import CustomDataset
+        dataset = CustomDataset(args.dataroot, drop_rate=args.drop_rate)
     if args.subset > 0:
         dataset = Subset(dataset, range(args.subset))
     sampler = DistributedSampler(dataset, num_replicas=world_size, rank=rank, shuffle=True) if world_size > 1 else None

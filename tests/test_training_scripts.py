@@ -211,3 +211,49 @@ def test_sample_script_geometry_cli_and_output_layout(tmp_path):
     for sub in ("sample", "control", "img"):
         assert sorted(os.listdir(out / sub)) == ["0.png", "1.png"]
     assert open(out / "prompt.txt").read() == "a cat\ndog\n"
+
+
+def test_multigen20m_reader_and_collate(tmp_path):
+    """datasets.multigen20m.MultiGen20M (reference datasets/multigen20m.py:20-142): json-lines index, conditions/ +
+    images/ layout, SAME square crop on both images, 512 x 512 float outputs in the documented ranges, unreadable
+    samples skipped forward, prompt dropout; datasets.dataset_collate.collate_fn drops failed samples."""
+    import json
+    import random
+    from PIL import Image
+    from datasets.dataset_collate import collate_fn
+    from datasets.multigen20m import MultiGen20M
+    root = tmp_path
+    for d in ("json_files", "conditions", "images"):
+        (root / d).mkdir()
+    rng = np.random.RandomState(0)
+    lines = []
+    for i in range(4):
+        w, h = (640, 384) if i % 2 == 0 else (300, 420)
+        img = rng.randint(0, 255, (h, w, 3), dtype=np.uint8)
+        img[:, : w // 2, 0] = 255                                    # left half marked in the red channel
+        Image.fromarray(img).save(root / "images" / f"a{i}.png")
+        Image.fromarray(img).save(root / "conditions" / f"c{i}.png")
+        lines.append(json.dumps({"source": f"./a{i}.png", "prompt": f"p{i}", "control_canny": f"c{i}.png"}))
+    lines.insert(1, json.dumps({"source": "./missing.png", "prompt": "x", "control_canny": "missing.png"}))
+    (root / "json_files" / "aesthetics_plus_all_group_canny_all.json").write_text("\n".join(lines) + "\n")
+    ds = MultiGen20M(str(root / "json_files" / "aesthetics_plus_all_group_canny_all.json"), str(root), "canny",
+                     drop_rate=0.0, random_cropping=False)
+    assert len(ds) == 5
+    it = ds[0]
+    assert it["task"] == "control_canny" and it["txt"] == "p0"
+    assert it["jpg"].shape == (512, 512, 3) and it["hint"].shape == (512, 512, 3)
+    assert it["jpg"].dtype == np.float32 and -1.0 <= it["jpg"].min() and it["jpg"].max() <= 1.0
+    assert 0.0 <= it["hint"].min() and it["hint"].max() <= 1.0
+    # centred crop of a 640 x 384 image keeps columns 128..512: the red marker covers the left (320-128)/384 = 1/2
+    red = it["hint"][:, :, 0] > 0.99
+    assert abs(red[:, :250].mean() - 1.0) < 0.02 and red[:, 270:].mean() < 0.1
+    # same crop on the target: same marker position
+    assert abs(((it["jpg"][:, :250, 0] + 1) / 2 > 0.99).mean() - 1.0) < 0.02
+    # the unreadable sample falls through to the next one
+    assert ds[1]["txt"] == "p1"
+    random.seed(0)
+    dropped = MultiGen20M(str(root / "json_files" / "aesthetics_plus_all_group_canny_all.json"), str(root), "canny", drop_rate=1.0)
+    assert dropped[0]["txt"] == ""
+    batch = collate_fn([ds[0], dict(jpg=None, hint=None, txt="", task="control_canny"), ds[2]])
+    assert batch["jpg"].shape == (2, 512, 512, 3) and batch["txt"] == ["p0", "p1"] and batch["task"] == ["control_canny"] * 2
+    assert collate_fn([dict(jpg=None, hint=None)]) is None
