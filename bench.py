@@ -171,6 +171,30 @@ def family_census(model, opt, data, reps=10):
     return out
 
 
+def vae_bench(device, dtype, B=8, iters=3):
+    """First-stage cost of one REAL training step: the reference VAE-encodes the B target images
+    (ddpm.py:773) and the B condition images (cldm_ctrlora_finetune.py:76-77) of every step -- 2B encodes of 512x512
+    images on the engine's AutoencoderKL (random-init SD ddconfig)."""
+    from ldm.models.autoencoder import AutoencoderKL
+    dd = dict(attn_resolutions=[], ch=128, ch_mult=[1, 2, 4, 4], double_z=True, dropout=0.0, in_channels=3, num_res_blocks=2,
+              out_ch=3, resolution=256, z_channels=4)
+    torch.manual_seed(0)
+    vae = AutoencoderKL(ddconfig=dd, lossconfig=dict(target="torch.nn.Identity"), embed_dim=4).to(device).eval()
+    vae.engine_dtype = dtype
+    x = torch.rand(2 * B, 3, 512, 512, device=device) * 2 - 1
+    with torch.no_grad():
+        vae.encode(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            post = vae.encode(x)
+        torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    assert torch.isfinite(post.mean).all() and "_enc" in vae.__dict__
+    gf = 1117.0 * 2 * B              # GFLOP: 1 117 per 512x512 encode (SURVEY.md 8 f1)
+    return dict(images=2 * B, ms=round(ms, 2), tflops=round(gf / ms, 1), mfma_frac=round(gf / ms / PEAK_BF16_TFLOPS, 4))
+
+
 def ddim_bench(device, dtype, B=16, S=50, tiny=False, loops=5):
     from cldm.ddim_hacked import DDIMSampler
     model = build_model("inference/ctrlora_sd15_rank128_1lora.yaml", 0, tiny=tiny).to(device).eval()
@@ -271,6 +295,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ddim", action="store_true")
+    ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--ddim-only", action="store_true", help="profiling aid: run only the DDIM leg")
     ap.add_argument("--force-split-graphs", action="store_true",
@@ -398,6 +423,16 @@ def main():
             if "attention" in fam:
                 roof["attention_family"] = fam["attention"]
         out["roofline"] = roof
+    if rank == 0 and not args.tiny and args.dtype == "bf16" and not args.no_vae:
+        try:   # end to end = the core step + the first-stage encodes the reference performs inside every step
+            vb = vae_bench(device, dtype, B)
+            step_ms = dt / args.steps * 1e3
+            out["end_to_end"] = dict(vae_encode=vb, ms_per_step=round(step_ms + vb["ms"], 2),
+                                     images_per_s_per_gpu=round(B / (step_ms + vb["ms"]) * 1e3, 2),
+                                     note="core step (value) + VAE encode of the B target and B condition images on the engine, "
+                                          "timed separately and added; CLIP text encoding (~1 % of the FLOPs) not included")
+        except Exception as e:
+            print(f"[bench] VAE leg failed: {type(e).__name__}: {e}", file=sys.stderr)
     # DDIM leg: every rank samples its own batch (replicas, no collective); aggregate = sum over ranks
     ddim = None
     if not args.no_ddim:
