@@ -31,13 +31,34 @@ namespace cl {
 namespace {
 
 template <int DH> struct Geo {
-  static constexpr int CPR = DH / 8;             // 16-byte chunks per row
+  static constexpr int CPR = DH / 8;             // 16-byte chunks of DATA per row
   static constexpr int KSTEPS = (CPR + 3) / 4;   // 32-deep MFMA steps over the head dim
   static constexpr int DN = (DH + 15) / 16;      // 16-wide output fragments over the head dim
-  static constexpr int ROWB = DH * 2;            // bytes per tile row
+  // LDS row pitch.  d_head 40 (the 64x64 level, where the attention time is): 80-byte rows put the ds_read_b128 row
+  // fragments AND the ds_read_b64_tr_b16 column fragments 2-way on the banks (PMC: SQ_LDS_BANK_CONFLICT = 50 % of
+  // SQ_LDS_IDX_ACTIVE, and LDS bandwidth is what bounds these kernels: ~20 fragment reads per 28 MFMAs per wave); a
+  // 96-byte pitch (one pad chunk per row) makes both patterns conflict-free: chunk (6 r + g) mod 16 is a permutation over
+  // a b128 lane group, and rows r = 0..7 start 24 banks apart -> eight disjoint 8-bank windows for the transpose reads.
+  // The pad chunk is written once per kernel (zeros; ones for V in the ping-pong forward: it IS the softmax denominator
+  // row) and masked out of the tile DMA.  160- and 320-byte pitches (d_head 80, 160) are left as they are.
+  static constexpr int ROWB = DH == 40 ? 96 : DH * 2;   // bytes per LDS tile row (pitch)
+  static constexpr int CPRP = ROWB / 16;         // chunks per LDS row incl. padding
   static constexpr int TILE = 64 * ROWB;         // a 64-row operand tile
-  static constexpr int TI = 64 * CPR / 64;       // DMA instructions per tile (= CPR)
+  static constexpr int TI = CPRP;                // DMA instructions (64 lanes x 16 B) per tile
 };
+
+// write the pad chunk (bytes [16 CPR, ROWB) of every row) of `ntile` consecutive tiles; odd tiles get `odd` instead of
+// `even` (K / V or Q / dO pairs).  No-op when the pitch has no padding.  Callers synchronise before the first read.
+template <int DH> __device__ __forceinline__ void init_pads(char* tiles, int ntile, uint32_t even, uint32_t odd, int tid,
+                                                            int nthreads) {
+  using G = Geo<DH>;
+  if constexpr (G::CPRP > G::CPR) {
+    for (int i = tid; i < ntile * 64; i += nthreads) {
+      const uint32_t v = ((i >> 6) & 1) ? odd : even;
+      *reinterpret_cast<uint4*>(tiles + (long)i * G::ROWB + G::CPR * 16) = make_uint4(v, v, v, v);
+    }
+  }
+}
 
 // Plain fp32 VALU instructions issue at 4 cycles per wave64 on gfx950 (measured: the softmax / dS arithmetic, not
 // the matrix pipe, bounds these kernels); v_pk_{fma,mul,add}_f32 do two lanes' worth per issue slot.
@@ -60,14 +81,17 @@ template <int ROWB, int STEP> __device__ __forceinline__ u32x4_t tr_frag(uint32_
 // clamp, 64-bit multiply), so the per-lane (row, chunk) decomposition is done ONCE and a full tile costs one
 // 64-bit add per instruction; only the ragged last tile clamps rows.
 template <int DH> struct TileDma {
-  static constexpr int TI = Geo<DH>::TI, NJ = (TI + 3) / 4, CPR = Geo<DH>::CPR;
+  static constexpr int TI = Geo<DH>::TI, NJ = (TI + 3) / 4, CPR = Geo<DH>::CPR, CPRP = Geo<DH>::CPRP;
   int r[NJ], cc16[NJ];
+  bool real[NJ];                                   // false: this lane's LDS slot is a pad chunk (left alone)
   __device__ __forceinline__ void init(int wave, int lane) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int c = (wave + 4 * j) * 64 + lane;
-      r[j] = c / CPR;
-      cc16[j] = (c - r[j] * CPR) * 16;
+      r[j] = c / CPRP;
+      const int col = c - r[j] * CPRP;
+      real[j] = col < CPR;
+      cc16[j] = (real[j] ? col : 0) * 16;
     }
   }
   __device__ __forceinline__ void offsets(long ld_bytes, int (&off)[NJ]) const {
@@ -80,11 +104,11 @@ template <int DH> struct TileDma {
     if (row0 + 64 <= nrows) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
-        if (wave + 4 * j < TI) glds16(tb + off[j], dst + (wave + 4 * j) * 1024);
+        if (wave + 4 * j < TI && real[j]) glds16(tb + off[j], dst + (wave + 4 * j) * 1024);
     } else {
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
-        if (wave + 4 * j < TI) {
+        if (wave + 4 * j < TI && real[j]) {
           const int rr = min(row0 + r[j], nrows - 1);
           glds16(base + (long)rr * ld_bytes + cc16[j], dst + (wave + 4 * j) * 1024);
         }
@@ -140,6 +164,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_tr_kernel(AttnFwdArgs p, cons
   TileDma<DH> dma; dma.init(wave, lane);
   int koff[TileDma<DH>::NJ], voff[TileDma<DH>::NJ];
   dma.offsets(p.ldk * 2, koff); dma.offsets(ldv * 2, voff);
+  init_pads<DH>(smem, 4, 0u, 0u, tid, 256);           // 2 stages x {K, V}
   dma.issue(kbase, p.ldk * 2, koff, 0, p.Nkv, smem, wave);
   dma.issue(vbase, ldv * 2, voff, 0, p.Nkv, smem + TILE, wave);
   for (int t = 0; t < ntiles; ++t) {
@@ -291,6 +316,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnFwdArgs p, cons
   constexpr int CPR = G::CPR, KSTEPS = G::KSTEPS, DN = G::DN, ROWB = G::ROWB, TILE = G::TILE;
   constexpr int STAGE = 2 * TILE, QW = 2;
   constexpr bool ONES = (DH % 16) != 0;        // spare V^T rows exist: row DH carries the softmax denominator
+  constexpr bool PADONES = ONES && G::CPRP > G::CPR;   // ... and the padded V tile already holds ones there
   constexpr int LROW = DH % 16;
   constexpr float RESCALE_THR = 6.0f;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 stages + 16 rows + 64 bytes of (zeroed) slack
@@ -313,6 +339,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnFwdArgs p, cons
 
   // fragment over-reads (chunks >= CPR of the last rows) land in the slack: keep it finite (x 0 must stay 0)
   for (int i = tid; i < (16 * ROWB + 64) / 4; i += 512) reinterpret_cast<uint32_t*>(smem + 3 * STAGE)[i] = 0u;
+  init_pads<DH>(smem, 6, 0u, 0x3F803F80u, tid, 512);   // K pad = 0 (meets Q zeros); V pad = 1.0: rows 40..47 of V^T
 
   u32x4_t qf[QW][KSTEPS];
 #pragma unroll
@@ -340,11 +367,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnFwdArgs p, cons
   u32x4_t pb[2][QW];
 
   // ---- DMA: wave w issues instructions w, w + 8, ... of a tile (1 KiB each, lane-linear image)
-  constexpr int NJ = (CPR + 7) / 8;
+  constexpr int CPRP = G::CPRP, NJ = (CPRP + 7) / 8;
   int koff[NJ], voff[NJ];
+  bool real[NJ];                                   // pad chunks of the LDS rows are not DMA targets
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const int c = (wave + 8 * j) * 64 + lane, r = c / CPR, cc = (c - r * CPR) * 16;
+    const int c = (wave + 8 * j) * 64 + lane, r = c / CPRP, col = c - r * CPRP;
+    real[j] = col < CPR;
+    const int cc = (real[j] ? col : 0) * 16;
     koff[j] = r * (int)(p.ldk * 2) + cc;
     voff[j] = r * (int)(ldv * 2) + cc;
   }
@@ -354,7 +384,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnFwdArgs p, cons
     char* dst = smem + stage * STAGE;
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
-      if (wave + 8 * j < CPR) {
+      if (wave + 8 * j < CPRP && real[j]) {
         glds16(kb + koff[j], dst + (wave + 8 * j) * 1024);
         glds16(vb + voff[j], dst + TILE + (wave + 8 * j) * 1024);
       }
@@ -402,7 +432,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnFwdArgs p, cons
       if constexpr (J < NV) {
         pin(va[J % LA][0]); pin(va[J % LA][1]);
         u32x4_t a0 = va[J % LA][0], a1 = va[J % LA][1];
-        if constexpr (ONES && J == DN - 1) {
+        if constexpr (ONES && !PADONES && J == DN - 1) {
           const uint32_t one2 = 0x3F803F80u;
           a0.x = ones_lane ? one2 : a0.x; a0.y = ones_lane ? one2 : a0.y; a0.z = ones_lane ? one2 : a0.z; a0.w = ones_lane ? one2 : a0.w;
           a1.x = ones_lane ? one2 : a1.x; a1.y = ones_lane ? one2 : a1.y; a1.z = ones_lane ? one2 : a1.z; a1.w = ones_lane ? one2 : a1.w;
@@ -504,7 +534,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnFwdArgs p, cons
       for (int i = 0; i < DN; ++i) {
         va[0] = tr_frag<ROWB, 0>(vt + troff + i * 32); va[1] = tr_frag<ROWB, 1>(vt + troff + i * 32);
         lds_wait();
-        if (ONES && i == DN - 1 && ones_lane) { va[0] = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u}; va[1] = va[0]; }
+        if (ONES && !PADONES && i == DN - 1 && ones_lane) { va[0] = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u}; va[1] = va[0]; }
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -533,7 +563,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnFwdArgs p, cons
       for (int i = 0; i < DN; ++i) {
         va[0] = tr_frag<ROWB, 0>(vt + troff + i * 32); va[1] = tr_frag<ROWB, 1>(vt + troff + i * 32);
         lds_wait();
-        if (ONES && i == DN - 1 && ones_lane) { va[0] = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u}; va[1] = va[0]; }
+        if (ONES && !PADONES && i == DN - 1 && ones_lane) { va[0] = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u}; va[1] = va[0]; }
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -626,6 +656,8 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_tr_kerne
   const uint32_t rrow = lq * ROWB + g * 16;
   const uint32_t troff = (4 * g + ((lane >> 2) & 3)) * ROWB + (lane & 3) * 8;
   const int ntiles = (p.N + 63) / 64;
+  init_pads<DH>(smem, 2, 0u, 0u, tid, 256);
+  init_pads<DH>(smem + STAGE, 2, 0u, 0u, tid, 256);
   issue(0, 0);
   for (int t = 0; t < ntiles; ++t) {
     const int buf = t & 1;
@@ -764,6 +796,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_tr_kernel(AttnBwdArgs p) {
   TileDma<DH> dma; dma.init(wave, lane);
   int koff[TileDma<DH>::NJ], voff[TileDma<DH>::NJ];
   dma.offsets(p.ldk * 2, koff); dma.offsets(p.ldv * 2, voff);
+  init_pads<DH>(smem, 4, 0u, 0u, tid, 256);
   dma.issue(kbase, p.ldk * 2, koff, 0, p.Nkv, smem, wave);
   dma.issue(vbase, p.ldv * 2, voff, 0, p.Nkv, smem + TILE, wave);
   for (int t = 0; t < ntiles; ++t) {
@@ -878,6 +911,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(AttnBwdArgs p, 
   const float sl2 = p.scale * 1.4426950408889634f;
 
   for (int i = tid; i < SLACK / 4; i += 512) reinterpret_cast<uint32_t*>(smem + 3 * STAGE)[i] = 0u;
+  init_pads<DH>(smem, 6, 0u, 0u, tid, 512);
 
   u32x4_t kb[KF][KSTEPS], vb[KF][KSTEPS];
 #pragma unroll
@@ -905,11 +939,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(AttnBwdArgs p, 
   f32x4_t sc[KF][2], dp[KF][2];
   u32x4_t pb[KF], sb[KF];
 
-  constexpr int NJ = (CPR + 7) / 8;
+  constexpr int CPRP = G::CPRP, NJ = (CPRP + 7) / 8;
   int qoff[NJ], dooff[NJ];
+  bool real[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const int c = (wave + 8 * j) * 64 + lane, r = c / CPR, cc = (c - r * CPR) * 16;
+    const int c = (wave + 8 * j) * 64 + lane, r = c / CPRP, col = c - r * CPRP;
+    real[j] = col < CPR;
+    const int cc = (real[j] ? col : 0) * 16;
     qoff[j] = r * (int)(p.ldq * 2) + cc;
     dooff[j] = r * (int)(p.lddo * 2) + cc;
   }
@@ -919,11 +956,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(AttnBwdArgs p, 
     char* dst = smem + stage * STAGE;
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
-      if (wave + 8 * j < CPR) {
+      if (wave + 8 * j < CPRP && real[j]) {
         glds16(qb + qoff[j], dst + (wave + 8 * j) * 1024);
         glds16(ob + dooff[j], dst + TILE + (wave + 8 * j) * 1024);
       }
-    if (wave == (CPR & 7) && lane < 32) {   // lse (lanes 0-15) and delta (16-31), 64 floats each
+    if (wave == (CPRP & 7) && lane < 32) {   // lse (lanes 0-15) and delta (16-31), 64 floats each
       const float* src = lane < 16 ? lse + t * 64 + lane * 4 : dlt + t * 64 + (lane - 16) * 4;
       glds16(src, smem + LOFF + stage * 512);
     }
@@ -1094,6 +1131,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(AttnBwdArgs p, i
   const float sl2 = p.scale * 1.4426950408889634f;
 
   for (int i = tid; i < SLACK / 4; i += 512) reinterpret_cast<uint32_t*>(smem + 3 * STAGE)[i] = 0u;
+  init_pads<DH>(smem, 6, 0u, 0u, tid, 512);
 
   u32x4_t qb[QF][KSTEPS], ob[QF][KSTEPS];
   float lse_q[QF], ndl_q[QF];
@@ -1122,11 +1160,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(AttnBwdArgs p, i
   f32x4_t sc[QF][2], dp[QF][2];
   u32x4_t sb[QF];
 
-  constexpr int NJ = (CPR + 7) / 8;
+  constexpr int CPRP = G::CPRP, NJ = (CPRP + 7) / 8;
   int koff[NJ], voff[NJ];
+  bool real[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const int c = (wave + 8 * j) * 64 + lane, r = c / CPR, cc = (c - r * CPR) * 16;
+    const int c = (wave + 8 * j) * 64 + lane, r = c / CPRP, col = c - r * CPRP;
+    real[j] = col < CPR;
+    const int cc = (real[j] ? col : 0) * 16;
     koff[j] = r * (int)(p.ldk * 2) + cc;
     voff[j] = r * (int)(p.ldv * 2) + cc;
   }
@@ -1136,7 +1177,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(AttnBwdArgs p, i
     char* dst = smem + stage * STAGE;
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
-      if (wave + 8 * j < CPR) {
+      if (wave + 8 * j < CPRP && real[j]) {
         glds16(kb + koff[j], dst + (wave + 8 * j) * 1024);
         glds16(vb + voff[j], dst + TILE + (wave + 8 * j) * 1024);
       }
