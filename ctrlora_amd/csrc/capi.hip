@@ -35,6 +35,12 @@ int cl_set_stream_workspace(void* stream, void* ptr, long bytes) {
   return gemm_set_stream_workspace(S(stream), ptr, bytes);
 }
 int cl_gemm_force_config(int cfg) { g_gemm_force_cfg = cfg; return CL_OK; }
+int cl_gemm_force_splitk(int splitk) { g_gemm_force_splitk = splitk < 0 ? 0 : splitk; return CL_OK; }
+int cl_gemm_tune_set(int dtype, int mode, int M, int N, int K1, int K2, int geglu, int cfg, int splitk) {
+  return gemm_tune_set(dtype, mode, M, N, K1, K2, geglu, cfg, splitk);
+}
+int cl_gemm_tune_clear(void) { gemm_tune_clear(); return CL_OK; }
+int cl_gemm_tune_size(void) { return gemm_tune_size(); }
 int cl_attention_force_variant(int v) { g_attn_variant = v; return CL_OK; }
 
 int cl_gemm(const cl_gemm_params* p, int dtype, void* stream) {

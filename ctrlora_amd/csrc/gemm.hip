@@ -38,6 +38,9 @@
 // range of output tiles: neighbouring tiles share A rows / conv halos.
 #include <type_traits>
 #include "gemm.h"
+#include <algorithm>
+#include <map>
+#include <utility>
 #include "mma.h"
 
 namespace cl {
@@ -909,6 +912,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, const 
   }
 }
 
+// split-K factor imposed on the launch being prepared (0 = the launcher's own rule): set by launch_t from a tuned
+// table entry or from the tuner's hook for the duration of one launch (launches are prepared on one host thread at a time)
+static thread_local int t_force_sk = 0;
+
 template <typename T, int BM, int BN, int WGM, int WGN, int KSUB, int R>
 static int launch_cfg(const GemmParams& p0, hipStream_t stream) {
   constexpr int NW = WGM * WGN;
@@ -938,7 +945,11 @@ static int launch_cfg(const GemmParams& p0, hipStream_t stream) {
     int sk = 1;
     void* wsp; long wsb;
     ws_for(stream, &wsp, &wsb);
-    if (p.splitk <= 1 && tiles < 160 && ksub >= 32 && wsp) {
+    if (t_force_sk > 0) {   // tuned entry (or the tuner's hook): take the factor as given, within K and the workspace
+      sk = wsp ? t_force_sk : 1;
+      if (sk > ksub) sk = ksub > 0 ? ksub : 1;
+      while (sk > 1 && (long)sk * p.M * p.N * 4 > wsb) --sk;
+    } else if (p.splitk <= 1 && tiles < 160 && ksub >= 32 && wsp) {
       sk = (int)((256 + tiles - 1) / tiles);
       const int minsub = p.M <= 64 ? g_tiny_m_minsub : 16;
       if (sk > ksub / minsub) sk = ksub / minsub;
@@ -976,7 +987,11 @@ static int pick_splitk(GemmParams& p, long tiles, int steps, int want, int min_s
     if (p.splitk > steps) p.splitk = steps > 0 ? steps : 1;
   } else {
     int sk = 1;
-    if (tiles < want && steps >= 2 * min_steps && wsp) {
+    if (t_force_sk > 0) {
+      sk = wsp ? t_force_sk : 1;
+      if (sk > steps) sk = steps > 0 ? steps : 1;
+      while (sk > 1 && (long)sk * p.M * p.N * 4 > wsb) --sk;
+    } else if (tiles < want && steps >= 2 * min_steps && wsp) {
       sk = (int)((want + tiles - 1) / tiles);
       if (sk > steps / min_steps) sk = steps / min_steps;
       if (sk > 32) sk = 32;
@@ -1034,9 +1049,45 @@ int g_gemm_force_cfg = -1;   // probe / tuning hook: >= 0 forces a tile configur
 int g_fl128_split_want = 128;   // 128-row full-line tiles: split K while the grid is below this many workgroups
 int g_tiny_m_minsub = 8;        // fallback kernel, M <= 64: minimum 64-byte substeps per K split
 
+int g_gemm_force_splitk = 0;    // tuning hook: > 0 imposes the split-K factor (workspace path), 0 = launcher's rule
+
+// Measured launch table (tools/gemm_autotune.py on an MI355X -> ctrlora_amd/gemm_tuned_gfx950.json, loaded by the host
+// at start-up): product signature -> (tile configuration, split-K factor).  A signature that is not in the table takes
+// the rules below; an entry can only name configurations the switch below accepts, each of which re-checks its own
+// preconditions, so a stale or foreign table costs speed, never correctness.
+struct TuneKey {
+  int v[7];   // dtype, mode, M, N, K1, K2, geglu
+  bool operator<(const TuneKey& o) const { return std::lexicographical_compare(v, v + 7, o.v, o.v + 7); }
+};
+static std::map<TuneKey, std::pair<int, int>> g_tune;
+
+int gemm_tune_set(int dtype, int mode, int M, int N, int K1, int K2, int geglu, int cfg, int splitk) {
+  if (cfg < 0 || cfg > 21 || splitk < 0 || splitk > 64) return CL_EINVAL;
+  g_tune[TuneKey{{dtype, mode, M, N, K1, K2, geglu ? 1 : 0}}] = std::make_pair(cfg, splitk);
+  return CL_OK;
+}
+void gemm_tune_clear() { g_tune.clear(); }
+int gemm_tune_size() { return (int)g_tune.size(); }
+
+template <typename T>
+static int launch_t_cfg(const GemmParams& p, hipStream_t stream, int cfg);
+
 template <typename T>
 static int launch_t(const GemmParams& p, hipStream_t stream) {
-  int cfg = g_gemm_force_cfg;
+  int cfg = g_gemm_force_cfg, sk = g_gemm_force_splitk;
+  if (cfg < 0 && !p.atomic && !g_tune.empty()) {
+    const auto it = g_tune.find(TuneKey{{(int)sizeof(T) == 2 ? CL_BF16 : CL_F32, p.mode, p.M, p.N, p.K1, p.K2,
+                                         p.act == ACT_GEGLU ? 1 : 0}});
+    if (it != g_tune.end()) { cfg = it->second.first; sk = it->second.second; }
+  }
+  t_force_sk = p.atomic ? 0 : sk;
+  const int rc = launch_t_cfg<T>(p, stream, cfg);
+  t_force_sk = 0;
+  return rc;
+}
+
+template <typename T>
+static int launch_t_cfg(const GemmParams& p, hipStream_t stream, int cfg) {
   if (p.act == ACT_GEGLU && cfg != 2 && cfg != 12 && cfg != 8 && cfg != 10 && cfg != 14 && cfg != 16 && cfg != 18 && cfg != 20) cfg = -2;   // needs a 2 x 80-column wave pair
   if (cfg < 0) {
     // v2 (64-byte substeps, 4 waves) choices

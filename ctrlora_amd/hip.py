@@ -60,6 +60,10 @@ _SIGS = {
     "cl_set_workspace": [_P, _L],
     "cl_set_stream_workspace": [_P, _P, _L],
     "cl_gemm_force_config": [_I],
+    "cl_gemm_force_splitk": [_I],
+    "cl_gemm_tune_set": [_I] * 9,
+    "cl_gemm_tune_clear": [],
+    "cl_gemm_tune_size": [],
     "cl_attention_force_variant": [_I],
     "cl_gemm": [C.POINTER(GemmParams), _I, _P],
     "cl_lora_down": [_I, _P, _L, _P, _I, _P, _L, _I, _I, _P],
@@ -124,7 +128,31 @@ def lib():
             fn.argtypes = args
             fn.restype = C.c_long if name == "cl_groupnorm_ws_floats" else C.c_int
         _lib = L
+        if os.environ.get("CTRLORA_GEMM_TUNED", "1") != "0":
+            load_gemm_table(os.environ.get("CTRLORA_GEMM_TABLE", GEMM_TABLE_PATH))
     return _lib
+
+
+GEMM_TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tuned_gfx950.json")
+
+
+def load_gemm_table(path: str, clear: bool = True) -> int:
+    """Register the measured launch table (tools/gemm_autotune.py) with the library: rows
+    [dtype, mode, M, N, K1, K2, geglu, cfg, splitk].  A missing file leaves the built-in rules in charge
+    (CTRLORA_GEMM_TUNED=0 does the same on purpose, for A/B runs).  Returns the number of entries."""
+    import json
+    L = lib() if _lib is not None else None
+    if L is None:
+        return 0
+    if clear:
+        L.cl_gemm_tune_clear()
+    if not path or not os.path.exists(path):
+        return 0
+    with open(path) as f:
+        tab = json.load(f)
+    for row in tab.get("entries", []):
+        _chk(L.cl_gemm_tune_set(*[int(v) for v in row[:9]]), "cl_gemm_tune_set")
+    return int(L.cl_gemm_tune_size())
 
 
 def _chk(rc: int, what: str):

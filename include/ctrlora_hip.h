@@ -50,6 +50,16 @@ int cl_set_workspace(void* device_ptr, long bytes);
 int cl_set_stream_workspace(void* stream, void* device_ptr, long bytes);
 /* tuning hook: force a tile configuration of csrc/gemm.hip (-1 = built-in heuristic) */
 int cl_gemm_force_config(int cfg);
+/* tuning hook: impose the split-K factor of the workspace path on every following contraction (0 = built-in rule) */
+int cl_gemm_force_splitk(int splitk);
+/* Measured launch table: the contraction with this signature (dtype CL_BF16/CL_F32, cl_gemm_mode, M, N, K1, K2,
+ * geglu = GEGLU epilogue) is launched with tile configuration `cfg` and split-K factor `splitk` (0 = built-in rule
+ * for the factor) instead of the built-in choice.  The host loads ctrlora_amd/gemm_tuned_gfx950.json (written by
+ * tools/gemm_autotune.py from timings on an MI355X) through this entry at start-up; signatures not in the table
+ * keep the built-in rules, and every configuration re-checks its own preconditions at launch. */
+int cl_gemm_tune_set(int dtype, int mode, int M, int N, int K1, int K2, int geglu, int cfg, int splitk);
+int cl_gemm_tune_clear(void);
+int cl_gemm_tune_size(void);
 /* A/B probe hook for the attention schedules: 0 = default (ping-pong forward where it applies, tile-synchronous
  * backward), 1 = tile-synchronous kernels only, 3 = ping-pong forward and backward */
 int cl_attention_force_variant(int variant);

@@ -68,3 +68,23 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(hip, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(hip.HipError):
         hip.lib()
+
+
+def test_measured_gemm_table_is_well_formed_and_registers():
+    """ctrlora_amd/gemm_tuned_gfx950.json (tools/gemm_autotune.py): every row is a product signature + a tile
+    configuration the launcher knows + a split factor; hip.lib() registers all of them through cl_gemm_tune_set."""
+    import json
+    from ctrlora_amd import hip
+    with open(hip.GEMM_TABLE_PATH) as f:
+        tab = json.load(f)
+    rows = tab["entries"]
+    assert rows and len({tuple(r[:7]) for r in rows}) == len(rows)
+    for dtype, mode, M, N, K1, K2, geglu, cfg, sk in rows:
+        assert dtype in (hip.BF16, hip.F32) and 0 <= mode <= 5 and M > 0 and N > 0 and K1 > 0 and K2 >= 0
+        assert geglu in (0, 1) and 0 <= cfg <= 21 and 0 <= sk <= 64
+        assert not (geglu and cfg not in (2, 10, 16, 20))
+    L = hip.lib()
+    assert hip.load_gemm_table(hip.GEMM_TABLE_PATH) == len(rows) == L.cl_gemm_tune_size()
+    assert hip.load_gemm_table("") == 0 == L.cl_gemm_tune_size()          # A/B switch: built-in rules only
+    assert L.cl_gemm_tune_set(0, 0, 64, 64, 64, 0, 0, 99, 0) != 0           # unknown configuration refused
+    hip.load_gemm_table(hip.GEMM_TABLE_PATH)

@@ -1,0 +1,248 @@
+"""Measured launch table for the contraction kernels (csrc/gemm.hip).
+
+Records every `hip.gemm` call of the workloads the benchmarks run -- one LoRA fine-tuning step (rank 128, B = 8,
+latent 64x64), one CFG DDIM denoise step (B = 16 -> 32 rows through both networks), one VAE encode / decode at 512x512,
+optionally one pre-training step -- and, for each distinct product signature (dtype, mode, M, N, K1, K2, GEGLU), times
+the tile configurations and split-K factors the launcher accepts for it, in isolation, between HIP events on the
+launching stream.  A candidate replaces the built-in choice only if it is >= `--gain` faster in two separate
+measurements and its result agrees with the built-in launch's.  Output: ctrlora_amd/gemm_tuned_gfx950.json, which
+`ctrlora_amd.hip.lib()` registers through `cl_gemm_tune_set` at start-up.
+
+Run on the GPU box with the table disabled:   CTRLORA_GEMM_TUNED=0 python tools/gemm_autotune.py [--quick]
+"""
+import argparse
+import collections
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["CTRLORA_GEMM_TUNED"] = "0"
+import bench  # noqa: E402
+from ctrlora_amd import hip  # noqa: E402
+
+FL = (10, 11, 16, 17, 20, 21)          # full-line (LDS-DMA, 128-byte K lines) configurations
+W160 = (2, 5, 10, 16, 20)              # 160-column tiles
+W128 = (1, 7, 11, 17, 21)              # 128-column tiles
+GEGLU_OK = (2, 10, 16, 20)             # a value / gate wave pair per 160-column tile
+
+
+class Recorder:
+    """Wraps hip.gemm: first call of every signature is kept (tensors stay alive through the closure)."""
+
+    def __init__(self):
+        self.calls = collections.OrderedDict()
+        self.tag = ""
+
+    def __enter__(self):
+        self.orig = hip.gemm
+
+        def rec(a1, w1, out, **kw):
+            M = out.shape[0] if kw.get("M") is None else kw["M"]
+            N = out.shape[1] if kw.get("N") is None else kw["N"]
+            k1 = a1.shape[1] if kw.get("k1") is None else kw["k1"]
+            mode, a2 = kw.get("mode", hip.LINEAR), kw.get("a2")
+            k2 = 0 if a2 is None else a2.shape[1]
+            geglu = 1 if kw.get("act", 0) == hip.ACT_GEGLU else 0
+            if not kw.get("atomic", False):
+                key = (hip.dt(a1), int(mode), int(M), int(N), int(k1), int(k2), geglu)
+                e = self.calls.get(key)
+                if e is None:
+                    # private copies of the output (and of an in-place residual) so that re-launching is idempotent
+                    o2 = torch.empty_like(out)
+                    kw2 = dict(kw)
+                    if kw.get("residual") is not None:
+                        kw2["residual"] = kw["residual"].clone()
+                    e = self.calls[key] = dict(n={}, run=lambda a1=a1, w1=w1, o2=o2, kw2=kw2: self.orig(a1, w1, o2, **kw2),
+                                               out=o2)
+                e["n"][self.tag] = e["n"].get(self.tag, 0) + 1
+            return self.orig(a1, w1, out, **kw)
+
+        hip.gemm = rec
+        return self
+
+    def __exit__(self, *a):
+        hip.gemm = self.orig
+
+
+def time_us(run, reps):
+    for _ in range(2):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def candidates(key):
+    _, mode, M, N, K1, K2, geglu = key
+    taps = 1 if mode == hip.LINEAR else 9
+    fl_ok = K1 % 64 == 0 and K2 % 64 == 0 and not (mode != hip.LINEAR and K2) and M > 128 and N >= 96
+    cfgs = [0]
+    for c in (1, 2, 5, 7) + FL:
+        if c in FL and not fl_ok:
+            continue
+        if c in W160 and N % 160:
+            continue
+        if c in W128 and N % 128 and N % 160 == 0:
+            continue                      # keep the tile width the heuristic would use for this N
+        cfgs.append(c)
+    if geglu:
+        cfgs = [c for c in cfgs if c in GEGLU_OK]
+    steps = (taps * K1 + K2) // 64
+    sks = [0, 1] + [s for s in (2, 3, 4, 6, 8, 12, 16) if s * 2 <= steps]
+    return cfgs, sks
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true", help="training step only")
+    ap.add_argument("--gain", type=float, default=0.04)
+    ap.add_argument("--reps", type=int, default=12)
+    ap.add_argument("--out", default=os.path.join(ROOT, "ctrlora_amd", "gemm_tuned_gfx950.json"))
+    ap.add_argument("--log", default=os.path.join(ROOT, "gpurun_out", "gemm_autotune.log"))
+    args = ap.parse_args()
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dtype = torch.bfloat16
+    L = hip.lib()
+    L.cl_gemm_tune_clear()
+    rec = Recorder()
+
+    # ---- workloads -------------------------------------------------------------------------------------------
+    model = bench.build_model("ctrlora_finetune_sd15_rank128.yaml", 0).to(device).train()
+    model.set_engine_dtype(dtype)
+    model.learning_rate = 1e-5
+    opt = model.configure_optimizers()
+    data = bench.synth(8, 64, model.control_model.context_dim, device, 1234, 1)
+    cond = {"c_crossattn": [data["ctx"][0]], "c_concat": [data["hint"][0]]}
+    opt.zero_grad()
+    model.engine_train_step(data["z"][0], cond, data["t"][0], data["noise"][0])
+    torch.cuda.synchronize()
+    with rec:
+        rec.tag = "train"
+        opt.zero_grad()
+        model.engine_train_step(data["z"][0], cond, data["t"][0], data["noise"][0])
+        torch.cuda.synchronize()
+    del model, opt
+    if not args.quick:
+        from cldm.ddim_hacked import DDIMSampler
+        minf = bench.build_model("inference/ctrlora_sd15_rank128_1lora.yaml", 0).to(device).eval()
+        minf.set_engine_dtype(dtype)
+        cd, B, H = minf.control_model.context_dim, 16, 64
+        g = torch.Generator().manual_seed(7)
+        hint = torch.randn(B, 4, H, H, generator=g).to(device)
+        c = {"c_concat": [hint], "c_crossattn": [torch.randn(B, 77, cd, generator=g).to(device)]}
+        u = {"c_concat": [hint], "c_crossattn": [torch.randn(B, 77, cd, generator=g).to(device)]}
+        sampler = DDIMSampler(minf)
+        sampler.use_graph = False
+        with rec:
+            rec.tag = "ddim"
+            sampler.sample(2, B, (4, H, H), c, verbose=False, eta=0.0, unconditional_guidance_scale=7.5,
+                           unconditional_conditioning=u)
+            torch.cuda.synchronize()
+        for k in rec.calls.values():               # two denoise steps were recorded
+            if "ddim" in k["n"]:
+                k["n"]["ddim"] = max(1, k["n"]["ddim"] // 2)
+        del minf, sampler
+        from ldm.models.autoencoder import AutoencoderKL
+        dd = dict(attn_resolutions=[], ch=128, ch_mult=[1, 2, 4, 4], double_z=True, dropout=0.0, in_channels=3,
+                  num_res_blocks=2, out_ch=3, resolution=256, z_channels=4)
+        torch.manual_seed(0)
+        vae = AutoencoderKL(ddconfig=dd, lossconfig=dict(target="torch.nn.Identity"), embed_dim=4).to(device).eval()
+        vae.engine_dtype = dtype
+        with torch.no_grad(), rec:
+            rec.tag = "vae_enc"
+            post = vae.encode(torch.rand(16, 3, 512, 512, device=device) * 2 - 1)
+            rec.tag = "vae_dec"
+            vae.decode(post.mean[:4].contiguous())
+            torch.cuda.synchronize()
+        del vae
+    torch.cuda.empty_cache()
+
+    # ---- search ----------------------------------------------------------------------------------------------
+    os.makedirs(os.path.dirname(args.log), exist_ok=True)
+    log = open(args.log, "w")
+    entries, rows = [], []
+    t_start = time.time()
+    for key, e in rec.calls.items():
+        run, out = e["run"], e["out"]
+        L.cl_gemm_force_config(-1); L.cl_gemm_force_splitk(0)
+        run(); torch.cuda.synchronize()
+        ref = out.float().clone()
+        scale = float(ref.abs().max()) + 1e-20
+        base = time_us(run, args.reps)
+        cfgs, sks = candidates(key)
+        best = (base, -1, 0)
+        per_cfg = []
+        for c in cfgs:                                   # tile configuration at the launcher's own split rule
+            L.cl_gemm_force_config(c); L.cl_gemm_force_splitk(0)
+            try:
+                us = time_us(run, args.reps)
+            except hip.HipError:
+                continue
+            per_cfg.append((us, c))
+        per_cfg.sort()
+        trials = [(us, c, 0) for us, c in per_cfg]
+        for us, c in per_cfg[:3]:                        # split factors for the three fastest tiles
+            for sk in sks[1:]:
+                L.cl_gemm_force_config(c); L.cl_gemm_force_splitk(sk)
+                try:
+                    trials.append((time_us(run, args.reps), c, sk))
+                except hip.HipError:
+                    pass
+        trials.sort()
+        chosen = None
+        for us, c, sk in trials[:4]:
+            if us > base * (1.0 - args.gain):
+                break
+            L.cl_gemm_force_config(c); L.cl_gemm_force_splitk(sk)
+            out.zero_()
+            run(); torch.cuda.synchronize()
+            err = float((out.float() - ref).abs().max()) / scale
+            us2 = time_us(run, 3 * args.reps)
+            L.cl_gemm_force_config(-1); L.cl_gemm_force_splitk(0)
+            base2 = time_us(run, 3 * args.reps)
+            ok = err < 2e-2 and us2 < base2 * (1.0 - args.gain)
+            log.write(f"  confirm {key} cfg {c} sk {sk}: {us2:.1f} vs {base2:.1f} us, err {err:.2e} -> {'take' if ok else 'drop'}\n")
+            if ok:
+                chosen = (us2, base2, c, sk)
+                break
+        L.cl_gemm_force_config(-1); L.cl_gemm_force_splitk(0)
+        calls = sum(e["n"].values())
+        if chosen:
+            us2, base2, c, sk = chosen
+            entries.append(list(key) + [c, sk])
+            rows.append((calls * (base2 - us2), key, e["n"], base2, us2, c, sk))
+        else:
+            rows.append((0.0, key, e["n"], base, base, -1, 0))
+        log.write(f"{key} calls {e['n']} base {base:.1f} us; best trials {[(round(u, 1), c, s) for u, c, s in trials[:4]]}\n")
+        log.flush()
+    rows.sort(key=lambda r: -r[0])
+    saved = collections.Counter()
+    for gain_us, key, n, b, u, c, sk in rows:
+        for tag, cnt in n.items():
+            saved[tag] += cnt * (b - u)
+    summary = {tag: round(v * 1e-3, 3) for tag, v in saved.items()}
+    print(f"signatures {len(rec.calls)}, tuned {len(entries)}, predicted saving (ms, isolated timings): {summary}, "
+          f"search {time.time() - t_start:.0f} s")
+    for gain_us, key, n, b, u, c, sk in rows[:40]:
+        print(f"  {gain_us:8.0f} us  {key}  {n}  {b:7.1f} -> {u:7.1f} us  cfg {c} sk {sk}")
+    head = {"device": torch.cuda.get_device_name(0), "columns": "dtype mode M N K1 K2 geglu cfg splitk",
+            "gain_threshold": args.gain, "predicted_saving_ms": summary}
+    with open(args.out, "w") as f:          # one entry per line: reviewable diffs
+        f.write("{" + ", ".join(f"{json.dumps(k)}: {json.dumps(v)}" for k, v in head.items()) + ',\n"entries": [\n')
+        f.write(",\n".join(json.dumps(r) for r in sorted(entries)))
+        f.write("\n]}\n")
+    log.close()
+
+
+if __name__ == "__main__":
+    main()
