@@ -1062,7 +1062,7 @@ struct TuneKey {
 static std::map<TuneKey, std::pair<int, int>> g_tune;
 
 int gemm_tune_set(int dtype, int mode, int M, int N, int K1, int K2, int geglu, int cfg, int splitk) {
-  if (cfg < 0 || cfg > 21 || splitk < 0 || splitk > 64) return CL_EINVAL;
+  if (cfg < 0 || cfg > 24 || splitk < 0 || splitk > 64) return CL_EINVAL;
   g_tune[TuneKey{{dtype, mode, M, N, K1, K2, geglu ? 1 : 0}}] = std::make_pair(cfg, splitk);
   return CL_OK;
 }
@@ -1088,7 +1088,7 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
 
 template <typename T>
 static int launch_t_cfg(const GemmParams& p, hipStream_t stream, int cfg) {
-  if (p.act == ACT_GEGLU && cfg != 2 && cfg != 12 && cfg != 8 && cfg != 10 && cfg != 14 && cfg != 16 && cfg != 18 && cfg != 20) cfg = -2;   // needs a 2 x 80-column wave pair
+  if (p.act == ACT_GEGLU && cfg != 2 && cfg != 12 && cfg != 8 && cfg != 10 && cfg != 14 && cfg != 16 && cfg != 18 && cfg != 20 && cfg != 23) cfg = -2;   // needs a 2 x 80-column wave pair
   if (cfg < 0) {
     // v2 (64-byte substeps, 4 waves) choices
     if (p.M <= 64 || p.N <= 64) cfg = 0;
@@ -1163,6 +1163,10 @@ static int launch_t_cfg(const GemmParams& p, hipStream_t stream, int cfg) {
         return launch_cfg<T, 128, 128, 2, 2, 2, 4>(p, stream);
       return cfg == 10 ? launch_fl<T, 128, 160, 2, 2, 2>(p, stream) : launch_fl<T, 128, 128, 2, 2, 2>(p, stream);
     }
+    // small-M tiles of the generic kernel (8x8 / 16x16 levels, text-context projections): offered to the tuner
+    case 22: return launch_cfg<T, 64, 128, 2, 2, 1, 4>(p, stream);
+    case 23: return launch_cfg<T, 64, 160, 2, 2, 1, 4>(p, stream);
+    case 24: return launch_cfg<T, 128, 64, 2, 2, 1, 4>(p, stream);
     default: return CL_EINVAL;
   }
 }

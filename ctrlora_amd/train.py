@@ -258,10 +258,13 @@ class GraphedTrainStep:
     """
 
     def __init__(self, model, opt, z, cond_txt, hint, t, noise, warmup: int = 2, split_graphs=None,
-                 bucket_bytes: int = 32 << 20, reduce_fn=None):
+                 bucket_bytes: int = 32 << 20, reduce_fn=None, capture_error_mode=None):
         import torch.distributed as dist
         self.model, self.opt = model, opt
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        # With a process group alive, RCCL's watchdog thread polls events while this thread captures: only calls made
+        # by the capturing thread may invalidate the capture ("thread_local"); single-process keeps the strict default.
+        self.capture_error_mode = capture_error_mode or ("thread_local" if self.world > 1 else "global")
         self.dist = dist
         if split_graphs is None:
             mode = "segmented" if self.world > 1 else "one"
@@ -323,22 +326,22 @@ class GraphedTrainStep:
         self.g_b = None
         if mode == "one":
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=self.capture_error_mode):
                 self.loss = fwd_bwd()
                 opt.step()
             self.segments.append((g, None, 0, 0))
         elif mode == "two":
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=self.capture_error_mode):
                 self.loss = fwd_bwd()
             self.segments.append((g, "all", 0, 0))
             self.g_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_b, pool=g.pool()):
+            with torch.cuda.graph(self.g_b, pool=g.pool(), capture_error_mode=self.capture_error_mode):
                 opt.step()
         else:
             self._capture_segments(fwd_bwd, max(1, bucket_bytes // 4))
             self.g_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_b, pool=self._pool):
+            with torch.cuda.graph(self.g_b, pool=self._pool, capture_error_mode=self.capture_error_mode):
                 opt.step()
         self.warmup_steps = warmup
 
@@ -356,7 +359,7 @@ class GraphedTrainStep:
 
         def begin():
             state["g"] = torch.cuda.CUDAGraph()
-            state["g"].capture_begin(pool=self._pool)
+            state["g"].capture_begin(pool=self._pool, capture_error_mode=self.capture_error_mode)
 
         def end(tag, lo, hi):
             state["g"].capture_end()

@@ -537,7 +537,8 @@ def test_graphed_ddim_with_image_hint_resamples_the_posterior_on_the_device():
         assert not torch.equal(a, b)
 
 
-def test_segmented_graph_step_hands_out_every_gradient_slice_once_and_matches_eager():
+@pytest.mark.parametrize("capture_error_mode", [None, "thread_local"])
+def test_segmented_graph_step_hands_out_every_gradient_slice_once_and_matches_eager(capture_error_mode):
     """Data-parallel form of GraphedTrainStep on ONE GPU: the backward is captured as segment graphs that end where a
     gradient bucket is complete; between replays the bucket's slice of the flat gradient buffer is handed to the
     reduction (here a recording stand-in for the RCCL all-reduce).  Every element must be handed out exactly once,
@@ -575,7 +576,8 @@ def test_segmented_graph_step_hands_out_every_gradient_slice_once_and_matches_ea
         return None
 
     g = GraphedTrainStep(mb, ob, cu(inp["z"]), cu(inp["ctx"]), cu(inp["hint_z"]), cu(inp["t"]), cu(inp["noise"]),
-                         warmup=1, split_graphs="segmented", bucket_bytes=256 << 10, reduce_fn=fake_reduce)
+                         warmup=1, split_graphs="segmented", bucket_bytes=256 << 10, reduce_fn=fake_reduce,
+                         capture_error_mode=capture_error_mode)   # "thread_local": what a live process group selects
     assert g.mode == "segmented" and len(g.segments) >= 3
     handed.clear()
     l2 = float(g(cu(inp["z"]), cu(inp["ctx"]), cu(inp["hint_z"]), cu(inp["t"]), cu(inp["noise"])))

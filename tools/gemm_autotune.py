@@ -25,10 +25,10 @@ os.environ["CTRLORA_GEMM_TUNED"] = "0"
 import bench  # noqa: E402
 from ctrlora_amd import hip  # noqa: E402
 
-FL = (10, 11, 16, 17, 20, 21)          # full-line (LDS-DMA, 128-byte K lines) configurations
-W160 = (2, 5, 10, 16, 20)              # 160-column tiles
-W128 = (1, 7, 11, 17, 21)              # 128-column tiles
-GEGLU_OK = (2, 10, 16, 20)             # a value / gate wave pair per 160-column tile
+FL = (10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21)   # full-line (LDS-DMA, 128-byte K lines) configurations
+W160 = (2, 5, 10, 12, 14, 16, 18, 20, 23)               # 160-column tiles
+W128 = (1, 7, 11, 13, 15, 17, 19, 21, 22)               # 128-column tiles
+GEGLU_OK = (2, 10, 12, 14, 16, 18, 20, 23)              # a value / gate wave pair per 160-column tile
 
 
 class Recorder:
@@ -70,23 +70,32 @@ class Recorder:
 
 
 def time_us(run, reps):
-    for _ in range(2):
-        run()
+    """Average duration of one launch inside a replayed hipGraph of `reps` back-to-back launches: what the launch
+    costs in the captured training / DDIM step (an eager loop from Python measures the ~9 us host launch path
+    instead for every product below that)."""
+    run()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            run()
+    g.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        run()
+    g.replay(); g.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / reps
+    us = e0.elapsed_time(e1) * 1e3 / (2 * reps)
+    del g
+    return us
 
 
 def candidates(key):
     _, mode, M, N, K1, K2, geglu = key
     taps = 1 if mode == hip.LINEAR else 9
     fl_ok = K1 % 64 == 0 and K2 % 64 == 0 and not (mode != hip.LINEAR and K2) and M > 128 and N >= 96
-    cfgs = [0]
-    for c in (1, 2, 5, 7) + FL:
+    cfgs = [0, 24] if N % 64 == 0 else [0]
+    for c in (1, 2, 5, 7, 22, 23) + FL:
         if c in FL and not fl_ok:
             continue
         if c in W160 and N % 160:
@@ -104,8 +113,8 @@ def candidates(key):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true", help="training step only")
-    ap.add_argument("--gain", type=float, default=0.04)
-    ap.add_argument("--reps", type=int, default=12)
+    ap.add_argument("--gain", type=float, default=0.03)
+    ap.add_argument("--reps", type=int, default=16)
     ap.add_argument("--out", default=os.path.join(ROOT, "ctrlora_amd", "gemm_tuned_gfx950.json"))
     ap.add_argument("--log", default=os.path.join(ROOT, "gpurun_out", "gemm_autotune.log"))
     args = ap.parse_args()
@@ -207,9 +216,9 @@ def main():
             out.zero_()
             run(); torch.cuda.synchronize()
             err = float((out.float() - ref).abs().max()) / scale
-            us2 = time_us(run, 3 * args.reps)
+            us2 = time_us(run, 2 * args.reps)
             L.cl_gemm_force_config(-1); L.cl_gemm_force_splitk(0)
-            base2 = time_us(run, 3 * args.reps)
+            base2 = time_us(run, 2 * args.reps)
             ok = err < 2e-2 and us2 < base2 * (1.0 - args.gain)
             log.write(f"  confirm {key} cfg {c} sk {sk}: {us2:.1f} vs {base2:.1f} us, err {err:.2e} -> {'take' if ok else 'drop'}\n")
             if ok:
@@ -235,6 +244,20 @@ def main():
           f"search {time.time() - t_start:.0f} s")
     for gain_us, key, n, b, u, c, sk in rows[:40]:
         print(f"  {gain_us:8.0f} us  {key}  {n}  {b:7.1f} -> {u:7.1f} us  cfg {c} sk {sk}")
+    # in-graph census of the training step under the chosen launches (per signature: calls x us, TF/s)
+    cen = []
+    for gain_us, key, n, b, u, c, sk in rows:
+        if n.get("train"):
+            taps = 1 if key[1] == hip.LINEAR else 9
+            fl = 2.0 * key[2] * key[3] * (taps * key[4] + key[5])
+            cen.append((n["train"] * u, n["train"], u, fl / u * 1e-6, key, c, sk))
+    cen.sort(reverse=True)
+    with open(os.path.join(os.path.dirname(args.log), "gemm_census_train_ingraph.txt"), "w") as f:
+        f.write(f"training step, {len(cen)} signatures, {sum(r[0] for r in cen) * 1e-3:.2f} ms per step "
+                "(launch time inside a replayed hipGraph, sum over calls)\n")
+        f.write(f"{'tot_us':>8} {'n':>4} {'us':>8} {'TF/s':>7}  (dtype, mode, M, N, K1, K2, geglu)  cfg sk (-1 = built-in)\n")
+        for t, cnt, us, tf, key, c, sk in cen:
+            f.write(f"{t:8.0f} {cnt:4d} {us:8.1f} {tf:7.1f}  {key}  {c} {sk}\n")
     head = {"device": torch.cuda.get_device_name(0), "columns": "dtype mode M N K1 K2 geglu cfg splitk",
             "gain_threshold": args.gain, "predicted_saving_ms": summary}
     with open(args.out, "w") as f:          # one entry per line: reviewable diffs
