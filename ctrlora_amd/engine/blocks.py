@@ -37,16 +37,61 @@ class Ctx:
         self._tcache: Dict[Tuple[int, int, int, int], torch.Tensor] = {}
         # queued weight-gradient problems (dy, x, dW, scale): flushed as ONE grouped launch per block
         self._wq: list = []
+        self._bq: list = []       # queued bias gradients (dy, db, rows, scale)
+        # Weight gradients feed nothing but the optimizer: with `wstream` set, a flushed group runs on that stream
+        # (own split scratch) while the main stream goes on with the next stage's data gradients.  One group is in
+        # flight at a time: (done event, operands kept alive, callback to run once the main stream has joined it).
+        self.wstream: Optional["torch.cuda.Stream"] = None
+        self._wpending = None
 
     def queue_wgrad(self, dy, x, dW, scale=1.0, conv=None):
         self._wq.append((dy, x, dW, scale, conv))  # keeps dy / x alive until the flush
         if len(self._wq) >= 24:
             self.flush_wgrad()
 
-    def flush_wgrad(self):
+    def queue_bias_grad(self, dy, db, rows: int, scale: float = 1.0):
+        """db += scale * column sums of dy: rides with the stage's weight-gradient group when that runs on the side stream."""
+        if self.wstream is None:
+            hip.colsum(dy, db, 1, rows, scale)
+        else:
+            self._bq.append((dy, db, rows, scale))
+
+    def _launch_group(self):
         if self._wq:
             hip.weight_grad_tn_group(self._wq)
-            self._wq = []
+        for dy, db, rows, scale in self._bq:
+            hip.colsum(dy, db, 1, rows, scale)
+
+    def flush_wgrad(self, after=None):
+        """Launch the queued group.  `after()` runs when the group's results are ordered before everything the main
+        stream does next: at once without a side stream, at the NEXT flush / retire_wgrad() with one."""
+        if self.wstream is None:
+            self._launch_group()
+            self._wq, self._bq = [], []
+            if after is not None:
+                after()
+            return
+        self.retire_wgrad()
+        if self._wq or self._bq:
+            main = torch.cuda.current_stream()
+            self.wstream.wait_stream(main)
+            with torch.cuda.stream(self.wstream):
+                self._launch_group()
+                done = torch.cuda.Event()
+                done.record(self.wstream)
+            self._wpending = (done, (self._wq, self._bq), after)
+            self._wq, self._bq = [], []
+        elif after is not None:
+            after()
+
+    def retire_wgrad(self):
+        """Join the group in flight into the main stream, release its operands, run its callback."""
+        if self._wpending is not None:
+            done, _held, after = self._wpending
+            self._wpending = None
+            torch.cuda.current_stream().wait_event(done)
+            if after is not None:
+                after()
 
     def new(self, rows: int, cols: int, dtype=None) -> torch.Tensor:
         return torch.empty((rows, cols), dtype=dtype or self.dtype, device=self.device)
@@ -155,7 +200,7 @@ def dense_bwd_weight(ctx: Ctx, L: LinearW, x, dy, B: int, HW: int, scale: float 
     else:
         hip.weight_grad(ctx.transposed(dy), ctx.transposed(x), L.tW.grad.view(L.N, L.K), scale)
     if L.tb is not None:
-        hip.colsum(dy, L.tb.grad.view(1, L.N), 1, B * HW, scale)
+        ctx.queue_bias_grad(dy, L.tb.grad.view(1, L.N), B * HW, scale)
 
 
 # --------------------------------------------------------------------------- norms

@@ -7,6 +7,8 @@ after the hint has been encoded to a 4-channel latent.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -19,6 +21,7 @@ from .packing import TrainableSet, rup
 
 class CtrLoRAEngine:
     overlap_streams = True     # ControlNet trunk || UNet encoder on two HIP streams (forward)
+    overlap_wgrad = os.environ.get("CTRLORA_OVERLAP_WGRAD", "1") != "0"   # weight gradients of stage i || data gradients of stage i+1
 
     def __init__(self, sd_unet: Dict[str, torch.Tensor], sd_controls: Sequence[Dict[str, torch.Tensor]], cfg: NetCfg,
                  dtype: torch.dtype = torch.bfloat16, device="cuda", need_bwd: bool = True,
@@ -189,8 +192,13 @@ class CtrLoRAEngine:
         hip.nchw_to_tok(d_eps.float().contiguous(), d_tok)
         dbufs = self.unet.decode_bwd(ctx, d_tok, dec_rec, B)
         dsinks = self.unet.control_grad_sinks(dbufs)
+        if self.overlap_wgrad and self.dtype == torch.bfloat16:
+            if self._side is None:
+                self._side = hip.side_stream(self.device)
+            ctx.wstream = self._side        # idle during backward; has its own split scratch
         for cn, (rec, w) in zip(self.controls, cn_recs):
             cn.bwd(ctx, rec, dsinks, scales, w, B)
+        ctx.wstream = None
 
     # ---------------------------------------------------------------- trainables
     def zero_grad(self):

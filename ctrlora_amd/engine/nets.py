@@ -502,11 +502,16 @@ class ControlNetE:
             self._done(ctx, self.stage_spans[k])
         self.time.bwd(ctx, env.dsemb, tsv)
         self._done(ctx, self.time_span)
+        ctx.retire_wgrad()      # every weight gradient of this network is ordered before what follows
 
     def _done(self, ctx, span):
-        ctx.flush_wgrad()       # the stage's queued weight gradients: one grouped launch
-        if self.on_stage_done is not None and span[1] > span[0]:
-            self.on_stage_done(span[0], span[1])
+        """End of a backward stage: its queued weight gradients go out as one grouped launch, and once they are
+        ordered before the main stream's next work (immediately, or one stage later when they ride the side stream)
+        the stage's slice of the flat gradient buffer is reported final (data-parallel overlap hook)."""
+        def report():
+            if self.on_stage_done is not None and span[1] > span[0]:
+                self.on_stage_done(span[0], span[1])
+        ctx.flush_wgrad(after=report)
 
     def _zero_bwd(self, ctx, k, h, dz, alpha, dh_in, B, HW, need_dx=True):
         z = self.zero[k]
