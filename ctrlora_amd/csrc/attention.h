@@ -38,6 +38,7 @@ int attn_bwd(const AttnBwdArgs& a, int dtype, hipStream_t st);
 // bf16, no materialised transposes (attention_tr.hip): Vt / Qt / dOt / Kt of the argument blocks are ignored
 int attn_fwd_tr(const AttnFwdArgs& a, const void* V, long ldv, hipStream_t st);
 int attn_bwd_tr(const AttnBwdArgs& a, hipStream_t st);
+extern int g_attn_fuse_delta;   // 1 = the dQ kernel forms delta (default), 0 = separate attn_delta launch
 extern int g_attn_variant;   // probe hook: 0 = heuristic, 1 = tile-synchronous kernels only (no ping-pong schedule)
 int attn_delta(const AttnBwdArgs& a, hipStream_t st);   // delta[q] = sum_d dO[q,d] O[q,d]  (bf16)
 

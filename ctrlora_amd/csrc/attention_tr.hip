@@ -750,7 +750,10 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_tr_kerne
 
 // =============================================================================== dQ
 // TAIL: Nkv is not a multiple of 64 (key masking)
-template <int DH, int QF, bool TAIL>
+// DELTA: delta[q] = sum_d dO[q,d] O[q,d] is formed here from the dO fragments the kernel holds anyway (+ one read of the
+// O rows) and stored for the dK/dV kernel, which then has to be launched AFTER this one: saves the separate
+// attn_delta launch (32 per training step, ~13 us each at the 64x64 level).
+template <int DH, int QF, bool TAIL, bool DELTA = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_tr_kernel(AttnBwdArgs p) {
   using G = Geo<DH>;
   constexpr int CPR = G::CPR, KSTEPS = G::KSTEPS, DN = G::DN, ROWB = G::ROWB, TILE = G::TILE;
@@ -778,7 +781,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_tr_kernel(AttnBwdArgs p) {
       ob[f][ks] = (c < CPR) ? *reinterpret_cast<const u32x4_t*>(op + c * 16) : u32x4_t{0u, 0u, 0u, 0u};
     }
     lse_q[f] = p.LSE[((long)b * p.H + h) * p.lse_stride + qr];
-    dlt_q[f] = p.Delta[((long)b * p.H + h) * p.lse_stride + qr];
+    if constexpr (DELTA) {
+      // lane (lq, g) holds channels [8 (4 ks + g), +8) of query lq: partial dot product, then the four g lanes
+      const char* orow = (const char*)p.O + (((long)b * p.N + qr) * p.ldo + (long)h * DH) * 2;
+      float acc = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        const int c = 4 * ks + g;
+        if (c < CPR) {
+          const u32x4_t ov = *reinterpret_cast<const u32x4_t*>(orow + c * 16);
+          const u32x4_t dv = ob[f][ks];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc += __uint_as_float(ov[j] << 16) * __uint_as_float(dv[j] << 16);
+            acc += __uint_as_float(ov[j] & 0xffff0000u) * __uint_as_float(dv[j] & 0xffff0000u);
+          }
+        }
+      }
+      acc += __shfl_xor(acc, 16, 64);
+      acc += __shfl_xor(acc, 32, 64);
+      dlt_q[f] = acc;
+      if (g == 0 && q_w + f * 16 + lq < p.N) p.Delta[((long)b * p.H + h) * p.lse_stride + qr] = acc;
+    } else {
+      dlt_q[f] = p.Delta[((long)b * p.H + h) * p.lse_stride + qr];
+    }
   }
   const char* kbase = (const char*)p.K + ((long)b * p.Nkv * p.ldk + (long)h * DH) * 2;
   const char* vbase = (const char*)p.V + ((long)b * p.Nkv * p.ldv + (long)h * DH) * 2;
@@ -1396,8 +1422,10 @@ int attn_fwd_tr(const AttnFwdArgs& a, const void* V, long ldv, hipStream_t st) {
   }
 }
 
+int g_attn_fuse_delta = 1;   // A/B hook (cl_attention_force_variant(16) clears it)
+
 template <int DH, bool TQ, bool TK>
-static int launch_bwd_tr_sync(const AttnBwdArgs& a, hipStream_t st, bool skip_dq);
+static int launch_bwd_tr_sync(const AttnBwdArgs& a, hipStream_t st, bool skip_dq, bool fused_delta = false);
 
 template <int DH, bool TQ, bool TK>
 static int launch_bwd_tr(const AttnBwdArgs& a, hipStream_t st) {
@@ -1411,6 +1439,10 @@ static int launch_bwd_tr(const AttnBwdArgs& a, hipStream_t st) {
       return CL_ELAUNCH;
     done = true;
   }
+  // default path: the tile-synchronous dQ kernel forms delta itself and runs first; the ping-pong probe variant
+  // (and anything that skips that kernel) keeps the separate delta launch
+  if (g_attn_variant != 3 && g_attn_fuse_delta)
+    return launch_bwd_tr_sync<DH, TQ, TK>(a, st, false, /*fused_delta=*/true);
   int rc = attn_delta(a, st);
   if (rc) return rc;
   if constexpr (!TQ && !TK && (DH == 40 || DH == 80)) {
@@ -1455,10 +1487,27 @@ static int launch_bwd_tr(const AttnBwdArgs& a, hipStream_t st) {
 }
 
 template <int DH, bool TQ, bool TK>
-static int launch_bwd_tr_sync(const AttnBwdArgs& a, hipStream_t st, bool skip_dq) {
+static int launch_bwd_tr_sync(const AttnBwdArgs& a, hipStream_t st, bool skip_dq, bool fused_delta) {
   constexpr int KF = DH <= 40 ? 2 : 1;
   constexpr int LDS_DKV = 2 * (2 * Geo<DH>::TILE + 512) + 64 + 16 * Geo<DH>::ROWB;
   constexpr int LDS_DQ = 2 * 2 * Geo<DH>::TILE + 64 + 16 * Geo<DH>::ROWB;
+  if (fused_delta) {   // dQ (+ delta) first, then dK/dV
+    static bool done = false;
+    if (!done) {
+      if (set_lds(&attn_bwd_dq_tr_kernel<DH, KF, TK, true>, LDS_DQ) || set_lds(&attn_bwd_dq_tr_kernel<DH, 1, TK, true>, LDS_DQ))
+        return CL_ELAUNCH;
+      done = true;
+    }
+    const long qb2 = (long)((a.N + 64 * KF - 1) / (64 * KF)) * a.H * a.B;
+    if (KF == 2 && qb2 >= 512) {
+      dim3 grid((a.N + 127) / 128, a.H, a.B);
+      hipLaunchKernelGGL((attn_bwd_dq_tr_kernel<DH, KF, TK, true>), grid, dim3(256), LDS_DQ, st, a);
+    } else {
+      dim3 grid((a.N + 63) / 64, a.H, a.B);
+      hipLaunchKernelGGL((attn_bwd_dq_tr_kernel<DH, 1, TK, true>), grid, dim3(256), LDS_DQ, st, a);
+    }
+    skip_dq = true;
+  }
   if (a.dK) {
     // two key fragments per wave only when that still leaves enough workgroups to fill the chip
     const long blocks2 = (long)((a.Nkv + 64 * KF - 1) / (64 * KF)) * a.H * a.B;

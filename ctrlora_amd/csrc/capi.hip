@@ -41,7 +41,10 @@ int cl_gemm_tune_set(int dtype, int mode, int M, int N, int K1, int K2, int gegl
 }
 int cl_gemm_tune_clear(void) { gemm_tune_clear(); return CL_OK; }
 int cl_gemm_tune_size(void) { return gemm_tune_size(); }
-int cl_attention_force_variant(int v) { g_attn_variant = v; return CL_OK; }
+int cl_attention_force_variant(int v) {
+  if (v == 16 || v == 17) { g_attn_fuse_delta = v == 17; return CL_OK; }   // 16 / 17: separate / fused delta (A/B hook)
+  g_attn_variant = v; return CL_OK;
+}
 
 int cl_gemm(const cl_gemm_params* p, int dtype, void* stream) {
   if (!p) return CL_EINVAL;

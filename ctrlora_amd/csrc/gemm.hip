@@ -435,9 +435,21 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_kernel(GemmParams p, i
 // validity mask computed once, and a wave-uniform (scalar) tap offset updated when the tap changes.
 enum { FL_LINEAR = 0, FL_CONV_S1 = 1, FL_CONV_ANY = 2 };
 
-template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int R, int PRIO = 0>
-__global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p, int tiles_m, int tiles_n,
-                                                                 float* __restrict__ slab) {
+#ifdef FL_TIMING
+// probe builds only (tools/probe_gemm.hip): wave 0 of every workgroup stores s_memtime at five points of its tile
+__device__ unsigned long long* g_fl_timing = nullptr;
+#define FL_STAMP(i) do { if (g_fl_timing && threadIdx.x == 0) { g_fl_timing[(long)vpid * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+    if ((i) == 0) { g_fl_timing[(long)vpid * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    /* HW_ID */ \
+                    g_fl_timing[(long)vpid * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 20); } } } while (0)   /* XCC_ID */
+void fl_timing_set(unsigned long long* buf) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fl_timing), &buf, sizeof(buf)); }
+#else
+#define FL_STAMP(i) do { } while (0)
+#endif
+
+// One output tile (virtual workgroup id `vpid` in [0, tiles * splitk)) of the full-line kernel.
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int R, int PRIO>
+__device__ __forceinline__ void fl_tile(const GemmParams& p, int tiles_m, int tiles_n, float* __restrict__ slab,
+                                        int vpid, char* smem) {
   constexpr int NW = WGM * WGN;
   static_assert(R == 2 || R == 3, "ring depth");
   constexpr int KPS = 128 / (int)sizeof(T);  // elements per stage row
@@ -450,14 +462,14 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p
   constexpr int EROWS = (FM >= 2) ? 32 : 16;
   static_assert(AI % NW == 0 && WM % 16 == 0 && WN % 16 == 0, "tile shape");
   static_assert(NW * EROWS * EST * 4 <= R * SLOT, "epilogue staging must fit in the ring");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  FL_STAMP(0);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
 
   const int nt = tiles_m * tiles_n;
-  int pid = blockIdx.x;
+  int pid = vpid;
   const int zsplit = pid / nt;
   pid -= zsplit * nt;
   {
@@ -612,6 +624,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p
     ++kt_next;
   };
   auto issue_next = [&](int slot) { issue_a(slot); issue_b(slot); };
+  FL_STAMP(1);
 
   f32x4_t acc[FM][FN];
 #pragma unroll
@@ -711,6 +724,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p
     if (total > 1) issue_next(1);
     if (total > 2) { issue_a(2); wait_vm<G + AJ>(); } else if (total > 1) { wait_vm<G>(); } else { wait_vm<0>(); }
     __builtin_amdgcn_s_barrier();
+    FL_STAMP(2);
     __builtin_amdgcn_sched_barrier(0);
     read_frags(0, 0, fa, fb);
     wait_frags(fa, fb);
@@ -821,6 +835,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p
     wait_vm<0>();
   }
   __builtin_amdgcn_s_barrier();
+  FL_STAMP(2);
   __builtin_amdgcn_sched_barrier(0);
   read_frags(0, 0, fa, fb);
   wait_frags(fa, fb);
@@ -859,11 +874,34 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p
   for (; s + 2 < total; ++s) stage(std::true_type{}, true);
   for (; s < total; ++s) stage(std::false_type{}, s + 1 < total);
   }
+  FL_STAMP(3);
   __syncthreads();  // all waves done with the operand slots; reuse LDS for the epilogue
 
   store_tile<T, FM, FN, (WGN == 2 && FN == 5)>(p, acc, reinterpret_cast<float*>(smem) + wave * (EROWS * EST),
                                                m0 + wm * WM, n0 + wn * WN, lane, slab, zsplit, wn,
                                                reinterpret_cast<float*>(smem) + (wave ^ 1) * (EROWS * EST));
+  FL_STAMP(4);
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int R, int PRIO = 0>
+__global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p, int tiles_m, int tiles_n,
+                                                                 float* __restrict__ slab) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  fl_tile<T, BM, BN, WGM, WGN, MODE, R, PRIO>(p, tiles_m, tiles_n, slab, (int)blockIdx.x, smem);
+}
+
+// Persistent form: gridDim.x workgroups (a multiple of 8, at most what the chip holds at once) walk the virtual
+// workgroup ids blockIdx.x, blockIdx.x + gridDim.x, ... -- the XCD of a virtual id is unchanged (id mod 8), and a
+// workgroup pays its launch, kernel-argument and first-touch costs once instead of once per tile.  For the
+// small-K products (K = 320: five stages per tile) those fixed costs are several times the tile's MFMA time.
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int R, int PRIO = 0>
+__global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_persist_kernel(GemmParams p, int tiles_m, int tiles_n,
+                                                                         float* __restrict__ slab, int nvirt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  for (int v = blockIdx.x; v < nvirt; v += gridDim.x) {
+    fl_tile<T, BM, BN, WGM, WGN, MODE, R, PRIO>(p, tiles_m, tiles_n, slab, v, smem);
+    __syncthreads();   // the epilogue staging aliases the operand ring of the next tile
+  }
 }
 
 // sum the split-K slabs and apply the epilogue: one lane per 8 output columns
@@ -1008,15 +1046,26 @@ static int pick_splitk(GemmParams& p, long tiles, int steps, int want, int min_s
   return p.splitk;
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int R, int PRIO = 0>
+static int device_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0; hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256;
+    n = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+  }
+  return n;
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int R, int PRIO = 0, bool PERSIST = false>
 static int launch_fl_mode(const GemmParams& p0, hipStream_t stream) {
   constexpr int NW = WGM * WGN;
   constexpr int SMEM = R * (BM / 8 + BN / 8) * 1024;
-  auto kern = &gemm_fl_kernel<T, BM, BN, WGM, WGN, MODE, R, PRIO>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (SMEM > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
+    const void* k;
+    if constexpr (PERSIST) k = reinterpret_cast<const void*>(&gemm_fl_persist_kernel<T, BM, BN, WGM, WGN, MODE, R, PRIO>);
+    else k = reinterpret_cast<const void*>(&gemm_fl_kernel<T, BM, BN, WGM, WGN, MODE, R, PRIO>);
+    if (SMEM > 65536 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
       return CL_ELAUNCH;
     attr_set = true;
   }
@@ -1027,7 +1076,21 @@ static int launch_fl_mode(const GemmParams& p0, hipStream_t stream) {
   const int steps = ((MODE == FL_LINEAR ? 1 : 9) * p.K1 + p.K2) / kps;
   float* slab;
   pick_splitk(p, tiles, steps, R == 3 ? (BM == 128 ? g_fl128_split_want : 256) : 512, 4, &slab, stream);
-  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * p.splitk)), dim3(NW * 64), SMEM, stream, p, tm, tn, slab);
+  const long nvirt = tiles * p.splitk;
+  if constexpr (PERSIST) {
+    // as many workgroups as stay resident together (LDS-bound: one per CU above 80 KB, else two), a multiple of 8
+    // so that virtual id mod 8 -- the XCD -- is the same for every tile a workgroup walks
+    long grid = (long)device_cus() * (SMEM > 80 * 1024 ? 1 : 2);
+    grid -= grid % 8;
+    if (grid > nvirt) grid = nvirt;
+    if (grid < nvirt) grid -= grid % 8;
+    if (grid < 1) grid = nvirt;
+    hipLaunchKernelGGL((gemm_fl_persist_kernel<T, BM, BN, WGM, WGN, MODE, R, PRIO>), dim3((unsigned)grid), dim3(NW * 64),
+                       SMEM, stream, p, tm, tn, slab, (int)nvirt);
+  } else {
+    hipLaunchKernelGGL((gemm_fl_kernel<T, BM, BN, WGM, WGN, MODE, R, PRIO>), dim3((unsigned)nvirt), dim3(NW * 64), SMEM,
+                       stream, p, tm, tn, slab);
+  }
   if (slab) {
     const long total = (long)p.M * (p.N / 8);
     int rg = (int)((total + 255) / 256); if (rg > 4096) rg = 4096;
@@ -1037,9 +1100,10 @@ static int launch_fl_mode(const GemmParams& p0, hipStream_t stream) {
   return CL_OK;
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int R, int PRIO = 0>
+template <typename T, int BM, int BN, int WGM, int WGN, int R, int PRIO = 0, bool PERSIST = false>
 static int launch_fl(const GemmParams& p, hipStream_t stream) {
-  if (p.mode == GEMM_LINEAR) return launch_fl_mode<T, BM, BN, WGM, WGN, FL_LINEAR, R, PRIO>(p, stream);
+  if (p.mode == GEMM_LINEAR) return launch_fl_mode<T, BM, BN, WGM, WGN, FL_LINEAR, R, PRIO, PERSIST>(p, stream);
+  if constexpr (PERSIST) return CL_EINVAL;   // persistent form: linear products only (callers check)
   if (p.K2) return CL_EINVAL;   // a second K segment exists for linear operands only
   if (p.mode == GEMM_CONV_S1) return launch_fl_mode<T, BM, BN, WGM, WGN, FL_CONV_S1, R, PRIO>(p, stream);
   return launch_fl_mode<T, BM, BN, WGM, WGN, FL_CONV_ANY, R>(p, stream);   // ping-pong measured slower here (heavy address VALU in the L sections)
@@ -1062,7 +1126,7 @@ struct TuneKey {
 static std::map<TuneKey, std::pair<int, int>> g_tune;
 
 int gemm_tune_set(int dtype, int mode, int M, int N, int K1, int K2, int geglu, int cfg, int splitk) {
-  if (cfg < 0 || cfg > 24 || splitk < 0 || splitk > 64) return CL_EINVAL;
+  if (cfg < 0 || cfg > 30 || splitk < 0 || splitk > 64) return CL_EINVAL;
   g_tune[TuneKey{{dtype, mode, M, N, K1, K2, geglu ? 1 : 0}}] = std::make_pair(cfg, splitk);
   return CL_OK;
 }
@@ -1088,7 +1152,7 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
 
 template <typename T>
 static int launch_t_cfg(const GemmParams& p, hipStream_t stream, int cfg) {
-  if (p.act == ACT_GEGLU && cfg != 2 && cfg != 12 && cfg != 8 && cfg != 10 && cfg != 14 && cfg != 16 && cfg != 18 && cfg != 20 && cfg != 23) cfg = -2;   // needs a 2 x 80-column wave pair
+  if (p.act == ACT_GEGLU && cfg != 2 && cfg != 12 && cfg != 8 && cfg != 10 && cfg != 14 && cfg != 16 && cfg != 18 && cfg != 20 && cfg != 23 && cfg != 25 && cfg != 27 && cfg != 29) cfg = -2;   // needs a 2 x 80-column wave pair
   if (cfg < 0) {
     // v2 (64-byte substeps, 4 waves) choices
     if (p.M <= 64 || p.N <= 64) cfg = 0;
@@ -1162,6 +1226,19 @@ static int launch_t_cfg(const GemmParams& p, hipStream_t stream, int cfg) {
       if (p.K1 % kps || p.K2 % kps || (p.mode != GEMM_LINEAR && p.K2))
         return launch_cfg<T, 128, 128, 2, 2, 2, 4>(p, stream);
       return cfg == 10 ? launch_fl<T, 128, 160, 2, 2, 2>(p, stream) : launch_fl<T, 128, 128, 2, 2, 2>(p, stream);
+    }
+    case 25: case 26: case 27: case 28: case 29: case 30: {   // persistent forms of 16 / 17 / 20 / 21 / 10 / 11 (linear products)
+      const int kps = 128 / (int)sizeof(T);
+      if (p.K1 % kps || p.K2 % kps || p.mode != GEMM_LINEAR)
+        return launch_cfg<T, 128, 128, 2, 2, 2, 4>(p, stream);
+      switch (cfg) {
+        case 25: return launch_fl<T, 256, 160, 4, 2, 3, 3, true>(p, stream);
+        case 26: return launch_fl<T, 256, 128, 4, 2, 3, 3, true>(p, stream);
+        case 27: return launch_fl<T, 128, 160, 4, 2, 3, 3, true>(p, stream);
+        case 28: return launch_fl<T, 128, 128, 4, 2, 3, 3, true>(p, stream);
+        case 29: return launch_fl<T, 128, 160, 2, 2, 2, 0, true>(p, stream);
+        default: return launch_fl<T, 128, 128, 2, 2, 2, 0, true>(p, stream);
+      }
     }
     // small-M tiles of the generic kernel (8x8 / 16x16 levels, text-context projections): offered to the tuner
     case 22: return launch_cfg<T, 64, 128, 2, 2, 1, 4>(p, stream);

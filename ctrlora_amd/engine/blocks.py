@@ -130,12 +130,13 @@ def linear_fwd(ctx: Ctx, L: LinearW, x, out=None, residual=None, act=hip.ACT_NON
     """y = (x W^T + b [+ (x A^T) B^T]) * alpha + beta * residual.  Returns (y, t = x A^T or None)."""
     M = x.shape[0]
     t = None
-    if L.r:
+    merged = L.Wm is not None and not ctx.record      # inference executor: W + B A already folded
+    if L.r and not merged:
         t = ctx.new(M, L.r)
         hip.gemm(x, L.A, t)
     if out is None:
         out = ctx.new(M, L.N, torch.float32 if out_f32 else None)
-    hip.gemm(x, L.W, out, a2=t, w2=L.B if L.r else None, bias=L.bias, residual=residual,
+    hip.gemm(x, L.Wm if merged else L.W, out, a2=t, w2=L.B if t is not None else None, bias=L.bias, residual=residual,
              alpha=alpha, beta=beta if residual is not None else 0.0, act=act, out_f32=out_f32)
     return out, t
 
@@ -488,7 +489,7 @@ class SpatialTransformerE:
             L = self.ff_proj
             Wg, bg, Bg = L.geglu_pack()
             tp = None
-            if L.r:
+            if Bg is not None:
                 tp = ctx.new(B * N, L.r)
                 hip.gemm(n3, L.A, tp)
             gg = ctx.new(B * N, 4 * self.C)

@@ -16,6 +16,8 @@ Dataflow differences from the reference that do not change the arithmetic:
 """
 from __future__ import annotations
 
+import os
+
 import math
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -325,12 +327,17 @@ def _encoder_layers(b: _Builder, cfg: NetCfg, lora: bool, after_block=None):
 class ControlNetE:
     def __init__(self, sd, cfg: NetCfg, dtype, device, prefix: str = "", need_bwd: bool = True,
                  trainables: Optional[TrainableSet] = None, layout_only: bool = False, train_all: bool = False,
-                 lora_set: Optional[TrainableSet] = None):
-        """layout_only: build the flat trainable layout (offsets, backward-ordered stage spans, the stage-completion
+                 lora_set: Optional[TrainableSet] = None, merge_lora: Optional[bool] = None):
+        """merge_lora (default: on for executors built without a backward): fold W + B A into one packed weight per
+        LoRA linear at every repack, as the reference's _fuse_lora does for inference (cldm/lora.py:297-318).
+        layout_only: build the flat trainable layout (offsets, backward-ordered stage spans, the stage-completion
         hook) without packing anything for the kernels -- what the data-parallel exchange needs; usable without a
         GPU (the multi-process gloo tests).  Such an executor cannot run: fwd / bwd raise."""
         self.cfg, self.dtype, self.device = cfg, dtype, device
         self.layout_only = layout_only
+        self.merge_lora = (not need_bwd) if merge_lora is None else bool(merge_lora)
+        if os.environ.get("CTRLORA_MERGE_LORA", "1") == "0":
+            self.merge_lora = False
         self.tr = trainables if trainables is not None else TrainableSet()
         self.train_all = train_all
         # pre-training: base weights in self.tr, the active task's LoRA bank in self.tr_lora (switch_bank swaps it)
@@ -439,6 +446,8 @@ class ControlNetE:
             if n:
                 hip.repack(self.dtype, ts.flat, desc, prefix, n, tiles)
         for L in self._b.linears:
+            if self.merge_lora:
+                L.merge_lora()
             L.invalidate_geglu()     # permuted (GEGLU-fused) copies are rebuilt lazily from the fresh B
 
     def fwd(self, ctx: Ctx, hint_tok, t, c, B, H, W, sinks, scales, weight=1.0, kv=None):

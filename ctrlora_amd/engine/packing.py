@@ -104,6 +104,9 @@ class LinearW:
         self.tA: Optional[Trainable] = None
         self.tB: Optional[Trainable] = None
         self.A = self.At = self.B = self.Bt = None
+        # inference executors: W + B A folded into one packed weight (cldm/lora.py:_fuse_lora does the same on the
+        # module; the reference sanctions it for inference) -- no down-projection launch, no second K segment
+        self.Wm: Optional[torch.Tensor] = None
         # trainable dense weight (zero convs)
         self.tW: Optional[Trainable] = None
         self.tb: Optional[Trainable] = None
@@ -133,9 +136,9 @@ class LinearW:
             j = torch.arange(half // 80, device=self.W.device).repeat_interleave(160)
             c = torch.arange(160, device=self.W.device).repeat(half // 80)
             perm = torch.where(c < 80, j * 80 + c, half + j * 80 + (c - 80))
-            Wg = self.W.index_select(0, perm).contiguous()
+            Wg = (self.W if self.Wm is None else self.Wm).index_select(0, perm).contiguous()
             bg = None if self.bias is None else self.bias.index_select(0, perm).contiguous()
-            Bg = self.B.index_select(0, perm).contiguous() if self.r else None
+            Bg = self.B.index_select(0, perm).contiguous() if (self.r and self.Wm is None) else None
             g = (Wg, bg, Bg)
             self.__dict__["_geglu"] = g
         return g
@@ -150,6 +153,17 @@ class LinearW:
         self.At = torch.empty(self.K, self.r, dtype=self.dtype, device=device)
         self.B = torch.empty(self.N, self.r, dtype=self.dtype, device=device)
         self.Bt = torch.empty(self.r, self.N, dtype=self.dtype, device=device)
+
+    def merge_lora(self):
+        """Wm = storage-dtype(W + B A) from the packed base weight and the fp32 LoRA masters (weight-load time only)."""
+        if self.tA is None:
+            return
+        m = torch.addmm(self.W.float(), self.tB.master.view(self.N, self.r), self.tA.master.view(self.r, self.K))
+        if self.Wm is None:
+            self.Wm = m.to(self.dtype).contiguous()
+        else:
+            self.Wm.copy_(m)
+        self.invalidate_geglu()
 
     def attach_trainable_weight(self, tW: Trainable, tb: Optional[Trainable]):
         self.tW, self.tb = tW, tb

@@ -128,6 +128,8 @@ def lib():
             fn.argtypes = args
             fn.restype = C.c_long if name == "cl_groupnorm_ws_floats" else C.c_int
         _lib = L
+        if os.environ.get("CTRLORA_ATTN_FUSE_DELTA", "1") == "0":      # A/B switch: separate attn_delta launch
+            L.cl_attention_force_variant(16)
         if os.environ.get("CTRLORA_GEMM_TUNED", "1") != "0":
             load_gemm_table(os.environ.get("CTRLORA_GEMM_TABLE", GEMM_TABLE_PATH))
     return _lib

@@ -8,6 +8,7 @@ C=ctrlora_amd/csrc
 for p in "$@"; do
   case $p in
     gemm) hipcc $FLAGS tools/probe_gemm.hip $C/gemm.hip $C/wgrad.hip -o build/probe_gemm ;;
+    gemm_t) hipcc $FLAGS -DFL_TIMING tools/probe_gemm.hip $C/gemm.hip $C/wgrad.hip -o build/probe_gemm_t ;;
     attn) hipcc $FLAGS tools/probe_attn.hip $C/gemm.hip $C/attention_fwd.hip $C/attention_bwd.hip $C/attention_tr.hip $C/elementwise.hip -o build/probe_attn ;;
     attn_bwd) hipcc $FLAGS tools/probe_attn_bwd.hip $C/gemm.hip $C/attention_fwd.hip $C/attention_bwd.hip $C/attention_tr.hip $C/elementwise.hip -o build/probe_attn_bwd ;;
     *) echo "unknown probe $p"; exit 1 ;;

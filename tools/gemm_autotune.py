@@ -26,9 +26,10 @@ import bench  # noqa: E402
 from ctrlora_amd import hip  # noqa: E402
 
 FL = (10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21)   # full-line (LDS-DMA, 128-byte K lines) configurations
-W160 = (2, 5, 10, 12, 14, 16, 18, 20, 23)               # 160-column tiles
-W128 = (1, 7, 11, 13, 15, 17, 19, 21, 22)               # 128-column tiles
-GEGLU_OK = (2, 10, 12, 14, 16, 18, 20, 23)              # a value / gate wave pair per 160-column tile
+PERSIST = (25, 26, 27, 28, 29, 30)                      # persistent forms of 16 / 17 / 20 / 21 / 10 / 11 (linear only)
+W160 = (2, 5, 10, 12, 14, 16, 18, 20, 23, 25, 27, 29)   # 160-column tiles
+W128 = (1, 7, 11, 13, 15, 17, 19, 21, 22, 26, 28, 30)   # 128-column tiles
+GEGLU_OK = (2, 10, 12, 14, 16, 18, 20, 23, 25, 27, 29)  # a value / gate wave pair per 160-column tile
 
 
 class Recorder:
@@ -95,9 +96,11 @@ def candidates(key):
     taps = 1 if mode == hip.LINEAR else 9
     fl_ok = K1 % 64 == 0 and K2 % 64 == 0 and not (mode != hip.LINEAR and K2) and M > 128 and N >= 96
     cfgs = [0, 24] if N % 64 == 0 else [0]
-    for c in (1, 2, 5, 7, 22, 23) + FL:
+    for c in (1, 2, 5, 7, 22, 23) + FL + PERSIST:
         if c in FL and not fl_ok:
             continue
+        if c in PERSIST and not (fl_ok and mode == hip.LINEAR and M * N >= 256 * 160 * 512):
+            continue                      # persistent walk only where a workgroup would own several tiles
         if c in W160 and N % 160:
             continue
         if c in W128 and N % 128 and N % 160 == 0:

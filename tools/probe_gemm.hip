@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <map>
 #include <vector>
 #include "../ctrlora_amd/csrc/gemm.h"
 
@@ -289,6 +291,81 @@ static void correctness_suite(const char* tag) {
   case_conv("conv3x3 s1 f32 1x9x7x16->24", CL_F32, GEMM_CONV_S1, 1, 9, 7, 16, 24);
 }
 
+#ifdef FL_TIMING
+namespace cl { void fl_timing_set(unsigned long long* buf); }
+#endif
+
+// persistent vs one-tile-per-workgroup form of the same tile code: results must be IDENTICAL (same tiles, same math)
+static void persist_case(const char* name, int M, int N, int K1, int K2, int act, int cfg, int pcfg, bool timing) {
+  Buf A, Wt, A2, W2, C0, C1;
+  A.init((size_t)M * K1, CL_BF16); Wt.init((size_t)N * K1, CL_BF16, 0.05f);
+  if (K2) { A2.init((size_t)M * K2, CL_BF16); W2.init((size_t)N * K2, CL_BF16, 0.05f); }
+  const int No = act == ACT_GEGLU ? N / 2 : N;
+  C0.init((size_t)M * No, CL_BF16, 1.f, true); C1.init((size_t)M * No, CL_BF16, 1.f, true);
+  GemmParams p{}; p.A1 = A.d; p.lda1 = K1; p.K1 = K1; p.W1 = Wt.d; p.ldw1 = K1; p.M = M; p.N = N; p.mode = GEMM_LINEAR;
+  if (K2) { p.A2 = A2.d; p.lda2 = K2; p.K2 = K2; p.W2 = W2.d; p.ldw2 = K2; }
+  p.zero_page = g_zero; p.alpha = 1.f; p.ldc = No; p.splitk = 1; p.act = act;
+  float ms[2]; int rc[2];
+  hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  for (int v = 0; v < 2; ++v) {
+    g_gemm_force_cfg = v ? pcfg : cfg; p.C = v ? C1.d : C0.d;
+    for (int i = 0; i < 3; ++i) rc[v] = launch_gemm(p, CL_BF16, 0);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipEventRecord(e0, 0));
+    for (int i = 0; i < 20; ++i) launch_gemm(p, CL_BF16, 0);
+    HIPCHK(hipEventRecord(e1, 0)); HIPCHK(hipEventSynchronize(e1));
+    HIPCHK(hipEventElapsedTime(&ms[v], e0, e1)); ms[v] /= 20;
+  }
+  std::vector<uint16_t> h0((size_t)M * No), h1((size_t)M * No);
+  HIPCHK(hipMemcpy(h0.data(), C0.d, h0.size() * 2, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(h1.data(), C1.d, h1.size() * 2, hipMemcpyDeviceToHost));
+  size_t diff = 0, nz = 0;
+  for (size_t i = 0; i < h0.size(); ++i) { diff += h0[i] != h1[i]; nz += h0[i] != 0; }
+  const bool ok = rc[0] == 0 && rc[1] == 0 && diff == 0 && nz > h0.size() / 2;
+  double fl = 2.0 * M * N * ((double)K1 + K2);
+  printf("[%s] %-40s cfg %2d: %7.1f us %7.1f TF | persistent cfg %2d: %7.1f us %7.1f TF | %zu differing of %zu\n", ok ? "PASS" : "FAIL",
+         name, cfg, ms[0] * 1e3, fl / ms[0] * 1e-9, pcfg, ms[1] * 1e3, fl / ms[1] * 1e-9, diff, h0.size());
+  if (!ok) g_fail++;
+#ifdef FL_TIMING
+  if (timing) {
+    for (int v = 0; v < 2; ++v) {
+      const int bm = ((v ? pcfg : cfg) == 16 || (v ? pcfg : cfg) == 25) ? 256 : 128;
+      const long nv = (long)((M + bm - 1) / bm) * ((N + 159) / 160);
+      unsigned long long* tb; HIPCHK(hipMalloc(&tb, nv * 64)); HIPCHK(hipMemset(tb, 0, nv * 64));
+      cl::fl_timing_set(tb);
+      g_gemm_force_cfg = v ? pcfg : cfg; p.C = C1.d;
+      launch_gemm(p, CL_BF16, 0); HIPCHK(hipDeviceSynchronize());
+      cl::fl_timing_set(nullptr);
+      std::vector<unsigned long long> t(nv * 8);
+      HIPCHK(hipMemcpy(t.data(), tb, nv * 64, hipMemcpyDeviceToHost)); HIPCHK(hipFree(tb));
+      // phases per tile, and per-CU turnaround between consecutive tiles on the same compute unit
+      double ph[4] = {0, 0, 0, 0}; unsigned long long tmin = ~0ull, tmax = 0;
+      std::vector<std::pair<unsigned long long, long>> order;
+      for (long i = 0; i < nv; ++i) {
+        for (int k = 0; k < 4; ++k) ph[k] += (double)(t[i * 8 + k + 1] - t[i * 8 + k]);
+        tmin = std::min(tmin, t[i * 8]); tmax = std::max(tmax, t[i * 8 + 4]);
+        order.push_back({t[i * 8], i});
+      }
+      std::sort(order.begin(), order.end());
+      std::map<unsigned long long, unsigned long long> last_end; double gap = 0; long ngap = 0;
+      for (auto& o : order) {
+        const long i = o.second;
+        const unsigned long long hw = t[i * 8 + 5], xcc = t[i * 8 + 6] & 0xf;
+        const unsigned long long cu = (xcc << 16) | (hw & 0xff00) | ((hw >> 4) & 0x3 ? 0 : 0);   // xcc, se/sh/cu bits
+        auto it = last_end.find(cu);
+        if (it != last_end.end() && t[i * 8] > it->second) { gap += (double)(t[i * 8] - it->second); ++ngap; }
+        if (it == last_end.end() || t[i * 8 + 4] > it->second) last_end[cu] = t[i * 8 + 4];
+      }
+      printf("       timing cfg %2d: %ld tiles on %zu CUs, span %.0f ticks; per tile: setup %.0f | first stage %.0f | main loop %.0f | epilogue %.0f | "
+             "idle between tiles on a CU %.0f (n=%ld)  [s_memtime ticks]\n", v ? pcfg : cfg, nv, last_end.size(), (double)(tmax - tmin),
+             ph[0] / nv, ph[1] / nv, ph[2] / nv, ph[3] / nv, ngap ? gap / ngap : 0.0, ngap);
+    }
+  }
+#endif
+  g_gemm_force_cfg = -1;
+  hipFree(A.d); hipFree(Wt.d); hipFree(C0.d); hipFree(C1.d); if (K2) { hipFree(A2.d); hipFree(W2.d); }
+}
+
 int main(int argc, char** argv) {
   hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s  CUs=%d  arch=%s\n", prop.name, prop.multiProcessorCount, prop.gcnArchName);
@@ -317,6 +394,26 @@ int main(int argc, char** argv) {
       g_probe_act = 0;
     }
     return 0;
+  }
+  if (argc > 1 && !strcmp(argv[1], "--persist")) {
+    const int pairs[][2] = {{16, 25}, {20, 27}, {10, 29}};
+    for (auto& pr : pairs) {
+      persist_case("32768x320x320 (to_q @64^2 B8)", 32768, 320, 320, 0, 0, pr[0], pr[1], true);
+      persist_case("32768x320x320+r128", 32768, 320, 320, 128, 0, pr[0], pr[1], false);
+      persist_case("32768x2560x320 (FF proj)", 32768, 2560, 320, 0, 0, pr[0], pr[1], true);
+      persist_case("32768x2560x320 GEGLU", 32768, 2560, 320, 0, ACT_GEGLU, pr[0], pr[1], false);
+      persist_case("131072x2560x320 GEGLU (DDIM)", 131072, 2560, 320, 0, ACT_GEGLU, pr[0], pr[1], true);
+      persist_case("131072x320x320 (DDIM)", 131072, 320, 320, 0, 0, pr[0], pr[1], false);
+      persist_case("131072x960x320 (DDIM qkv)", 131072, 960, 320, 0, 0, pr[0], pr[1], false);
+      persist_case("32768x320x1280 (FF out)", 32768, 320, 1280, 0, 0, pr[0], pr[1], false);
+      persist_case("8192x5120x640", 8192, 5120, 640, 0, 0, pr[0], pr[1], false);
+      persist_case("8192x640x640", 8192, 640, 640, 0, 0, pr[0], pr[1], false);
+      persist_case("2048x10240x1280", 2048, 10240, 1280, 0, 0, pr[0], pr[1], false);
+      persist_case("ragged 40000x320x320", 40000, 320, 320, 0, 0, pr[0], pr[1], false);
+      persist_case("ragged 33333x480x192+64", 33333, 480, 192, 64, 0, pr[0], pr[1], false);
+    }
+    printf("probe_gemm --persist: %s (%d failures)\n", g_fail ? "FAILED" : "ALL PASS", g_fail);
+    return g_fail ? 1 : 0;
   }
   if (argc > 1 && !strcmp(argv[1], "--knobs")) {   // split-K tuning knobs on the shapes they affect
     for (int want : {256, 128, 256, 128}) {
