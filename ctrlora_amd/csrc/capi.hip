@@ -43,6 +43,7 @@ int cl_gemm_tune_clear(void) { gemm_tune_clear(); return CL_OK; }
 int cl_gemm_tune_size(void) { return gemm_tune_size(); }
 int cl_attention_force_variant(int v) {
   if (v == 16 || v == 17) { g_attn_fuse_delta = v == 17; return CL_OK; }   // 16 / 17: separate / fused delta (A/B hook)
+  if (v == 32 || v == 33) { g_gn_three_pass = v == 32; return CL_OK; }      // 32 / 33: three- / two-launch GroupNorm (A/B hook)
   g_attn_variant = v; return CL_OK;
 }
 

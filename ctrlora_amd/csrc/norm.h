@@ -4,6 +4,8 @@
 
 namespace cl {
 
+extern int g_gn_three_pass;   // A/B hook: 1 = partial -> finalize -> apply for every GroupNorm
+
 struct GnArgs {
   const void* x; long ldx;      // [B*HW, C] token-major (NHWC), row stride ldx
   void* y; long ldy;

@@ -13,6 +13,7 @@
 // (openaimodel.py:201-202,225-226; eps 1e-5), SpatialTransformer.norm
 // (attention.py:88-89,295; eps 1e-6, no SiLU), BasicTransformerBlock.norm1-3
 // (attention.py:263-265; eps 1e-5), UNetModel.out[0:2] (openaimodel.py:726-728).
+#include <algorithm>
 #include "norm.h"
 #include "gemm.h"
 
@@ -153,9 +154,148 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, long ldx, T* __restrict
   }
 }
 
+// ---- two-launch forms (no finalize launch).  The statistics pass reduces its chunk to per-GROUP sums
+// ([B][nchunk][G][2] floats); every workgroup of the apply pass then sums the nchunk partials of its sample itself
+// (fp64, fixed order: deterministic) -- G * nchunk * 8 bytes from L2, a microsecond -- instead of a third launch whose
+// ~6 us are almost all launch latency (149 such launches per training step).  Needs one channel pass per lane
+// (C <= 2560) and G <= 64.
+
+// LDS layout helper: channel totals [C][2] floats reuse the py-reduction scratch
+template <typename T>
+__global__ void gn_gpartial_kernel(const T* __restrict__ x, long ldx, int HW, int C, int G, int VX, int PY, int ppc,
+                                   int nchunk, float* __restrict__ gpartial) {
+  extern __shared__ float red[];  // max([PY][VX][16], [C][2]) floats
+  const int vx = threadIdx.x % VX, py = threadIdx.x / VX;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int p0 = chunk * ppc, p1 = min(HW, p0 + ppc);
+  float s[8], q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+  for (int p = p0 + py; p < p1; p += PY) {
+    float f[8];
+    load8(x + ((long)b * HW + p) * ldx + vx * 8, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+  }
+  float* r = red + (py * VX + vx) * 16;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { r[e] = s[e]; r[8 + e] = q[e]; }
+  __syncthreads();
+  if (py == 0) {
+    for (int k = 1; k < PY; ++k) {
+      const float* o = red + (k * VX + vx) * 16;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] += o[e]; q[e] += o[8 + e]; }
+    }
+  }
+  __syncthreads();
+  if (py == 0) {
+    float* ch = red + vx * 16;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ch[2 * e] = s[e]; ch[2 * e + 1] = q[e]; }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < G) {
+    const int cg = C / G, c0 = threadIdx.x * cg;
+    float S = 0.f, Q = 0.f;
+    for (int c = c0; c < c0 + cg; ++c) { S += red[2 * c]; Q += red[2 * c + 1]; }
+    float* dst = gpartial + (((long)b * nchunk + chunk) * G + threadIdx.x) * 2;
+    dst[0] = S; dst[1] = Q;
+  }
+}
+
+// sum the nchunk group partials of sample b: every thread group (g = tid % G, lane kl = tid / G) takes chunks
+// kl, kl + KL, ...; result per group in tot[g][0..1] (double), valid after the trailing barrier
+__device__ __forceinline__ void gn_group_totals(const float* __restrict__ gpartial, int b, int nchunk, int G,
+                                                double (*part)[64][2], double (*tot)[2]) {
+  const int tid = threadIdx.x;
+  int KL = blockDim.x / G; if (KL > 8) KL = 8;
+  const int g = tid % G, kl = tid / G;
+  if (kl < KL) {
+    double s = 0, q = 0;
+    for (int k = kl; k < nchunk; k += KL) {
+      const float2 p = *reinterpret_cast<const float2*>(gpartial + (((long)b * nchunk + k) * G + g) * 2);
+      s += p.x; q += p.y;
+    }
+    part[kl][g][0] = s; part[kl][g][1] = q;
+  }
+  __syncthreads();
+  if (tid < G) {
+    double s = 0, q = 0;
+    for (int k = 0; k < KL; ++k) { s += part[k][tid][0]; q += part[k][tid][1]; }
+    tot[tid][0] = s; tot[tid][1] = q;
+  }
+  __syncthreads();
+}
+
+template <typename T, bool SILU>
+__global__ void gn_gapply_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy, int HW, int C, int G,
+                                 int VX, int PY, int ppc, int nchunk, float eps, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, const float* __restrict__ gpartial,
+                                 float* __restrict__ stats /*[B][G][2]*/) {
+  __shared__ double part[8][64][2];
+  __shared__ double tot[64][2];
+  const int b = blockIdx.y, chunk = blockIdx.x, cg = C / G;
+  gn_group_totals(gpartial, b, nchunk, G, part, tot);
+  if ((int)threadIdx.x < G) {
+    const double n = (double)HW * cg;
+    const double mean = tot[threadIdx.x][0] / n;
+    double var = tot[threadIdx.x][1] / n - mean * mean;
+    if (var < 0) var = 0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    tot[threadIdx.x][0] = mean; tot[threadIdx.x][1] = rstd;
+    if (chunk == 0) {
+      stats[((long)b * G + threadIdx.x) * 2] = (float)mean;
+      stats[((long)b * G + threadIdx.x) * 2 + 1] = (float)rstd;
+    }
+  }
+  __syncthreads();
+  const int vx = threadIdx.x % VX, py = threadIdx.x / VX;
+  const int p0 = chunk * ppc, p1 = min(HW, p0 + ppc);
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = vx * 8 + e, gi = c / cg;
+    const double scd = tot[gi][1] * (double)gamma[c];
+    sc[e] = (float)scd;
+    sh[e] = (float)((double)beta[c] - tot[gi][0] * scd);
+  }
+  for (int p = p0 + py; p < p1; p += PY) {
+    float f[8];
+    const long row = (long)b * HW + p;
+    load8(x + row * ldx + vx * 8, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float z = f[e] * sc[e] + sh[e];
+      f[e] = SILU ? silu_f(z) : z;
+    }
+    store8(y + row * ldy + vx * 8, f);
+  }
+}
+
+int g_gn_three_pass = 0;   // A/B hook: 1 = always the partial -> finalize -> apply form
+
+static bool gn_two_pass_ok(const GnGeom& g, int C, int G) {
+  return !g_gn_three_pass && C / 8 == g.VX && G <= 64 && g.threads >= G && g.threads >= 64;
+}
+
 template <typename T>
 static int gn_fwd_t(const GnArgs& a, hipStream_t st) {
   const GnGeom g = gn_geom(a.B, a.HW, a.C);
+  if (gn_two_pass_ok(g, a.C, a.G)) {
+    dim3 grid(g.nchunk, a.B);
+    const int lds = std::max(g.threads * 64, a.C * 8);
+    hipLaunchKernelGGL((gn_gpartial_kernel<T>), grid, dim3(g.threads), lds, st, (const T*)a.x, a.ldx, a.HW, a.C, a.G,
+                       g.VX, g.PY, g.ppc, g.nchunk, a.ws);
+    if (a.silu)
+      hipLaunchKernelGGL((gn_gapply_kernel<T, true>), grid, dim3(g.threads), 0, st, (const T*)a.x, a.ldx, (T*)a.y, a.ldy,
+                         a.HW, a.C, a.G, g.VX, g.PY, g.ppc, g.nchunk, a.eps, a.gamma, a.beta, a.ws, a.stats);
+    else
+      hipLaunchKernelGGL((gn_gapply_kernel<T, false>), grid, dim3(g.threads), 0, st, (const T*)a.x, a.ldx, (T*)a.y, a.ldy,
+                         a.HW, a.C, a.G, g.VX, g.PY, g.ppc, g.nchunk, a.eps, a.gamma, a.beta, a.ws, a.stats);
+    CL_CHECK_LAUNCH();
+    return CL_OK;
+  }
   float* partial = a.ws;
   float* coef = a.ws + (long)a.B * g.nchunk * a.C * 2;
   dim3 grid(g.nchunk, a.B);
@@ -316,9 +456,127 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, long ldx, const T* 
   }
 }
 
+// two-launch backward for FROZEN norms (no dgamma / dbeta): the statistics pass forms the gamma-weighted group sums
+// s1 = sum_c gamma_c sum dz, s2 = sum_c gamma_c sum dz xhat of its chunk; the apply pass totals them itself.
+template <typename T, bool SILU>
+__global__ void gn_bwd_gpartial_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy, long lddy, int HW,
+                                       int C, int G, int VX, int PY, int ppc, int nchunk,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       const float* __restrict__ stats, float* __restrict__ gpartial) {
+  extern __shared__ float red[];
+  const int cg = C / G;
+  const int vx = threadIdx.x % VX, py = threadIdx.x / VX;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int p0 = chunk * ppc, p1 = min(HW, p0 + ppc);
+  float ga[8], be[8], mu[8], rs[8], s[8], q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = vx * 8 + e, gi = c / cg;
+    ga[e] = gamma[c]; be[e] = beta[c];
+    mu[e] = stats[((long)b * G + gi) * 2]; rs[e] = stats[((long)b * G + gi) * 2 + 1];
+    s[e] = 0.f; q[e] = 0.f;
+  }
+  for (int p = p0 + py; p < p1; p += PY) {
+    float f[8], d[8];
+    const long row = (long)b * HW + p;
+    load8(x + row * ldx + vx * 8, f);
+    load8(dy + row * lddy + vx * 8, d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xh = (f[e] - mu[e]) * rs[e];
+      float dz = d[e];
+      if (SILU) dz *= dsilu_f(xh * ga[e] + be[e]);
+      s[e] += dz; q[e] += dz * xh;
+    }
+  }
+  float* r = red + (py * VX + vx) * 16;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { r[e] = s[e]; r[8 + e] = q[e]; }
+  __syncthreads();
+  if (py == 0) {
+    for (int k = 1; k < PY; ++k) {
+      const float* o = red + (k * VX + vx) * 16;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] += o[e]; q[e] += o[8 + e]; }
+    }
+  }
+  __syncthreads();
+  if (py == 0) {
+    float* ch = red + vx * 16;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ch[2 * e] = ga[e] * s[e]; ch[2 * e + 1] = ga[e] * q[e]; }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < G) {
+    const int c0 = threadIdx.x * cg;
+    float S = 0.f, Q = 0.f;
+    for (int c = c0; c < c0 + cg; ++c) { S += red[2 * c]; Q += red[2 * c + 1]; }
+    float* dst = gpartial + (((long)b * nchunk + chunk) * G + threadIdx.x) * 2;
+    dst[0] = S; dst[1] = Q;
+  }
+}
+
+template <typename T, bool SILU>
+__global__ void gn_bwd_gapply_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy, long lddy,
+                                     const T* __restrict__ accum, long ldacc, T* __restrict__ dx, long lddx, int HW,
+                                     int C, int G, int VX, int PY, int ppc, int nchunk, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, const float* __restrict__ stats,
+                                     const float* __restrict__ gpartial) {
+  __shared__ double part[8][64][2];
+  __shared__ double tot[64][2];
+  const int b = blockIdx.y, chunk = blockIdx.x, cg = C / G;
+  gn_group_totals(gpartial, b, nchunk, G, part, tot);
+  const double n = (double)HW * cg;
+  const int vx = threadIdx.x % VX, py = threadIdx.x / VX;
+  const int p0 = chunk * ppc, p1 = min(HW, p0 + ppc);
+  float ga[8], be[8], mu[8], rs[8], k1[8], k2[8], k3[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = vx * 8 + e, gi = c / cg;
+    ga[e] = gamma[c]; be[e] = beta[c];
+    mu[e] = stats[((long)b * G + gi) * 2]; rs[e] = stats[((long)b * G + gi) * 2 + 1];
+    const double rstd = rs[e];
+    k1[e] = (float)(rstd * ga[e]);
+    k2[e] = (float)(rstd * tot[gi][0] / n);
+    k3[e] = (float)(rstd * tot[gi][1] / n);
+  }
+  for (int p = p0 + py; p < p1; p += PY) {
+    float f[8], d[8], ac[8];
+    const long row = (long)b * HW + p;
+    load8(x + row * ldx + vx * 8, f);
+    load8(dy + row * lddy + vx * 8, d);
+    if (accum) load8(accum + row * ldacc + vx * 8, ac);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xh = (f[e] - mu[e]) * rs[e];
+      float dz = d[e];
+      if (SILU) dz *= dsilu_f(xh * ga[e] + be[e]);
+      float r = dz * k1[e] - k2[e] - xh * k3[e];
+      if (accum) r += ac[e];
+      f[e] = r;
+    }
+    store8(dx + row * lddx + vx * 8, f);
+  }
+}
+
 template <typename T>
 static int gn_bwd_t(const GnBwdArgs& a, hipStream_t st) {
   const GnGeom g = gn_geom(a.B, a.HW, a.C);
+  if (!a.dgamma && gn_two_pass_ok(g, a.C, a.G)) {
+    dim3 grid(g.nchunk, a.B);
+    const int lds = std::max(g.threads * 64, a.C * 8);
+#define GN_BWD_G(S)                                                                                                \
+    hipLaunchKernelGGL((gn_bwd_gpartial_kernel<T, S>), grid, dim3(g.threads), lds, st, (const T*)a.x, a.ldx,        \
+                       (const T*)a.dy, a.lddy, a.HW, a.C, a.G, g.VX, g.PY, g.ppc, g.nchunk, a.gamma, a.beta, a.stats, \
+                       a.ws);                                                                                       \
+    hipLaunchKernelGGL((gn_bwd_gapply_kernel<T, S>), grid, dim3(g.threads), 0, st, (const T*)a.x, a.ldx,            \
+                       (const T*)a.dy, a.lddy, (const T*)a.accum, a.ldacc, (T*)a.dx, a.lddx, a.HW, a.C, a.G, g.VX,  \
+                       g.PY, g.ppc, g.nchunk, a.gamma, a.beta, a.stats, a.ws);
+    if (a.silu) { GN_BWD_G(true) } else { GN_BWD_G(false) }
+#undef GN_BWD_G
+    CL_CHECK_LAUNCH();
+    return CL_OK;
+  }
   float* partial = a.ws;
   float* bcoef = a.ws + (long)a.B * g.nchunk * a.C * 2;
   dim3 grid(g.nchunk, a.B);

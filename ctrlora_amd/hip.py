@@ -130,6 +130,8 @@ def lib():
         _lib = L
         if os.environ.get("CTRLORA_ATTN_FUSE_DELTA", "1") == "0":      # A/B switch: separate attn_delta launch
             L.cl_attention_force_variant(16)
+        if os.environ.get("CTRLORA_GN_THREE_PASS", "0") == "1":       # A/B switch: GroupNorm with the finalize launch
+            L.cl_attention_force_variant(32)
         if os.environ.get("CTRLORA_GEMM_TUNED", "1") != "0":
             load_gemm_table(os.environ.get("CTRLORA_GEMM_TABLE", GEMM_TABLE_PATH))
     return _lib
