@@ -396,7 +396,8 @@ def main():
                        "global_batch": world * B, "parallelism": f"dp{world}", "lora_rank": args.rank_lora,
                        "launch": "eager" if args.no_graph else ("hipGraph replay" if graphed is None or graphed.mode == "one" else
                                                                  f"hipGraph replay, {len(graphed.segments)} backward segments with the "
-                                                                 "LoRA-gradient all-reduce of each bucket overlapping the next segment")},
+                                                                 "LoRA-gradient all-reduce of each bucket overlapping the next segment"),
+                       "gemm_launch_table_entries": int(__import__("ctrlora_amd.hip", fromlist=["lib"]).lib().cl_gemm_tune_size())},
             "loss": round(final_loss, 5),
         }
         achieved = tf_img * ips / world          # per-GPU TFLOP/s

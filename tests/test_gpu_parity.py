@@ -443,7 +443,7 @@ def test_graphed_train_step_matches_eager_steps():
 
     def make():
         m = bench.build_model("ctrlora_finetune_sd15_rank128.yaml", 0, tiny=True).cuda().train()
-        m.set_engine_dtype(torch.float32)
+        m.set_engine_dtype(dtype)      # bf16: the weight-gradient groups ride the side stream across the segment cuts
         m.learning_rate = 1e-3
         return m, m.configure_optimizers()
 
@@ -537,8 +537,9 @@ def test_graphed_ddim_with_image_hint_resamples_the_posterior_on_the_device():
         assert not torch.equal(a, b)
 
 
-@pytest.mark.parametrize("capture_error_mode", [None, "thread_local"])
-def test_segmented_graph_step_hands_out_every_gradient_slice_once_and_matches_eager(capture_error_mode):
+@pytest.mark.parametrize("capture_error_mode,dtype", [(None, torch.float32), ("thread_local", torch.float32),
+                                                      ("thread_local", torch.bfloat16)])
+def test_segmented_graph_step_hands_out_every_gradient_slice_once_and_matches_eager(capture_error_mode, dtype):
     """Data-parallel form of GraphedTrainStep on ONE GPU: the backward is captured as segment graphs that end where a
     gradient bucket is complete; between replays the bucket's slice of the flat gradient buffer is handed to the
     reduction (here a recording stand-in for the RCCL all-reduce).  Every element must be handed out exactly once,
@@ -586,7 +587,8 @@ def test_segmented_graph_step_hands_out_every_gradient_slice_once_and_matches_ea
     assert all(a[1] == b[0] for a, b in zip(spans, spans[1:])), spans        # contiguous, no overlap, no gap
     assert handed == spans                                                   # handed out in backward-completion order
     l3 = float(g(cu(inp["z"]), cu(inp["ctx"]), cu(inp["hint_z"]), cu(inp["t"]), cu(inp["noise"])))
-    assert abs(l2 - losses[1]) < 1e-4 * abs(losses[1]) and abs(l3 - losses[2]) < 1e-4 * abs(losses[2])
+    tol = 1e-4 if dtype == torch.float32 else 2e-3
+    assert abs(l2 - losses[1]) < tol * abs(losses[1]) and abs(l3 - losses[2]) < tol * abs(losses[2])
 
 
 def test_dp_virtual_ranks_equal_one_large_batch_on_the_engine():
