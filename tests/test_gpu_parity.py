@@ -443,7 +443,7 @@ def test_graphed_train_step_matches_eager_steps():
 
     def make():
         m = bench.build_model("ctrlora_finetune_sd15_rank128.yaml", 0, tiny=True).cuda().train()
-        m.set_engine_dtype(dtype)      # bf16: the weight-gradient groups ride the side stream across the segment cuts
+        m.set_engine_dtype(torch.float32)
         m.learning_rate = 1e-3
         return m, m.configure_optimizers()
 
@@ -554,7 +554,7 @@ def test_segmented_graph_step_hands_out_every_gradient_slice_once_and_matches_ea
 
     def make():
         m = bench.build_model("ctrlora_finetune_sd15_rank128.yaml", 0, tiny=True).cuda().train()
-        m.set_engine_dtype(torch.float32)
+        m.set_engine_dtype(dtype)      # bf16: the weight-gradient groups ride the side stream across the segment cuts
         m.learning_rate = 1e-3
         return m, m.configure_optimizers()
 
