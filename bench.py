@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 TRAIN_TFLOP_PER_IMAGE = {32: 1.913, 64: 1.941, 128: 1.996, 256: 2.11, 512: 2.33}
 DDIM_TFLOP_PER_STEP_IMAGE = 2.207
+PEAK_HBM_TBS = 8.0          # TB/s, MI355X_MICROARCH.md
 PEAK_BF16_TFLOPS = 2500.0
 
 
@@ -122,8 +123,17 @@ def family_census(model, opt, data, reps=10):
         key = (mode, M, N, k1, k2, kw.get("conv"), kw.get("residual") is not None, bool(kw.get("out_f32", False)),
                kw.get("act", 0))
         if not kw.get("atomic", False):
-            fl = 2.0 * M * N * ((1 if mode == hip.LINEAR else 9) * k1 + k2)
-            e = calls["gemm"].setdefault(key, [0, fl, lambda: o_gemm(a1, w1, out, **kw)])
+            taps = 1 if mode == hip.LINEAR else 9
+            fl = 2.0 * M * N * (taps * k1 + k2)
+            # algorithmic HBM bytes of the launch: operands once (a conv reads its input tensor once), result once
+            esz = a1.element_size()
+            conv = kw.get("conv")
+            a_rows = M if conv is None else conv[0] * conv[1] * conv[2]
+            n_out = N // 2 if kw.get("act", 0) == hip.ACT_GEGLU else N
+            by = esz * (a_rows * k1 + M * k2 + N * (taps * k1 + k2)) + M * n_out * (4 if kw.get("out_f32") else esz)
+            if kw.get("residual") is not None:
+                by += M * n_out * esz
+            e = calls["gemm"].setdefault(key, [0, fl, lambda: o_gemm(a1, w1, out, **kw), by])
             e[0] += 1
         return o_gemm(a1, w1, out, **kw)
 
@@ -151,8 +161,9 @@ def family_census(model, opt, data, reps=10):
         hip.gemm, hip.attention_fwd_v2, hip.attention_bwd_v2 = o_gemm, o_af, o_ab
     out = {}
     for fam, tab in calls.items():
-        tot_us, tot_fl, n = 0.0, 0.0, 0
-        for key, (cnt, fl, run) in tab.items():
+        tot_us, tot_fl, n, ideal_us, mem_us = 0.0, 0.0, 0, 0.0, 0.0
+        for key, ent in tab.items():
+            cnt, fl, run = ent[:3]
             for _ in range(2):
                 run()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -163,11 +174,21 @@ def family_census(model, opt, data, reps=10):
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / reps
             tot_us += us * cnt; tot_fl += fl * cnt; n += cnt
+            t_mfma = fl / (PEAK_BF16_TFLOPS * 1e6)                      # us at the dense bf16 MFMA peak
+            t_hbm = (ent[3] / (PEAK_HBM_TBS * 1e6)) if len(ent) > 3 else 0.0   # us at the HBM peak
+            ideal_us += max(t_mfma, t_hbm) * cnt
+            if t_hbm > t_mfma:
+                mem_us += us * cnt
         if tot_us > 0:
             tf = tot_fl / tot_us * 1e-6
             out[fam] = dict(achieved=round(tf, 1), frac=round(tf / PEAK_BF16_TFLOPS, 4), unit="TFLOP/s",
                             ms_per_step=round(tot_us * 1e-3, 2), launches_per_step=n, unique_shapes=len(tab),
                             gflop_per_step=round(tot_fl * 1e-9, 1))
+            if fam == "gemm":
+                # every launch against ITS OWN roofline, max(FLOPs / MFMA peak, algorithmic bytes / HBM peak): the K = 320
+                # products of the 64x64 level are below the machine balance (160 FLOP/B against 312) and HBM-bound
+                out[fam]["frac_of_shape_rooflines"] = round(ideal_us / tot_us, 4)
+                out[fam]["hbm_bound_share_of_time"] = round(mem_us / tot_us, 4)
     return out
 
 

@@ -896,8 +896,16 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p
 // small-K products (K = 320: five stages per tile) those fixed costs are several times the tile's MFMA time.
 template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int R, int PRIO = 0>
 __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_persist_kernel(GemmParams p, int tiles_m, int tiles_n,
-                                                                         float* __restrict__ slab, int nvirt) {
+                                                                         float* __restrict__ slab, int nvirt,
+                                                                         int stagger) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // Equal tiles keep all workgroups in the same phase (everybody loads, then everybody stores).  `stagger` > 0 holds
+  // the second half of the grid (with two workgroups per CU: the second resident of every CU) back by that many
+  // s_memtime ticks once, so that one resident's stores run under the other's loads from then on.
+  if (stagger > 0 && blockIdx.x >= gridDim.x / 2) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)stagger) __builtin_amdgcn_s_sleep(8);
+  }
   for (int v = blockIdx.x; v < nvirt; v += gridDim.x) {
     fl_tile<T, BM, BN, WGM, WGN, MODE, R, PRIO>(p, tiles_m, tiles_n, slab, v, smem);
     __syncthreads();   // the epilogue staging aliases the operand ring of the next tile
@@ -1086,7 +1094,7 @@ static int launch_fl_mode(const GemmParams& p0, hipStream_t stream) {
     if (grid < nvirt) grid -= grid % 8;
     if (grid < 1) grid = nvirt;
     hipLaunchKernelGGL((gemm_fl_persist_kernel<T, BM, BN, WGM, WGN, MODE, R, PRIO>), dim3((unsigned)grid), dim3(NW * 64),
-                       SMEM, stream, p, tm, tn, slab, (int)nvirt);
+                       SMEM, stream, p, tm, tn, slab, (int)nvirt, (SMEM <= 80 * 1024 && grid == 2L * device_cus() && nvirt >= 2 * grid) ? g_fl_persist_stagger : 0);
   } else {
     hipLaunchKernelGGL((gemm_fl_kernel<T, BM, BN, WGM, WGN, MODE, R, PRIO>), dim3((unsigned)nvirt), dim3(NW * 64), SMEM,
                        stream, p, tm, tn, slab);
@@ -1113,6 +1121,7 @@ int g_gemm_force_cfg = -1;   // probe / tuning hook: >= 0 forces a tile configur
 int g_fl128_split_want = 128;   // 128-row full-line tiles: split K while the grid is below this many workgroups
 int g_tiny_m_minsub = 8;        // fallback kernel, M <= 64: minimum 64-byte substeps per K split
 
+int g_fl_persist_stagger = 0;   // probe hook: s_memtime ticks the second resident workgroup of a CU starts late (persistent 2-per-CU forms)
 int g_gemm_force_splitk = 0;    // tuning hook: > 0 imposes the split-K factor (workspace path), 0 = launcher's rule
 
 // Measured launch table (tools/gemm_autotune.py on an MI355X -> ctrlora_amd/gemm_tuned_gfx950.json, loaded by the host

@@ -395,6 +395,22 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  if (argc > 1 && !strcmp(argv[1], "--stagger")) {   // two workgroups per CU, the second one held back once
+    for (int st : {0, 4000, 8000, 12000, 16000, 24000, 0}) {
+      g_fl_persist_stagger = st;
+      printf("---- stagger %d ticks\n", st);
+      persist_case("131072x2560x320 GEGLU (DDIM)", 131072, 2560, 320, 0, ACT_GEGLU, 10, 29, false);
+      persist_case("131072x320x320 (DDIM)", 131072, 320, 320, 0, 0, 10, 29, false);
+      persist_case("131072x960x320 (DDIM qkv)", 131072, 960, 320, 0, 0, 10, 29, false);
+      persist_case("131072x320x1280", 131072, 320, 1280, 0, 0, 10, 29, false);
+      persist_case("32768x2560x320 (FF proj)", 32768, 2560, 320, 0, 0, 10, 29, false);
+      persist_case("32768x960x320", 32768, 960, 320, 0, 0, 10, 29, false);
+      persist_case("131072x128x320 (LoRA down)", 131072, 128, 320, 0, 0, 11, 30, false);
+    }
+    g_fl_persist_stagger = 0;
+    printf("probe_gemm --stagger: %s (%d failures)\n", g_fail ? "FAILED" : "ALL PASS", g_fail);
+    return g_fail ? 1 : 0;
+  }
   if (argc > 1 && !strcmp(argv[1], "--persist")) {
     const int pairs[][2] = {{16, 25}, {20, 27}, {10, 29}};
     for (auto& pr : pairs) {
