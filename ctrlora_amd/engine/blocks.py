@@ -299,10 +299,13 @@ class ResBlockE:
         self.conv1, self.conv2, self.emb, self.skip = conv1, conv2, emb, skip
         self.cin, self.cout = conv1.I, conv1.O
 
-    def fwd(self, ctx: Ctx, x, semb, B, H, W, out=None):
+    def fwd(self, ctx: Ctx, x, semb, B, H, W, out=None, e_pre=None):
         HW = H * W
         h1, st1 = self.gn1.fwd(ctx, x, B, HW)
-        e_out, t_e = linear_fwd(ctx, self.emb, semb)                      # [B, cout]
+        if e_pre is not None:                                             # frozen UNet: formed with all the others
+            e_out, t_e = e_pre, None
+        else:
+            e_out, t_e = linear_fwd(ctx, self.emb, semb)                  # [B, cout]
         h2 = conv3_fwd(ctx, self.conv1, h1, B, H, W, rowbias=e_out)       # + bias + emb (openaimodel.py:272)
         keep = ctx.record and self.conv1.tW is not None                   # conv inputs: operands of the conv dW
         if not keep:

@@ -149,7 +149,7 @@ class CtrLoRAEngine:
                              kv=None if kvs is None else kvs["cn"][i])
                 cn_recs.append((rec, weights[i]))
         del hs
-        eps_tok, dec_rec = self.unet.decode(ctx, bufs, semb, c, B, dims[-1])
+        eps_tok, dec_rec = self.unet.decode(ctx, bufs, semb, c, B, dims[-1], kv=None if kvs is None else kvs["unet"])
         eps = torch.empty((B, self.cfg.out_channels, H, W), dtype=torch.float32, device=self.device)
         hip.tok_to_nchw(eps_tok, eps)
         if record:

@@ -172,22 +172,28 @@ class _Builder:
 
 class _Env:
     """Mutable per-pass state threaded through the layers."""
-    __slots__ = ("B", "H", "W", "semb", "c", "Nkv", "dsemb", "emb_grads", "kv")
+    __slots__ = ("B", "H", "W", "semb", "c", "Nkv", "dsemb", "emb_grads", "kv", "emb_all", "kv_all")
 
     def __init__(self, B, H, W, semb, c, Nkv):
         self.B, self.H, self.W, self.semb, self.c, self.Nkv = B, H, W, semb, c, Nkv
         self.dsemb = None
         self.emb_grads = False
         self.kv = None
+        self.emb_all = None      # frozen UNet: every ResBlock's emb_layers output, one product [B, sum cout]
+        self.kv_all = None       # frozen UNet: every cross-attention's K / V of the context, one product
 
 
 class _Res:
     def __init__(self, blk: ResBlockE):
         self.blk = blk
         self.cout = blk.cout
+        self.emb_off = None      # column offset into _Env.emb_all (frozen UNet only)
 
     def fwd(self, ctx, x, env, out=None):
-        return self.blk.fwd(ctx, x, env.semb, env.B, env.H, env.W, out=out)
+        pre = None
+        if env.emb_all is not None and self.emb_off is not None:
+            pre = env.emb_all[:, self.emb_off:self.emb_off + self.cout]
+        return self.blk.fwd(ctx, x, env.semb, env.B, env.H, env.W, out=out, e_pre=pre)
 
     def bwd(self, ctx, dy, saved, env, out=None):
         return self.blk.bwd(ctx, dy, saved, env.B, env.H, env.W, dsemb=env.dsemb, need_emb_grads=env.emb_grads,
@@ -198,6 +204,7 @@ class _ST:
     def __init__(self, blk: SpatialTransformerE, key: str):
         self.blk, self.key = blk, key
         self.cout = blk.C
+        self.kv_off = None       # column offset into _Env.kv_all (frozen UNet only)
 
     def fwd(self, ctx, x, env, out=None):
         cache = None
@@ -206,6 +213,10 @@ class _ST:
             if cache is None:
                 cache = self.blk.attn2.project_context(ctx, env.c)
                 env.kv[self.key] = cache
+        elif env.kv_all is not None and self.kv_off is not None:
+            inner = self.blk.attn2.inner
+            cache = (env.kv_all[:, self.kv_off:self.kv_off + inner],
+                     env.kv_all[:, self.kv_off + inner:self.kv_off + 2 * inner], None, None)
         return self.blk.fwd(ctx, x, env.c, env.B, env.H, env.W, env.Nkv, out=out, kv_cache=cache)
 
     def bwd(self, ctx, dy, saved, env, out=None):
@@ -565,6 +576,34 @@ class UNetE:
         self.out_conv = b.conv3("out.2")
         from .blocks import GroupNormOp
         self.out_gn = GroupNormOp(self.out_norm, 1e-5, True)
+        # The 22 emb_layers products (M = batch) and the 16 context K / V products (M = 77 * batch) of the frozen UNet
+        # depend on nothing but silu(emb) / the text context: ONE product each at the start of the pass instead of 38
+        # launches that cost their ~8 us launch floor apiece.  Row slices of the concatenated weights are the layers'.
+        layers = [l for blk in list(self.blocks) + [self.mid] + list(self.dec) for l in blk]
+        self._res = [l for l in layers if isinstance(l, _Res)]
+        self._sts = [l for l in layers if isinstance(l, _ST) and l.blk.attn2.fused_kv is not None]
+        self.emb_all = self.kv_all_w = None
+        if os.environ.get("CTRLORA_BATCH_EMB", "1") != "0" and self._res:
+            off = 0
+            for l in self._res:
+                l.emb_off = off; off += l.cout
+            self.emb_all = LinearW(torch.cat([l.blk.emb.W.float() for l in self._res], 0),
+                                   torch.cat([l.blk.emb.bias for l in self._res], 0), dtype, device, need_bwd=False)
+            if self._sts:
+                off = 0
+                for l in self._sts:
+                    l.kv_off = off; off += 2 * l.blk.attn2.inner
+                fk = [l.blk.attn2.fused_kv for l in self._sts]
+                bias = None if fk[0].bias is None else torch.cat([f.bias for f in fk], 0)
+                self.kv_all_w = LinearW(torch.cat([f.W.float() for f in fk], 0), bias, dtype, device, need_bwd=False)
+        self._pre = None         # (semb, emb_all output, c, kv_all output) of the running pass: encode -> decode
+
+    def _precompute(self, ctx: Ctx, env: _Env, with_kv: bool):
+        if self.emb_all is not None:
+            env.emb_all, _ = linear_fwd(ctx, self.emb_all, env.semb)
+        if with_kv and self.kv_all_w is not None:
+            env.kv_all, _ = linear_fwd(ctx, self.kv_all_w, env.c)
+        self._pre = (env.semb, env.emb_all, env.c, env.kv_all)
 
     # -- encoder + middle (never needs gradients: cldm/cldm.py:25-32 runs it under no_grad)
     def encode(self, ctx: Ctx, x_tok, t, c, B, H, W, kv=None):
@@ -573,6 +612,7 @@ class UNetE:
         semb, _ = self.time.fwd(ctx, t)
         env = _Env(B, H, W, semb, c, c.shape[0] // B)
         env.kv = kv
+        self._precompute(ctx, env, with_kv=kv is None)
         hs, dims = [], []
         h = x_tok
         for layers in self.blocks:
@@ -608,8 +648,13 @@ class UNetE:
             hip.axpby(hs[k], bufs[i][:, self.dec_c1[i]:], 1.0, 0.0)
         hip.axpby(h_mid, bufs[0][:, :self.dec_c1[0]], 1.0, 0.0)
 
-    def decode(self, ctx: Ctx, bufs, semb, c, B, dims_mid):
+    def decode(self, ctx: Ctx, bufs, semb, c, B, dims_mid, kv=None):
         env = _Env(B, dims_mid[0], dims_mid[1], semb, c, c.shape[0] // B)
+        env.kv = kv
+        pre = self._pre
+        if pre is not None and pre[0] is semb and pre[2] is c:      # the batched products of THIS pass (encode made them)
+            env.emb_all, env.kv_all = pre[1], pre[3]
+        self._pre = None
         saved = []
         nd = len(self.dec)
         h = None
