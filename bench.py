@@ -249,6 +249,45 @@ def ddim_bench(device, dtype, B=16, S=50, tiny=False, loops=5):
                      "its own graph capture; hint latent given (VAE encode hoisted out of the loop); cond+uncond batched")
 
 
+def pretrain_bench(device, dtype, B=8, steps=9, warmup=9, tiny=False):
+    """BASELINE.json configs[3] on ONE GPU (not the headline metric; evidence that Base-ControlNet pre-training runs at
+    full width): ctrlora_pretrain_sd15_9tasks_rank128.yaml, every ControlNet weight + the step's task bank trained,
+    the task changes every step as BatchSchedulerSampler makes it (datasets/multi_task_scheduler.py), eager launches
+    (the bank switch re-packs that bank's LoRA copies between steps), PretrainAdamW with the reference's torch 1.13
+    zero_grad semantics.  Synthetic latents, random-init weights, latent hint."""
+    model = build_model("ctrlora_pretrain_sd15_9tasks_rank128.yaml", 0, tiny=tiny).to(device).train()
+    model.set_engine_dtype(dtype)
+    model.learning_rate = 1e-5
+    opt = model.configure_optimizers()
+    tasks = list(model.control_model.tasks)
+    data = synth(B, 64, model.control_model.context_dim, device, 4321, 2)
+
+    def step(i):
+        j = i % 2
+        cond = {"c_crossattn": [data["ctx"][j]], "c_concat": [data["hint"][j]], "task": tasks[i % len(tasks)]}
+        opt.zero_grad()
+        loss, _ = model.p_losses(data["z"][j], cond, data["t"][j], noise=data["noise"][j])
+        loss.backward()
+        opt.step()
+        return loss
+
+    for i in range(warmup):              # every bank gets its first gradient: from here on all nine are live
+        loss = step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = step(warmup + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert torch.isfinite(loss)
+    ntrain = sum(p.numel() for p in model.control_model.parameters())
+    return dict(metric="Base-ControlNet multi-task pre-training images/sec (1 GPU, eager)", value=round(B / dt, 2),
+                unit="images/s", ms_per_step=round(dt * 1e3, 2), batch=B, tasks=len(tasks), steps=steps, warmup=warmup,
+                trainable_params_M=round(ntrain / 1e6, 1), loss=round(float(loss), 5),
+                peak_mem_GB=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), dtype=str(dtype).replace("torch.", ""),
+                config="ctrlora_pretrain_sd15_9tasks_rank128.yaml, 512x512 (latent 64x64), task round-robin, synthetic")
+
+
 def cpu_baseline(rank_lora=32, threads=32):
     """The oracle (CPU restatement of the reference modules, oracle/ref_model.py) on the host cores, TIMED, not
     extrapolated: ONE genuine optimizer step of BASELINE.json configs[0] -- ctrlora_finetune_sd15_rank32, bs = 1,
@@ -325,6 +364,8 @@ def main():
     ap.add_argument("--probe-only", action="store_true",
                     help="profiling aid: run only the dominant-kernel probe (the rocprofv3 --stats summary of this "
                          "command, profiles/r01_dominant_kernel_stats.csv, is what roofline.ms_per_launch is checked against)")
+    ap.add_argument("--pretrain-only", action="store_true",
+                    help="evidence run, not the headline: one-GPU Base-ControlNet pre-training steps (BASELINE configs[3])")
     ap.add_argument("--tiny", action="store_true", help="debug: narrow model")
     args = ap.parse_args()
 
@@ -343,6 +384,9 @@ def main():
         return
     if args.probe_only:
         print(json.dumps(conv_kernel_probe(device, dtype, iters=200)))
+        return
+    if args.pretrain_only:
+        print(json.dumps(pretrain_bench(device, dtype, B=args.batch, tiny=args.tiny)))
         return
 
     model = build_model(f"ctrlora_finetune_sd15_rank{args.rank_lora}.yaml", 0, tiny=args.tiny).to(device).train()
