@@ -283,7 +283,7 @@ def pretrain_bench(device, dtype, B=8, steps=9, warmup=9, tiny=False):
     ntrain = sum(p.numel() for p in model.control_model.parameters())
     return dict(metric="Base-ControlNet multi-task pre-training images/sec (1 GPU, eager)", value=round(B / dt, 2),
                 unit="images/s", ms_per_step=round(dt * 1e3, 2), batch=B, tasks=len(tasks), steps=steps, warmup=warmup,
-                trainable_params_M=round(ntrain / 1e6, 1), loss=round(float(loss), 5),
+                trainable_params_M=round(ntrain / 1e6, 1), loss=round(float(loss.detach()), 5),
                 peak_mem_GB=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), dtype=str(dtype).replace("torch.", ""),
                 config="ctrlora_pretrain_sd15_9tasks_rank128.yaml, 512x512 (latent 64x64), task round-robin, synthetic")
 
