@@ -400,21 +400,29 @@ class GraphedTrainStep:
         self.s_z.copy_(z); self.s_ctx.copy_(cond_txt); self.s_hint.copy_(hint)
         self.s_t.copy_(t); self.s_noise.copy_(noise)
         self.opt.sync_hyper()
-        execs = self.opt.executors
-        works = []
-        for g, tag, lo, hi in self.segments:
-            g.replay()
-            if tag is None:
-                continue
-            if tag == "all":
-                works += [self._reduce_fn(ex.tr.flat_grad) for ex in execs]
-            elif tag == "tails":
-                works += [self._reduce_fn(execs[i].tr.flat_grad[a:b]) for i, a, b in lo]
-            else:
-                works.append(self._reduce_fn(execs[tag].tr.flat_grad[lo:hi]))   # overlaps the next segment's replay
-        for w in works:
-            if w is not None:
-                w.wait()
-        if self.g_b is not None:
-            self.g_b.replay()
+        replay_with_exchange(self.segments, self.g_b, self.opt.executors, self._reduce_fn)
         return self.loss
+
+
+def replay_with_exchange(segments, g_opt, execs, reduce_fn):
+    """One optimizer step from captured pieces (anything with .replay()): every segment is enqueued, and right after
+    a segment that completes a gradient bucket the reduction of that slice of the flat buffer is issued
+    (`reduce_fn(slice)` -> handle with .wait() or None) -- it runs while the NEXT segment executes; all handles are waited for
+    before the optimizer piece.  segments: [(graph, tag, lo, hi)], tag None = nothing to exchange, "all" = every executor's
+    whole buffer, "tails" = lo is [(executor index, start, stop)], an int = that executor's [lo, hi) slice."""
+    works = []
+    for g, tag, lo, hi in segments:
+        g.replay()
+        if tag is None:
+            continue
+        if tag == "all":
+            works += [reduce_fn(ex.tr.flat_grad) for ex in execs]
+        elif tag == "tails":
+            works += [reduce_fn(execs[i].tr.flat_grad[a:b]) for i, a, b in lo]
+        else:
+            works.append(reduce_fn(execs[tag].tr.flat_grad[lo:hi]))   # overlaps the next segment's replay
+    for w in works:
+        if w is not None:
+            w.wait()
+    if g_opt is not None:
+        g_opt.replay()

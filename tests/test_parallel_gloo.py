@@ -228,3 +228,84 @@ def test_dp2_equals_single_large_batch_on_the_engine_layout_gloo():
         assert worst < 2e-5, (rank, worst)
         assert launches >= 2
         assert in_sync
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The replay schedule of the segmented training step (ctrlora_amd.train.replay_with_exchange): here the "graphs" are
+# Python callables that write a rank's gradients into its flat buffer, the exchange is the REAL asynchronous
+# torch.distributed all-reduce -- what GraphedTrainStep issues between hipGraph replays on a GPU node.
+
+class _Piece:
+    def __init__(self, fn, log, name):
+        self.fn, self.log, self.name = fn, log, name
+
+    def replay(self):
+        self.log.append(self.name)
+        self.fn()
+
+
+def _segment_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ctrlora_amd.train import replay_with_exchange
+    try:
+        n = 5000
+        cuts = [0, 1200, 3100, n]                       # three backward segments, buckets in completion order
+        exs = [_FakeExecutor(n, rank), _FakeExecutor(777, rank + 10)]
+        for ex in exs:
+            ex.tr.flat_grad.zero_()
+        local = [_TR(n, rank).flat_grad, _TR(777, rank + 10).flat_grad]
+        log, waited = [], []
+
+        def fill(ei, a, b):
+            return lambda: exs[ei].tr.flat_grad[a:b].copy_(local[ei][a:b])
+
+        class _Handle:
+            def __init__(self, w, tag):
+                self.w, self.tag = w, tag
+
+            def wait(self):
+                waited.append(self.tag); self.w.wait()
+
+        def reduce_fn(buf):
+            log.append(("reduce", buf.numel()))
+            return _Handle(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True), buf.numel())
+
+        applied = []
+
+        def opt_piece():                               # the optimizer piece must see fully reduced gradients
+            applied.append([ex.tr.flat_grad.clone() for ex in exs])
+
+        segs = [(_Piece(fill(0, cuts[0], cuts[1]), log, "S0"), 0, cuts[0], cuts[1]),
+                (_Piece(fill(0, cuts[1], cuts[2]), log, "S1"), 0, cuts[1], cuts[2]),
+                (_Piece(lambda: (fill(0, cuts[2], cuts[3])(), fill(1, 0, 777)()), log, "S2"), "tails",
+                 [(0, cuts[2], cuts[3]), (1, 0, 777)], 0)]
+        replay_with_exchange(segs, _Piece(opt_piece, log, "OPT"), exs, reduce_fn)
+        expect = [sum(_TR(n, r).flat_grad for r in range(world)), sum(_TR(777, r + 10).flat_grad for r in range(world))]
+        ok_vals = all(torch.allclose(a, e, atol=1e-6) for a, e in zip(applied[0], expect))
+        # every slice handed out exactly once, each right after the segment that completed it, everything waited for
+        # before the optimizer piece
+        order_ok = log == ["S0", ("reduce", 1200), "S1", ("reduce", 1900), "S2", ("reduce", 1900), ("reduce", 777), "OPT"]
+        q.put((rank, ok_vals, order_ok, sorted(waited) == [777, 1200, 1900, 1900], log))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_segmented_replay_schedule_exchanges_every_bucket_before_the_optimizer_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_segment_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ok_vals, order_ok, all_waited, log in res:
+        assert ok_vals, rank
+        assert order_ok, log
+        assert all_waited
