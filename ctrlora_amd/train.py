@@ -284,9 +284,12 @@ class GraphedTrainStep:
             dp.enabled = False          # no collectives inside the captured regions: this class issues them itself
         # reduce_fn(tensor_slice) -> work handle with .wait() or None; default: RCCL SUM all-reduce, asynchronous
         if reduce_fn is None:
+            from .parallel import all_reduce_slice, payload_dtype_from_env
+            payload = payload_dtype_from_env()       # CTRLORA_DP_PAYLOAD=bf16: half the bytes per bucket
+
             def reduce_fn(buf):
                 if dist.is_initialized() and self.world > 1:
-                    return dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+                    return all_reduce_slice(buf, None, payload)
                 return None
         self._reduce_fn = reduce_fn
 

@@ -309,3 +309,43 @@ def test_segmented_replay_schedule_exchanges_every_bucket_before_the_optimizer_g
         assert ok_vals, rank
         assert order_ok, log
         assert all_waited
+
+
+def _payload_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ctrlora_amd.parallel import GradAllReduce
+    try:
+        n = 4000
+        ex = _FakeExecutor(n, rank)
+        dp = GradAllReduce([ex], bucket_bytes=4 * 1000, payload_dtype=torch.bfloat16)
+        for s, e in [(0, 1500), (1500, 2600), (2600, n)]:
+            ex.on_stage_done(s, e)
+        dp.on_backward_done(); dp.wait()
+        expect = sum(_TR(n, r).flat_grad for r in range(world))
+        err = float((ex.tr.flat_grad - expect).abs().max() / expect.abs().max())
+        q.put((rank, ex.tr.flat_grad.dtype == torch.float32, err, dp.launched_bytes, dp.launches))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bf16_payload_halves_the_exchanged_bytes_and_keeps_the_buffer_fp32_gloo():
+    """Optional reduced-precision payload (CTRLORA_DP_PAYLOAD=bf16 / payload_dtype): each bucket is cast, summed by the
+    collective in bf16 and written back into the fp32 flat buffer at wait(); half the bytes, bf16-level error."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_payload_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, is_f32, err, nbytes, launches in res:
+        assert is_f32 and launches >= 2
+        assert nbytes == 4000 * 2
+        assert 0 < err < 2e-2, err
