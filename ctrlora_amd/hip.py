@@ -145,9 +145,7 @@ def load_gemm_table(path: str, clear: bool = True) -> int:
     [dtype, mode, M, N, K1, K2, geglu, cfg, splitk].  A missing file leaves the built-in rules in charge
     (CTRLORA_GEMM_TUNED=0 does the same on purpose, for A/B runs).  Returns the number of entries."""
     import json
-    L = lib() if _lib is not None else None
-    if L is None:
-        return 0
+    L = lib()
     if clear:
         L.cl_gemm_tune_clear()
     if not path or not os.path.exists(path):
