@@ -116,6 +116,9 @@ def candidates(key):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true", help="training step only")
+    ap.add_argument("--ranks", default="128", help="comma-separated LoRA ranks whose training step is recorded "
+                    "(configs/ctrlora_finetune_sd15_rank<r>.yaml); DDIM / VAE workloads use rank 128")
+    ap.add_argument("--merge", default=None, help="existing table: its entries are kept, only NEW signatures are searched")
     ap.add_argument("--gain", type=float, default=0.03)
     ap.add_argument("--reps", type=int, default=16)
     ap.add_argument("--out", default=os.path.join(ROOT, "ctrlora_amd", "gemm_tuned_gfx950.json"))
@@ -129,21 +132,29 @@ def main():
     rec = Recorder()
 
     # ---- workloads -------------------------------------------------------------------------------------------
-    model = bench.build_model("ctrlora_finetune_sd15_rank128.yaml", 0).to(device).train()
-    model.set_engine_dtype(dtype)
-    model.learning_rate = 1e-5
-    opt = model.configure_optimizers()
-    data = bench.synth(8, 64, model.control_model.context_dim, device, 1234, 1)
-    cond = {"c_crossattn": [data["ctx"][0]], "c_concat": [data["hint"][0]]}
-    opt.zero_grad()
-    model.engine_train_step(data["z"][0], cond, data["t"][0], data["noise"][0])
-    torch.cuda.synchronize()
-    with rec:
-        rec.tag = "train"
+    kept = []
+    if args.merge and os.path.exists(args.merge):
+        with open(args.merge) as f:
+            kept = [list(map(int, r)) for r in json.load(f)["entries"]]
+    known = {tuple(r[:7]) for r in kept}
+    rank_set = {int(r) for r in args.ranks.split(",")}
+    for rank in [int(r) for r in args.ranks.split(",")]:
+        model = bench.build_model(f"ctrlora_finetune_sd15_rank{rank}.yaml", 0).to(device).train()
+        model.set_engine_dtype(dtype)
+        model.learning_rate = 1e-5
+        opt = model.configure_optimizers()
+        data = bench.synth(8, 64, model.control_model.context_dim, device, 1234, 1)
+        cond = {"c_crossattn": [data["ctx"][0]], "c_concat": [data["hint"][0]]}
         opt.zero_grad()
         model.engine_train_step(data["z"][0], cond, data["t"][0], data["noise"][0])
         torch.cuda.synchronize()
-    del model, opt
+        with rec:
+            rec.tag = "train" if rank == 128 else f"train_r{rank}"
+            opt.zero_grad()
+            model.engine_train_step(data["z"][0], cond, data["t"][0], data["noise"][0])
+            torch.cuda.synchronize()
+        del model, opt
+        torch.cuda.empty_cache()
     if not args.quick:
         from cldm.ddim_hacked import DDIMSampler
         minf = bench.build_model("inference/ctrlora_sd15_rank128_1lora.yaml", 0).to(device).eval()
@@ -185,6 +196,10 @@ def main():
     entries, rows = [], []
     t_start = time.time()
     for key, e in rec.calls.items():
+        if key in known:                                 # --merge: measured before, entry kept as it is
+            continue
+        if args.merge and not (key[5] or key[3] in rank_set or key[4] in rank_set):
+            continue                                     # --merge: rank-independent signature, searched when the table was made
         run, out = e["run"], e["out"]
         L.cl_gemm_force_config(-1); L.cl_gemm_force_splitk(0)
         run(); torch.cuda.synchronize()
@@ -265,7 +280,7 @@ def main():
             "gain_threshold": args.gain, "predicted_saving_ms": summary}
     with open(args.out, "w") as f:          # one entry per line: reviewable diffs
         f.write("{" + ", ".join(f"{json.dumps(k)}: {json.dumps(v)}" for k, v in head.items()) + ',\n"entries": [\n')
-        f.write(",\n".join(json.dumps(r) for r in sorted(entries)))
+        f.write(",\n".join(json.dumps(r) for r in sorted(kept + entries)))
         f.write("\n]}\n")
     log.close()
 
