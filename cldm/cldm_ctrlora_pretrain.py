@@ -106,20 +106,39 @@ class ControlNetPretrain(ControlNet):
 
 class _PretrainDP:
     """Gradient exchange of multi-task pre-training (ctrlora_amd.parallel.BankedGradAllReduce) behind the hooks the
-    training glue calls: the shared buffer and the banks live anywhere this step are summed over ranks."""
+    training glue calls: the shared buffer and the banks live anywhere this optimizer step are summed over ranks.
 
-    def __init__(self, cm):
+    Replica consistency (what DDP gives the reference for free): every rank must apply the SAME update to the SAME banks
+    in the SAME step.  So (a) the set handed to the exchange is every task this rank trained since its last optimizer
+    step (gradient accumulation may visit several), not only the current one; (b) right after the exchange -- before
+    optimizer.step() -- every bank that was live on ANY rank is marked used on THIS rank's optimizer, which makes it part
+    of this step's update (with the summed gradient) and of the following zero_grad, and starts its Adam step counter on
+    every rank at once."""
+
+    def __init__(self, cm, opt=None):
         from ctrlora_amd.parallel import BankedGradAllReduce
         ex = cm.executor()
         self.cm = cm
+        self.opt = opt                   # PretrainAdamW (configure_optimizers sets it): mark_used(task) on exchange
         self.inner = BankedGradAllReduce([ex.tr.flat_grad], {t: cm.bank(t).flat_grad for t in cm.tasks})
         self.world_size = self.inner.world_size
-        self.enabled = True
-        self.live = []
+        self.enabled = True              # False on non-final gradient-accumulation micro-steps
+        self.live = []                   # banks exchanged by the last optimizer step (on every rank)
+        self.used = []                   # tasks this rank back-propagated through since its last optimizer step
+
+    def note_used(self, task):
+        if task not in self.used:
+            self.used.append(task)
 
     def on_backward_done(self):
-        if self.enabled:
-            self.live = self.inner.exchange([self.cm._task])
+        self.note_used(self.cm._task)
+        if not self.enabled:
+            return
+        self.live = self.inner.exchange(self.used)
+        self.used = []
+        if self.opt is not None:
+            for t in self.live:
+                self.opt.mark_used(t)
 
     def wait(self):
         pass
@@ -152,10 +171,8 @@ class ControlPretrainLDM(ControlLDM):
             opt = self.__dict__.get("_opt")
             if opt is not None:
                 opt.mark_used(cond["task"])
-            if self.dp is not None and isinstance(self.dp, _PretrainDP):
-                for t in self.dp.live:               # banks other ranks trained last step: they carry gradients now
-                    if opt is not None:
-                        opt.mark_used(t)
+            if isinstance(self.dp, _PretrainDP):     # banks other ranks train join the update inside on_backward_done
+                self.dp.note_used(cond["task"])
         return self._run(x_noisy, t, cond_txt, [self._hint_latent(cond)])
 
     def init_data_parallel(self):
@@ -179,4 +196,6 @@ class ControlPretrainLDM(ControlLDM):
         world = 1 if self.dp is None else self.dp.world_size
         opt = PretrainAdamW(params, ex, banks, lr=self.learning_rate, grad_scale=1.0 / world)
         self.__dict__["_opt"] = opt
+        if isinstance(self.dp, _PretrainDP):
+            self.dp.opt = opt
         return opt

@@ -146,10 +146,21 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def load_state_dict(self, sd):
         self._step_dev.fill_(int(sd["step"]))
+        assert len(sd["m"]) == len(self._m), "optimizer state was saved for a different number of ControlNet banks"
         for dst, src in zip(self._m, sd["m"]):
             dst.copy_(src)
         for dst, src in zip(self._v, sd["v"]):
             dst.copy_(src)
+        _restore_param_groups(self, sd)
+
+
+def _restore_param_groups(opt, sd):
+    """Resume: the saved hyper-parameters (a scheduler may have moved lr) replace the constructor's, then go to the device."""
+    for g, saved in zip(opt.param_groups, sd.get("param_groups") or []):
+        for k, v in saved.items():
+            if k != "params":
+                g[k] = v
+    opt.sync_hyper()
 
 
 class PretrainAdamW(torch.optim.Optimizer):
@@ -225,10 +236,13 @@ class PretrainAdamW(torch.optim.Optimizer):
     def load_state_dict(self, sd):
         def unpack(st, src):
             st["m"].copy_(src["m"]); st["v"].copy_(src["v"]); st["step"].fill_(int(src["step"]))
+        if set(sd["banks"]) != set(self._bank_state):
+            raise KeyError(f"optimizer state holds banks {sorted(sd['banks'])}, the model has {sorted(self._bank_state)}")
         unpack(self._base, sd["base"])
         for k, src in sd["banks"].items():
             unpack(self._bank_state[k], src)
         self.active = list(sd["active"])
+        _restore_param_groups(self, sd)
 
 
 class GraphedTrainStep:

@@ -198,13 +198,19 @@ class AutoencoderKL(nn.Module):
         return (self.use_engine and x.is_cuda and not torch.is_grad_enabled() and not self.ddconfig.get("attn_resolutions")
                 and x.shape[-1] % 8 == 0 and x.shape[-2] % 8 == 0)
 
+    # the middle AttnBlock runs on N = (H / 8) * (W / 8) latent positions and cl_softmax_rows holds a row of at most 8192
+    # scores: larger images (768 x 768 -> N = 9216) take the torch modules, as the reference does, instead of raising
+    ENGINE_MAX_ATTN_TOKENS = 8192
+
     def encode(self, x):
-        if self._on_engine(x) and (x.shape[-1] * x.shape[-2]) % 2048 == 0:
+        if (self._on_engine(x) and (x.shape[-1] * x.shape[-2]) % 2048 == 0
+                and (x.shape[-1] // 8) * (x.shape[-2] // 8) <= self.ENGINE_MAX_ATTN_TOKENS):
             return DiagonalGaussianDistribution(self._engine("enc")(x))
         return DiagonalGaussianDistribution(self.quant_conv(self.encoder(x)))
 
     def decode(self, z):
-        if self._on_engine(z) and (z.shape[-1] * z.shape[-2]) % 32 == 0:
+        if (self._on_engine(z) and (z.shape[-1] * z.shape[-2]) % 32 == 0
+                and z.shape[-1] * z.shape[-2] <= self.ENGINE_MAX_ATTN_TOKENS):
             return self._engine("dec")(z)
         return self.decoder(self.post_quant_conv(z))
 

@@ -38,9 +38,15 @@ class FrozenCLIPEmbedder(AbstractEncoder):
         assert layer in self.LAYERS
         from transformers import CLIPTextConfig, CLIPTextModel
         self.version, self.device, self.max_length, self.layer, self.layer_idx = version, device, max_length, layer, layer_idx
+        self.weights_from_checkpoint = False
         try:
             self.transformer = CLIPTextModel.from_pretrained(version, local_files_only=True)
-        except Exception:
+        except (OSError, ValueError) as e:      # no local HF files (offline): anything else is a real error and propagates
+            import warnings
+            warnings.warn(f"CLIP text encoder '{version}': no local pretrained files ({type(e).__name__}); the module is built "
+                          "from its config with RANDOM weights -- they must come from the SD checkpoint's cond_stage_model.* "
+                          "keys (load_state_dict), otherwise the text conditioning is garbage")
+            self.weights_from_checkpoint = True
             cfg = CLIPTextConfig(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12,
                                  num_attention_heads=12, max_position_embeddings=77, hidden_act="quick_gelu",
                                  projection_dim=768)

@@ -143,6 +143,148 @@ def test_banked_grad_exchange_two_ranks_different_tasks_gloo():
     assert all(ok for _, ok in res), res
 
 
+# ------------------------------------------------------------------ _PretrainDP: replicas stay identical
+
+class _FlatSet:
+    def __init__(self, n, seed):
+        self.flat = torch.randn(n, generator=torch.Generator().manual_seed(seed))
+        self.flat_grad = torch.zeros(n)
+        self.numel = n
+
+
+class _FakePretrainExec:
+    def __init__(self):
+        self.tr = _FlatSet(64, 1)
+
+    def repack(self, only=None):
+        pass
+
+
+class _FakePretrainCN:
+    """What _PretrainDP / PretrainAdamW touch of ControlNetPretrain: executor(), bank(task), tasks, _task."""
+    tasks = ["hed", "canny", "depth"]
+
+    def __init__(self):
+        self._ex = _FakePretrainExec()
+        self._banks = {t: _FlatSet(32, 10 + i) for i, t in enumerate(self.tasks)}     # same init on every rank
+        self._task = None
+
+    def executor(self):
+        return self._ex
+
+    def bank(self, t):
+        return self._banks[t]
+
+
+def _cpu_kernels(hipmod):
+    """CPU stand-ins for the three device entry points PretrainAdamW uses (the arithmetic of cl_adamw_dev)."""
+    def tick(counter):
+        counter += 1
+
+    def zero_(t):
+        return t.zero_()
+
+    def adamw_dev(p, g, m, v, hyper, step):
+        lr, b1, b2, eps, wd, gs = [float(x) for x in hyper]
+        k = int(step.item())
+        gg = g * gs
+        p.mul_(1 - lr * wd)
+        m.mul_(b1).add_(gg, alpha=1 - b1)
+        v.mul_(b2).addcmul_(gg, gg, value=1 - b2)
+        bc1, bc2 = 1 - b1 ** k, 1 - b2 ** k
+        p.addcdiv_(m, (v / bc2).sqrt_().add_(eps), value=-lr / bc1)
+
+    hipmod.tick, hipmod.zero_, hipmod.adamw_dev = tick, zero_, adamw_dev
+
+
+# micro-step schedule per rank: (optimizer step, micro-step) -> task; accumulate_grad_batches = 2.  The ranks train different
+# tasks in the same step, a rank changes task between the micro-steps of one optimizer step, and `depth` first appears on
+# rank 1 only (its Adam step counter must start on both ranks at that step).
+_SCHED = {0: [("hed", "canny"), ("canny", "canny"), ("hed", "hed"), ("canny", "hed")],
+          1: [("depth", "hed"), ("hed", "depth"), ("hed", "hed"), ("depth", "depth")]}
+
+
+def _g(rank, step, micro, n, salt):
+    return torch.randn(n, generator=torch.Generator().manual_seed(1000 * rank + 100 * step + 10 * micro + salt))
+
+
+def _pretrain_dp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ctrlora_amd import hip as hipmod
+        _cpu_kernels(hipmod)
+        from ctrlora_amd.train import PretrainAdamW
+        from cldm.cldm_ctrlora_pretrain import _PretrainDP
+        cm = _FakePretrainCN()
+        dp = _PretrainDP(cm)
+        params = [torch.nn.Parameter(cm.executor().tr.flat)] + [torch.nn.Parameter(b.flat) for b in cm._banks.values()]
+        opt = PretrainAdamW(params, cm.executor(), {t: cm.bank(t) for t in cm.tasks}, lr=1e-2, grad_scale=1.0 / world)
+        dp.opt = opt
+        # the reference the replicas must follow: torch.optim.AdamW on the gradients DDP would produce (mean over ranks,
+        # zeros from ranks that did not use a bank; a bank joins at its first gradient anywhere and is then updated every
+        # step with a zero gradient when idle -- torch 1.13 zero_grad semantics, see PretrainAdamW)
+        ref_p = {"base": torch.nn.Parameter(cm.executor().tr.flat.clone())}
+        ref_p.update({t: torch.nn.Parameter(cm.bank(t).flat.clone()) for t in cm.tasks})
+        ref = torch.optim.AdamW(list(ref_p.values()), lr=1e-2)
+        ok = True
+        for step, _ in enumerate(_SCHED[0]):
+            tot = {k: None for k in ref_p}
+            for r in range(world):
+                for micro, task in enumerate(_SCHED[r][step]):
+                    gb, gt = _g(r, step, micro, 64, 1) / 2, _g(r, step, micro, 32, 2) / 2          # loss / acc
+                    tot["base"] = gb if tot["base"] is None else tot["base"] + gb
+                    tot[task] = gt if tot[task] is None else tot[task] + gt
+                    if r == rank:                       # this rank's own backward
+                        cm._task = task
+                        opt.mark_used(task); dp.note_used(task)
+                        cm.executor().tr.flat_grad += gb
+                        cm.bank(task).flat_grad += gt
+                        dp.enabled = micro == 1
+                        dp.on_backward_done()
+            opt.step(); opt.zero_grad()
+            for k, p in ref_p.items():
+                if tot[k] is not None:
+                    p.grad = tot[k] / world
+                elif p.grad is not None:
+                    p.grad = torch.zeros_like(p)
+            ref.step()
+            ok &= torch.allclose(cm.executor().tr.flat, ref_p["base"].detach(), atol=1e-6)
+            for t in cm.tasks:
+                ok &= torch.allclose(cm.bank(t).flat, ref_p[t].detach(), atol=1e-6)
+        # replicas bit-identical: parameters, moments and per-bank step counters
+        blob = torch.cat([cm.executor().tr.flat] + [cm.bank(t).flat for t in cm.tasks] +
+                         [opt._bank_state[t]["m"] for t in cm.tasks] +
+                         [opt._bank_state[t]["step"].float() for t in cm.tasks])
+        got = [torch.zeros_like(blob) for _ in range(world)]
+        dist.all_gather(got, blob)
+        ok &= all(torch.equal(got[0], g) for g in got[1:])
+        ok &= [int(opt._bank_state[t]["step"]) for t in cm.tasks] == [4, 4, 4] and sorted(opt.active) == sorted(cm.tasks)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_pretrain_dp_replicas_stay_identical_with_mixed_tasks_and_accumulation_gloo():
+    """ADVICE r2 high + medium: with ranks on different tasks (and a task change inside one accumulated optimizer step)
+    every rank must update the SAME banks with the SAME summed gradients in the SAME step -- parameters, moments and
+    per-bank Adam step counters end bit-identical across ranks and equal to torch.optim.AdamW on DDP's gradients."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pretrain_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
+
+
 # ------------------------------------------------------------------ DP-N == one large batch, on the real layout
 
 def _dp_equiv_worker(rank, world, port, q):
