@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 TRAIN_TFLOP_PER_IMAGE = {32: 1.913, 64: 1.941, 128: 1.996, 256: 2.11, 512: 2.33}
 DDIM_TFLOP_PER_STEP_IMAGE = 2.207
+STOCK_BF16_IMAGES_PER_S = 42.3   # profiles/r02_compare_precision.json: stock kernels, bf16 autocast, B=8, one MI355X
 PEAK_HBM_TBS = 8.0          # TB/s, MI355X_MICROARCH.md
 PEAK_BF16_TFLOPS = 2500.0
 
@@ -111,8 +112,35 @@ def family_census(model, opt, data, reps=10):
     the figure the step actually gets from the family, not its best shape."""
     import collections
     from ctrlora_amd import hip
-    calls = {"gemm": collections.OrderedDict(), "attention": collections.OrderedDict()}
+    calls = {"gemm": collections.OrderedDict(), "attention": collections.OrderedDict(), "hbm": collections.OrderedDict()}
     o_gemm, o_af, o_ab = hip.gemm, hip.attention_fwd_v2, hip.attention_bwd_v2
+
+    # HBM-bound family (SURVEY.md 8d: "reported per-kernel ... vs 8 TB/s"): GroupNorm(+SiLU) / LayerNorm / GEGLU forward and
+    # backward and the column sums.  ALGORITHMIC bytes = every operand once (a two-pass normalisation re-reads its input
+    # from L2 / Infinity Cache, not counted), in the storage dtype.
+    def _bytes_hbm(name, a, kw):
+        es = a[0].element_size()
+        M, C = a[0].shape
+        if name == "groupnorm_fwd" or name == "layernorm_fwd":
+            return 2 * M * C * es
+        if name == "groupnorm_bwd" or name == "layernorm_bwd":
+            return (4 if kw.get("accum") is not None else 3) * M * C * es
+        if name == "geglu_fwd":
+            return 3 * M * (C // 2) * es
+        if name == "geglu_bwd":
+            return 5 * M * (C // 2) * es
+        return M * C * es                                            # colsum
+
+    hbm_orig = {n: getattr(hip, n) for n in ("groupnorm_fwd", "groupnorm_bwd", "layernorm_fwd", "layernorm_bwd",
+                                             "geglu_fwd", "geglu_bwd", "colsum")}
+
+    def _mk_hbm(name, fn):
+        def rec(*a, **kw):
+            key = (name, tuple(a[0].shape), kw.get("accum") is not None, kw.get("dgamma") is not None)
+            e = calls["hbm"].setdefault(key, [0, 0.0, lambda: fn(*a, **kw), _bytes_hbm(name, a, kw)])
+            e[0] += 1
+            return fn(*a, **kw)
+        return rec
 
     def rec_gemm(a1, w1, out, **kw):
         M = out.shape[0] if kw.get("M") is None else kw["M"]
@@ -152,6 +180,8 @@ def family_census(model, opt, data, reps=10):
         return o_ab(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, N, Nkv, dh, scale)
 
     hip.gemm, hip.attention_fwd_v2, hip.attention_bwd_v2 = rec_gemm, rec_af, rec_ab
+    for n, fn in hbm_orig.items():
+        setattr(hip, n, _mk_hbm(n, fn))
     try:
         opt.zero_grad()
         cond = {"c_crossattn": [data["ctx"][0]], "c_concat": [data["hint"][0]]}
@@ -159,6 +189,8 @@ def family_census(model, opt, data, reps=10):
         torch.cuda.synchronize()
     finally:
         hip.gemm, hip.attention_fwd_v2, hip.attention_bwd_v2 = o_gemm, o_af, o_ab
+        for n, fn in hbm_orig.items():
+            setattr(hip, n, fn)
     out = {}
     for fam, tab in calls.items():
         tot_us, tot_fl, n, ideal_us, mem_us = 0.0, 0.0, 0, 0.0, 0.0
@@ -179,6 +211,21 @@ def family_census(model, opt, data, reps=10):
             ideal_us += max(t_mfma, t_hbm) * cnt
             if t_hbm > t_mfma:
                 mem_us += us * cnt
+        if fam == "hbm":
+            if tot_us > 0:
+                tot_by = sum(e[3] * e[0] for e in tab.values())
+                per = {}
+                for key, e in tab.items():
+                    d = per.setdefault(key[0], [0, 0.0])
+                    d[0] += e[0]; d[1] += e[3] * e[0]
+                tbs = tot_by / tot_us * 1e-6
+                out[fam] = dict(bound="hbm", achieved=round(tbs * 1e3, 1), peak=PEAK_HBM_TBS * 1e3, unit="GB/s",
+                                frac=round(tbs / PEAK_HBM_TBS, 4), ms_per_step=round(tot_us * 1e-3, 2), launches_per_step=n,
+                                unique_shapes=len(tab), algorithmic_MB_per_step=round(tot_by * 1e-6, 1),
+                                kernels="GroupNorm(+SiLU) / LayerNorm / GEGLU forward + backward, column sums; every operand "
+                                        "counted once; timed per signature in isolation with HIP events",
+                                calls_per_step={k: v[0] for k, v in per.items()})
+            continue
         if tot_us > 0:
             tf = tot_fl / tot_us * 1e-6
             out[fam] = dict(achieved=round(tf, 1), frac=round(tf / PEAK_BF16_TFLOPS, 4), unit="TFLOP/s",
@@ -216,7 +263,7 @@ def vae_bench(device, dtype, B=8, iters=3):
     return dict(images=2 * B, ms=round(ms, 2), tflops=round(gf / ms, 1), mfma_frac=round(gf / ms / PEAK_BF16_TFLOPS, 4))
 
 
-def ddim_bench(device, dtype, B=16, S=50, tiny=False, loops=5):
+def ddim_bench(device, dtype, B=16, S=50, tiny=False, loops=5, warm_loops=10):
     from cldm.ddim_hacked import DDIMSampler
     model = build_model("inference/ctrlora_sd15_rank128_1lora.yaml", 0, tiny=tiny).to(device).eval()
     model.set_engine_dtype(dtype)
@@ -228,9 +275,12 @@ def ddim_bench(device, dtype, B=16, S=50, tiny=False, loops=5):
     unc = {"c_concat": [hint], "c_crossattn": [torch.randn(B, 77, cd, generator=g).to(device)]}
     x_T = torch.randn(B, 4, H, H, generator=g).to(device)
     sampler = DDIMSampler(model)
+    sampler.reuse_graph = True               # same conditioning tensors, same weights: capture once, replay in every loop
     run = lambda s: sampler.sample(s, B, (4, H, H), cond, verbose=False, eta=0.0, x_T=x_T,
                                    unconditional_guidance_scale=7.5, unconditional_conditioning=unc)
-    run(6)                                   # warm-up loop (kernel attribute set-up, allocator, capture path)
+    run(6)                                   # kernel attribute set-up, allocator, capture path
+    for _ in range(warm_loops):              # warm-up loops at the timed length (the first one captures the S-step graph)
+        run(S)
     torch.cuda.synchronize()
     times = []
     for _ in range(loops):
@@ -245,8 +295,10 @@ def ddim_bench(device, dtype, B=16, S=50, tiny=False, loops=5):
     return dict(metric="DDIM denoise steps/s (CFG 7.5, both passes, all B images)", value=round(sps, 3), batch=B, S=S,
                 ms_per_step=round(dt / S * 1e3, 2), best=round(S / times[0], 3), loops=loops,
                 mfma_frac=round(DDIM_TFLOP_PER_STEP_IMAGE * B * sps / PEAK_BF16_TFLOPS, 4),
-                note=f"median of {loops} full S={S} loops after a warm-up loop (best loop in `best`); each loop includes "
-                     "its own graph capture; hint latent given (VAE encode hoisted out of the loop); cond+uncond batched")
+                warmup_loops=warm_loops, graph_captures_in_timed_loops=0 if getattr(sampler, "graph_hits", 0) >= loops else None,
+                note=f"median of {loops} full S={S} loops (best loop in `best`) after {warm_loops} warm-up loops of the same length; the "
+                     "denoise-step graph is captured once in the warm-up and replayed S times per timed loop; hint latent given "
+                     "(VAE encode hoisted out of the loop); cond+uncond batched")
 
 
 def pretrain_bench(device, dtype, B=8, steps=9, warmup=9, tiny=False):
@@ -345,6 +397,42 @@ def cpu_baseline(rank_lora=32, threads=32):
     return train_b, ddim_b
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: re-run this file under torch.distributed.run, one rank per GPU of this
+    node (what the reference's `Trainer(strategy='ddp', devices=-1)` does from one command,
+    scripts/train_ctrlora_finetune.py:122-126).  Rank 0's JSON line is passed through.  If the hipGraph-replay data-parallel
+    path dies (first contact of segment graphs with RCCL is the likeliest failure: capture invalidated by the watchdog
+    thread, a collective timing out), the run is repeated ONCE with --no-graph (eager launches, bucketed all-reduces issued
+    from the backward hooks) so that a number is still measured; the line then says `"launch": "eager"`."""
+    import subprocess
+
+    def run(extra):
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.abspath(__file__), *argv, *extra]
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+        return r.returncode, lines, r.stdout
+
+    rc, lines, out = run([])
+    if (rc != 0 or not lines) and "--no-graph" not in argv:
+        print(f"[bench] {n}-rank run failed (rc {rc}); retrying once with --no-graph (eager data parallel)", file=sys.stderr)
+        rc, lines, out = run(["--no-graph"])
+    if lines:
+        print(lines[-1])
+    else:
+        sys.stdout.write(out)
+    return rc if lines else (rc or 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -369,6 +457,8 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="debug: narrow model")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))        # `python bench.py --gpus N` starts its own ranks
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -377,7 +467,9 @@ def main():
     device = torch.device("cuda", local)
     if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        import datetime
+        # a collective that never completes aborts the job after 5 minutes instead of hanging the node for the default 10+
+        dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=300))
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     if args.ddim_only:
         print(json.dumps(ddim_bench(device, dtype, tiny=args.tiny)))
@@ -409,9 +501,18 @@ def main():
             graphed = GraphedTrainStep(model, opt, data["z"][0], data["ctx"][0], data["hint"][0], data["t"][0],
                                        data["noise"][0], split_graphs=True if args.force_split_graphs else None)
         except Exception as e:   # capture is an optimisation: never lose the measurement to it
-            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches",
+            print(f"[bench] rank {rank}: hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches",
                   file=sys.stderr)
-            graphed, args.no_graph = None, True
+            graphed = None
+        if world > 1:
+            # the ranks must agree: segment graphs and the eager hooks cut the gradient buffer into different buckets, so a
+            # mixed job would dead-lock in its first mismatched collective
+            okf = torch.tensor([0 if graphed is None else 1], device=device, dtype=torch.int32)
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+            if int(okf) == 0:
+                graphed = None
+        if graphed is None:
+            args.no_graph = True
             if model.dp is not None:
                 model.dp.enabled = True
                 opt.pre_step_hook = model.dp.wait
@@ -448,6 +549,37 @@ def main():
     final_loss = float(loss)
     assert final_loss == final_loss, "loss is NaN"
 
+    dp_info = None
+    if world > 1:
+        # what the exchange costs: the same K steps with the gradient all-reduce switched off (every rank then keeps its own
+        # gradients -- measurement only, AFTER the timed region); exposed = with - without
+        ex0 = model.control_model.executor()
+        dp_info = {"payload_MB_per_step": round(ex0.tr.numel * 4 / 1e6, 1), "collective": "RCCL all-reduce (SUM), fp32, "
+                   "LoRA + zero-conv + norm gradients only (flat buffer in backward-completion order)"}
+        try:
+            if graphed is not None:
+                saved_fn, graphed._reduce_fn = graphed._reduce_fn, (lambda buf: None)
+                dp_info.update(segments=len(graphed.segments), bucket_MB=32)
+            else:
+                model.dp.enabled = False
+                opt.pre_step_hook = None
+            for i in range(2):
+                step(i)
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                step(i)
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t_no = torch.tensor([time.perf_counter() - t1], device=device, dtype=torch.float64)
+            dist.all_reduce(t_no, op=dist.ReduceOp.MAX)
+            ms_no = float(t_no) / args.steps * 1e3
+            dp_info.update(ms_per_step_without_exchange=round(ms_no, 2),
+                           exposed_allreduce_ms_per_step=round(dt / args.steps * 1e3 - ms_no, 2))
+            if graphed is not None:
+                graphed._reduce_fn = saved_fn
+        except Exception as e:
+            print(f"[bench] exchange-off measurement failed on rank {rank}: {type(e).__name__}: {e}", file=sys.stderr)
+
     if rank == 0:
         ips = world * B * args.steps / dt
         tf_img = TRAIN_TFLOP_PER_IMAGE.get(args.rank_lora, 1.996)
@@ -465,6 +597,14 @@ def main():
                        "gemm_launch_table_entries": int(__import__("ctrlora_amd.hip", fromlist=["lib"]).lib().cl_gemm_tune_size())},
             "loss": round(final_loss, 5),
         }
+        if dp_info is not None:
+            out["config"]["data_parallel"] = dp_info
+        if world == 1 and args.rank_lora == 128 and args.dtype == "bf16" and not args.tiny and B == 8:
+            # context, not credit: the reference's own modules on PyTorch-ROCm eager kernels, bf16 autocast, same workload and
+            # GPU model (tests/tools/compare_stock.py -> profiles/r02_compare_precision.json); not re-measured in this run
+            out["vs_stock"] = {"value": round(ips / STOCK_BF16_IMAGES_PER_S, 2), "stock_images_per_s": STOCK_BF16_IMAGES_PER_S,
+                               "kind": "static: profiles/r02_compare_precision.json (reference modules, torch.autocast(bf16), "
+                                       "PyTorch-ROCm eager, B=8, 1x MI355X)"}
         achieved = tf_img * ips / world          # per-GPU TFLOP/s
         roof = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
@@ -488,6 +628,8 @@ def main():
                                                    "not re-measured in this run")
             if "attention" in fam:
                 roof["attention_family"] = fam["attention"]
+            if "hbm" in fam:
+                roof["norm_elementwise_family"] = fam["hbm"]
         out["roofline"] = roof
     if rank == 0 and not args.tiny and args.dtype == "bf16" and not args.no_vae:
         try:   # end to end = the core step + the first-stage encodes the reference performs inside every step

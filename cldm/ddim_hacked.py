@@ -50,6 +50,12 @@ class DDIMSampler(object):
         # capture one denoise step (both CFG passes + the fused update) as a hipGraph and replay it for the
         # rest of the loop; set False to run every step eagerly
         self.use_graph = True
+        # opt-in: keep the captured denoise-step graph (and its static buffers) across sample() calls.  Valid while the call
+        # is the same problem -- same conditioning TENSORS (identity and version), batch, shape, S, guidance scale -- and the
+        # model's weights are unchanged; anything else re-captures.  A serving loop over one prompt / a benchmark sets it.
+        self.reuse_graph = False
+        self._graph_state = None
+        self.graph_hits = 0
 
     def register_buffer(self, name, attr):
         if isinstance(attr, torch.Tensor) and attr.device != self.model.device:
@@ -165,6 +171,29 @@ class DDIMSampler(object):
         from ctrlora_amd import hip
         model, device = self.model, img.device
         S, b = int(timesteps.shape[0]), img.shape[0]
+
+        def _sig(c):
+            if c is None:
+                return None
+            return tuple((k, tuple((id(t), t._version, tuple(t.shape)) for t in (v if isinstance(v, (list, tuple)) else [v])
+                                   if torch.is_tensor(t))) for k, v in sorted(c.items()) if v is not None)
+
+        key = (id(model.engine()), S, tuple(img.shape), float(cfg_scale), float(temperature), _sig(cond), _sig(uncond),
+               np.ascontiguousarray(timesteps).tobytes(), self.coef_table.data_ptr())
+        st = self._graph_state if self.reuse_graph else None
+        if st is not None and st["key"] == key and not (callback or img_callback):
+            # replay-only loop: same kernels, same buffers (the context K/V products of iteration 0 are still in st)
+            st["x"].copy_(img.float())
+            st["cursor"].zero_()
+            for i in range(S):
+                st["graph"].replay()
+                index = S - i - 1
+                if index % log_every_t == 0 or index == S - 1:
+                    intermediates["x_inter"].append(st["x"].clone())
+                    intermediates["pred_x0"].append(st["pred_x0"].clone())
+            self.graph_hits += 1
+            return st["x"].clone(), intermediates
+        self._graph_state = None
         x = img.float().contiguous().clone()
         pred_x0 = torch.empty_like(x)
         ts = torch.zeros(b, dtype=torch.long, device=device)
@@ -218,8 +247,13 @@ class DDIMSampler(object):
                     intermediates["pred_x0"].append(pred_x0.clone())
         finally:
             eng.cache_context_kv = False
+            kv_keep = eng.detach_context_cache() if (self.reuse_graph and graph is not None) else None
             eng.reset_context_cache()
         out = x.clone()
+        if self.reuse_graph and graph is not None:
+            # the graph reads the cached K/V products and the conditioning tensors by address: hold them
+            self._graph_state = dict(key=key, graph=graph, x=x, pred_x0=pred_x0, ts=ts, cursor=cursor, table=table, kv=kv_keep,
+                                     conds=(cond, uncond, both))
         del graph
         return out, intermediates
 

@@ -85,6 +85,11 @@ class CtrLoRAEngine:
     def reset_context_cache(self):
         self._kv = None
 
+    def detach_context_cache(self):
+        """Hand the cached context K / V products to the caller (a kept hipGraph reads them by address) and forget them."""
+        kv, self._kv = self._kv, None
+        return kv
+
     # ---------------------------------------------------------------- forward
     @torch.no_grad()
     def forward(self, x_noisy, t, context, hints: Optional[Sequence[torch.Tensor]], control_scales=None,

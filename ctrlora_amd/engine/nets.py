@@ -68,6 +68,7 @@ class _Builder:
         # the network is declared in `trainables`; the LoRA factors go to `lora_set` (one set per task bank)
         self.tr_lora = lora_set if lora_set is not None else trainables
         self.train_all = train_all
+        self.fold_lora = False       # set by ControlNetE before building: LoRA linears keep their fp32 base weight
         self.linears: List[LinearW] = []
         self.norms: List[NormW] = []
         self.convs: List[Conv3W] = []
@@ -86,9 +87,10 @@ class _Builder:
         return (self.prefix + name) in self.sd
 
     def linear(self, name: str) -> LinearW:
-        L = LinearW(self._g(name + ".weight"), self._g(name + ".bias") if self._has(name + ".bias") else None,
-                    self.dtype, self.device, self.need_bwd)
         dn = name + ".lora_layer.down.weight"
+        L = LinearW(self._g(name + ".weight"), self._g(name + ".bias") if self._has(name + ".bias") else None,
+                    self.dtype, self.device, self.need_bwd,
+                    keep_f32=self.fold_lora and self._has(dn) and self.dtype != torch.float32)
         if self.train_all:
             tW = self.tr.declare(self.prefix + name + ".weight", (L.N, L.K))
             tb = self.tr.declare(self.prefix + name + ".bias", (L.N,)) if self._has(name + ".bias") else None
@@ -354,6 +356,7 @@ class ControlNetE:
         # pre-training: base weights in self.tr, the active task's LoRA bank in self.tr_lora (switch_bank swaps it)
         self.tr_lora = (lora_set if lora_set is not None else TrainableSet()) if train_all else self.tr
         b = _Builder(sd, prefix, dtype, device, need_bwd, self.tr, self.tr_lora, train_all)
+        b.fold_lora = self.merge_lora
         self.lora = (prefix + "time_embed.0.lora_layer.down.weight") in sd
         self.time = _TimeEmbed(b, cfg)
         marks = [len(self.tr.items)]          # stage boundaries in declaration (= forward) order

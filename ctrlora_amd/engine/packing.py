@@ -93,10 +93,13 @@ class TrainableSet:
 class LinearW:
     """nn.Linear / 1x1 conv / LoRACompatibleLinear in packed form."""
 
-    def __init__(self, W: torch.Tensor, bias: Optional[torch.Tensor], dtype, device, need_bwd: bool):
+    def __init__(self, W: torch.Tensor, bias: Optional[torch.Tensor], dtype, device, need_bwd: bool, keep_f32: bool = False):
         W = W.reshape(W.shape[0], -1).to(device=device, dtype=torch.float32)
         self.N, self.K = W.shape
         self.W = W.to(dtype).contiguous()
+        # inference executors that fold the LoRA keep the fp32 base weight: Wm = storage(W_fp32 + B A) is then ONE rounding of
+        # the merged weight -- exactly the error any stored weight has -- instead of round(round(W) + B A)
+        self.W32 = W.contiguous() if keep_f32 else None
         self.Wt = W.t().to(dtype).contiguous() if need_bwd else None
         self.bias = None if bias is None else bias.to(device=device, dtype=torch.float32).contiguous()
         self.r = 0
@@ -118,6 +121,8 @@ class LinearW:
         W = W.reshape(W.shape[0], -1).to(device=self.W.device, dtype=torch.float32)
         assert tuple(W.shape) == (self.N, self.K)
         self.W.copy_(W)
+        if self.W32 is not None:
+            self.W32.copy_(W)
         if self.Wt is not None:
             self.Wt.copy_(W.t())
         if bias is not None and self.bias is not None and self.tb is None:
@@ -158,7 +163,8 @@ class LinearW:
         """Wm = storage-dtype(W + B A) from the packed base weight and the fp32 LoRA masters (weight-load time only)."""
         if self.tA is None:
             return
-        m = torch.addmm(self.W.float(), self.tB.master.view(self.N, self.r), self.tA.master.view(self.r, self.K))
+        base = self.W32 if self.W32 is not None else self.W.float()
+        m = torch.addmm(base, self.tB.master.view(self.N, self.r), self.tA.master.view(self.r, self.K))
         if self.Wm is None:
             self.Wm = m.to(self.dtype).contiguous()
         else:

@@ -25,7 +25,9 @@ from tests.util import GOLDEN, ROOT, rel_l2
 
 pytestmark = pytest.mark.gpu
 
-BF16_EPS, BF16_GRAD_MAX, BF16_GRAD_MEDIAN = 2e-2, 8e-2, 4e-2
+# measured (profiles/r02_parity_measured.jsonl, r03): eps 8.9e-3 .. 9.6e-3, worst gradient 3.2e-2 .. 3.7e-2, median 1.28e-2;
+# the reference's own bf16-autocast path: 1.1e-2 / 3.2e-2 / 1.2e-2.  Gates = ~1.3 x measured, so a real regression trips them.
+BF16_EPS, BF16_GRAD_MAX, BF16_GRAD_MEDIAN = 1.3e-2, 5e-2, 1.7e-2
 
 
 def _need_gpu():
