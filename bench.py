@@ -205,6 +205,8 @@ def family_census(model, opt, data, reps=10):
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / reps
+            if fam == "hbm":
+                ent.append(us)
             tot_us += us * cnt; tot_fl += fl * cnt; n += cnt
             t_mfma = fl / (PEAK_BF16_TFLOPS * 1e6)                      # us at the dense bf16 MFMA peak
             t_hbm = (ent[3] / (PEAK_HBM_TBS * 1e6)) if len(ent) > 3 else 0.0   # us at the HBM peak
@@ -216,15 +218,16 @@ def family_census(model, opt, data, reps=10):
                 tot_by = sum(e[3] * e[0] for e in tab.values())
                 per = {}
                 for key, e in tab.items():
-                    d = per.setdefault(key[0], [0, 0.0])
-                    d[0] += e[0]; d[1] += e[3] * e[0]
+                    d = per.setdefault(key[0], [0, 0.0, 0.0])
+                    d[0] += e[0]; d[1] += e[3] * e[0]; d[2] += e[4] * e[0]
                 tbs = tot_by / tot_us * 1e-6
                 out[fam] = dict(bound="hbm", achieved=round(tbs * 1e3, 1), peak=PEAK_HBM_TBS * 1e3, unit="GB/s",
                                 frac=round(tbs / PEAK_HBM_TBS, 4), ms_per_step=round(tot_us * 1e-3, 2), launches_per_step=n,
                                 unique_shapes=len(tab), algorithmic_MB_per_step=round(tot_by * 1e-6, 1),
                                 kernels="GroupNorm(+SiLU) / LayerNorm / GEGLU forward + backward, column sums; every operand "
                                         "counted once; timed per signature in isolation with HIP events",
-                                calls_per_step={k: v[0] for k, v in per.items()})
+                                per_kernel={k: dict(calls=v[0], ms=round(v[2] * 1e-3, 3), GBps=round(v[1] / v[2] * 1e-3, 1))
+                                            for k, v in per.items()})
             continue
         if tot_us > 0:
             tf = tot_fl / tot_us * 1e-6

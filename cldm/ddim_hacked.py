@@ -179,9 +179,12 @@ class DDIMSampler(object):
                                    if torch.is_tensor(t))) for k, v in sorted(c.items()) if v is not None)
 
         key = (id(model.engine()), S, tuple(img.shape), float(cfg_scale), float(temperature), _sig(cond), _sig(uncond),
-               np.ascontiguousarray(timesteps).tobytes(), self.coef_table.data_ptr())
+               np.ascontiguousarray(timesteps).tobytes())
         st = self._graph_state if self.reuse_graph else None
-        if st is not None and st["key"] == key and not (callback or img_callback):
+        # sample() rebuilds the coefficient table on every call: the kept graph reads ITS table by address (held in st), so a
+        # hit needs equal contents, not the same tensor
+        if (st is not None and st["key"] == key and not (callback or img_callback)
+                and st["coef"].shape == self.coef_table.shape and bool(torch.equal(st["coef"], self.coef_table))):
             # replay-only loop: same kernels, same buffers (the context K/V products of iteration 0 are still in st)
             st["x"].copy_(img.float())
             st["cursor"].zero_()
@@ -253,7 +256,7 @@ class DDIMSampler(object):
         if self.reuse_graph and graph is not None:
             # the graph reads the cached K/V products and the conditioning tensors by address: hold them
             self._graph_state = dict(key=key, graph=graph, x=x, pred_x0=pred_x0, ts=ts, cursor=cursor, table=table, kv=kv_keep,
-                                     conds=(cond, uncond, both))
+                                     conds=(cond, uncond, both), coef=self.coef_table)
         del graph
         return out, intermediates
 

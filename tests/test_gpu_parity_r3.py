@@ -137,7 +137,7 @@ def test_ddim_cfg_sampler_sd15_latent64_vs_oracle_sampler():
     x, _ = s.sample(S, B, (4, H, H), cond, verbose=False, eta=0.0, x_T=x_T, unconditional_guidance_scale=7.5,
                     unconditional_conditioning=unc)
     assert list(s.ddim_timesteps) == [1, 251, 501, 751]
-    sched = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in R.make_schedule().items()}
+    sched = R.make_schedule()          # tables stay on the host (the oracle's sampler indexes them with numpy); x lives on the GPU
 
     def sampler(autocast):
         fn = lambda xx, tt, c: _oracle_eps(cfg, sd_cn, sd_un, xx, tt, ctx if c else ctx_u, hint, autocast=autocast)
