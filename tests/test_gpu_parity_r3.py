@@ -249,7 +249,7 @@ def test_pretraining_step_sd15_width_all_gradients_vs_oracle(dtype):
         assert errs[0][0] < 5e-4, errs[:5]
     else:
         assert abs(float(loss) - float(loss_o)) < 2e-2 * float(loss_o)
-        assert errs[0][0] < 8e-2 and med < 3e-2, (errs[:5], med)
+        assert errs[0][0] < 5.5e-2 and med < 2.1e-2, (errs[:5], med)      # measured 4.2e-2 / 1.6e-2 (profiles/r03_parity_measured_b.jsonl)
 
 
 def test_pretraining_bf16_error_is_flat_on_the_fp32_parameter_trajectory():
@@ -289,5 +289,5 @@ def test_pretraining_bf16_error_is_flat_on_the_fp32_parameter_trajectory():
         worst.append(e)
         of.step()
     _record("pretrain_bf16_on_fp32_trajectory", worst_per_step=[w[0] for w in worst], names=[w[1] for w in worst])
-    assert max(w[0] for w in worst) < 9e-2, worst
+    assert max(w[0] for w in worst) < 7.5e-2, worst          # measured 5.4e-2 / 4.6e-2 / 5.6e-2
     assert worst[-1][0] < 1.5 * worst[0][0] + 1e-2, worst          # no growth along the trajectory
