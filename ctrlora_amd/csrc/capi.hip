@@ -21,7 +21,7 @@ static GemmParams base_params() {
 
 extern "C" {
 
-int cl_abi_version(void) { return 4; }
+int cl_abi_version(void) { return 5; }
 int cl_last_hip_error(void) { return g_last_hip_error; }
 const char* cl_last_hip_error_string(void) { return hipGetErrorString((hipError_t)g_last_hip_error); }
 
@@ -44,6 +44,7 @@ int cl_gemm_tune_size(void) { return gemm_tune_size(); }
 int cl_attention_force_variant(int v) {
   if (v == 16 || v == 17) { g_attn_fuse_delta = v == 17; return CL_OK; }   // 16 / 17: separate / fused delta (A/B hook)
   if (v == 32 || v == 33) { g_gn_three_pass = v == 32; return CL_OK; }      // 32 / 33: three- / two-launch GroupNorm (A/B hook)
+  if (v == 34 || v == 35) { g_gn_one_pass = v == 35; return CL_OK; }        // 34 / 35: without / with the one-launch GroupNorm (A/B hook)
   g_attn_variant = v; return CL_OK;
 }
 
@@ -58,6 +59,7 @@ int cl_gemm(const cl_gemm_params* p, int dtype, void* stream) {
   g.rowbias = p->rowbias; g.ldrb = p->ldrb; g.rows_per_batch = p->rows_per_batch;
   g.residual = p->residual; g.ldr = p->ldr; g.alpha = p->alpha; g.beta = p->beta; g.act = p->act;
   g.C = p->C; g.ldc = p->ldc; g.out_f32 = p->out_f32; g.atomic = p->atomic; g.splitk = p->splitk < 1 ? 1 : p->splitk;
+  g.a1_group_n = p->a1_group_n; g.a2_group_n = p->a2_group_n;
   return launch_gemm(g, dtype, S(stream));
 }
 

@@ -41,6 +41,12 @@ struct GemmParams {
   int out_f32;                         // store fp32 regardless of T
   int atomic;                          // fp32 atomicAdd into C (grad accumulation; caller may set splitk)
   int splitk;                          // atomic mode: K splits.  Otherwise chosen by the launcher (workspace slabs)
+  // Grouped K segments (linear mode): several LoRA linears that share their input run as ONE product whose output
+  // columns are the linears side by side.  Output columns [g * a2_group_n, (g+1) * a2_group_n) take their SECOND segment
+  // from columns [g * K2, (g+1) * K2) of A2 (q | k | v with their own x A^T); with a1_group_n the FIRST segment comes from
+  // columns [g * K1, (g+1) * K1) of A1 (u_g = dy_g B_g for all g in one launch).  0 = ungrouped.  A tile never straddles
+  // groups: the launcher only takes configurations whose BN divides the group width.
+  int a1_group_n, a2_group_n;
 };
 
 int launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);

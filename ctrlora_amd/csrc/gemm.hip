@@ -261,9 +261,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_kernel(GemmParams p, i
   for (int j = 0; j < AJ; ++j) {
     int r = m0 + (j * NW + wave) * 16 + lrow;
     r = min(r, p.M - 1);
-    a2[j] = p.A2 ? (const char*)p.A2 + ((long)r * p.lda2) * sizeof(T) + lchk : nullptr;
+    a2[j] = p.A2 ? (const char*)p.A2 + ((long)r * p.lda2 + (p.a2_group_n ? (long)(n0 / p.a2_group_n) * p.K2 : 0)) * sizeof(T) + lchk
+                 : nullptr;
     if (p.mode == GEMM_LINEAR) {
-      a1[j] = (const char*)p.A1 + ((long)r * p.lda1) * sizeof(T) + lchk;
+      a1[j] = (const char*)p.A1 + ((long)r * p.lda1 + (p.a1_group_n ? (long)(n0 / p.a1_group_n) * p.K1 : 0)) * sizeof(T) + lchk;
       ab[j] = ay[j] = ax[j] = 0;
     } else {
       const int ox = r % p.Wout; const int t = r / p.Wout;
@@ -504,9 +505,11 @@ __device__ __forceinline__ void fl_tile(const GemmParams& p, int tiles_m, int ti
     a2[j] = nullptr; vmask[j] = 0; ab[j] = ay[j] = ax[j] = 0;
     if constexpr (MODE == FL_LINEAR) {
       const bool in2 = kbeg >= ks1;
-      a2[j] = p.A2 ? (const char*)p.A2 + ((long)r * p.lda2) * sizeof(T) + chunk : nullptr;
+      a2[j] = p.A2 ? (const char*)p.A2 + ((long)r * p.lda2 + (p.a2_group_n ? (long)(n0 / p.a2_group_n) * p.K2 : 0)) * sizeof(T) + chunk
+                   : nullptr;
       pa[j] = in2 ? a2[j] + (long)(kbeg - ks1) * 128
-                  : (const char*)p.A1 + ((long)r * p.lda1) * sizeof(T) + chunk + (long)kbeg * 128;
+                  : (const char*)p.A1 + ((long)r * p.lda1 + (p.a1_group_n ? (long)(n0 / p.a1_group_n) * p.K1 : 0)) * sizeof(T) +
+                        chunk + (long)kbeg * 128;
     } else {
       const int ox = r % p.Wout; const int t = r / p.Wout;
       const int oy = t % p.Hout, ob = t / p.Hout;
@@ -977,6 +980,7 @@ static int launch_cfg(const GemmParams& p0, hipStream_t stream) {
       return CL_ELAUNCH;
     attr_set = true;
   }
+  if ((p0.a1_group_n && p0.a1_group_n % BN) || (p0.a2_group_n && p0.a2_group_n % BN)) return CL_EINVAL;   // a tile would straddle groups
   GemmParams p = p0;
   const int kpb = 64 / (int)sizeof(T);
   const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
@@ -1077,6 +1081,7 @@ static int launch_fl_mode(const GemmParams& p0, hipStream_t stream) {
       return CL_ELAUNCH;
     attr_set = true;
   }
+  if ((p0.a1_group_n && p0.a1_group_n % BN) || (p0.a2_group_n && p0.a2_group_n % BN)) return CL_EINVAL;   // a tile would straddle groups
   GemmParams p = p0;
   const int kps = 128 / (int)sizeof(T);
   const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
@@ -1185,6 +1190,28 @@ static int launch_t_cfg(const GemmParams& p, hipStream_t stream, int cfg) {
     }
     if (p.act == ACT_GEGLU && cfg != 16 && cfg != 20) cfg = 2;
   }
+  if (p.a1_group_n || p.a2_group_n) {
+    // grouped K segments: the tile width must divide every group width.  BN of the configuration that would actually run
+    // (the full-line forms fall back to the generic 128 x 128 tile when K is not whole 128-byte lines)
+    const int kps = 128 / (int)sizeof(T);
+    const bool lines = p.K1 % kps == 0 && p.K2 % kps == 0;
+    auto bn_of = [&](int c) {
+      switch (c) {
+        case 0: case 24: return 64;
+        case 1: case 6: case 7: case 22: return 128;
+        case 2: case 3: case 4: case 5: case 23: return 160;
+        default: return lines ? ((c == 8 || c == 12 || c == 14 || c == 16 || c == 18 || c == 20 || c == 10 || c == 25 || c == 27 || c == 29) ? 160 : 128) : 128;
+      }
+    };
+    auto fits = [&](int bn) { return (!p.a1_group_n || p.a1_group_n % bn == 0) && (!p.a2_group_n || p.a2_group_n % bn == 0); };
+    if (!fits(bn_of(cfg))) {
+      const bool big = p.M > 128 && lines && !p.atomic;
+      if (fits(160)) cfg = big ? (p.M >= 8192 ? 16 : 20) : 2;
+      else if (fits(128)) cfg = big ? (p.M >= 8192 ? 17 : 21) : 1;
+      else if (fits(64)) cfg = 0;
+      else return CL_EINVAL;
+    }
+  }
   switch (cfg) {
     case 0: return launch_cfg<T, 64, 64, 2, 2, 1, 4>(p, stream);
     case 1: return launch_cfg<T, 128, 128, 2, 2, 2, 4>(p, stream);
@@ -1267,6 +1294,10 @@ int launch_gemm(const GemmParams& p, int dtype, hipStream_t stream) {
   if (p.atomic == 0 && p.splitk > 1) return CL_EINVAL;
   if (p.rowbias && p.rows_per_batch <= 0) return CL_EINVAL;
   if (p.act == ACT_GEGLU && (p.N % 160 || p.rowbias || p.residual || p.atomic || p.alpha != 1.0f)) return CL_EINVAL;
+  if (p.a1_group_n < 0 || p.a2_group_n < 0) return CL_EINVAL;
+  if ((p.a1_group_n || p.a2_group_n) && p.mode != GEMM_LINEAR) return CL_EINVAL;
+  if (p.a1_group_n && p.N % p.a1_group_n) return CL_EINVAL;
+  if (p.a2_group_n && (p.N % p.a2_group_n || !p.K2)) return CL_EINVAL;
   return dtype == CL_BF16 ? launch_t<bf16_t>(p, stream) : launch_t<float>(p, stream);
 }
 

@@ -5,6 +5,7 @@
 namespace cl {
 
 extern int g_gn_three_pass;   // A/B hook: 1 = partial -> finalize -> apply for every GroupNorm
+extern int g_gn_one_pass;     // A/B hook: 0 = never the one-launch register-resident form
 
 struct GnArgs {
   const void* x; long ldx;      // [B*HW, C] token-major (NHWC), row stride ldx

@@ -275,12 +275,284 @@ __global__ void gn_gapply_kernel(const T* __restrict__ x, long ldx, T* __restric
 
 int g_gn_three_pass = 0;   // A/B hook: 1 = always the partial -> finalize -> apply form
 
+// ------------------------------------------------------------------ one-launch GroupNorm (register-resident slab)
+// At the 32x32 / 16x16 / 8x8 levels the two-launch form above is bound by launch and dependency latency, not bytes:
+// both of its kernels last ~9 us whatever the tensor size (88 forward + 61 backward GroupNorms per training step).
+// Here ONE workgroup owns (sample b, channel block of CB = lcm(C / G, 8) channels = whole groups, 16-byte aligned) and
+// keeps the block's [HW][CB] slab in registers between the statistics and the apply: the tensor is read once and written
+// once, in one launch (the forward stores mean / rstd for the backward as before).  Lanes are laid out LPR (8 or 16) per
+// pixel row -- CB / 8 of them active -- so that the per-channel sums reduce over the pixels of a wave with shuffles and
+// over the waves through a small LDS array.  Taken when the grid (B * C / CB workgroups of up to 1024 threads) is at
+// least GN1_MIN_WG and the slab fits NV vectors per lane; everything else (the 64x64 level, whose groups span 4096
+// pixels) stays on the two-launch form.  The backward handles trainable norms too (dgamma / dbeta: one float atomic per
+// channel and sample, as the three-launch form did).
+static constexpr int GN1_MIN_WG = 96;
+int g_gn_one_pass = 1;        // A/B hook (cl_attention_force_variant(34 / 35)): 0 = never take the one-launch form
+
+template <typename T> struct Pack8;
+template <> struct Pack8<bf16_t> {
+  uint4 v;
+  __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void get(float f[8]) const {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+  }
+};
+template <> struct Pack8<float> {
+  float4 a, b;
+  __device__ __forceinline__ void load(const float* p) { a = reinterpret_cast<const float4*>(p)[0]; b = reinterpret_cast<const float4*>(p)[1]; }
+  __device__ __forceinline__ void get(float f[8]) const {
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+  }
+};
+
+struct Gn1Geom { int CB, VX, LPR, NW, NV, nblk; bool ok; };
+
+static Gn1Geom gn1_geom(int B, int HW, int C, int G, int esize, bool bwd) {
+  Gn1Geom g{}; g.ok = false;
+  if (!g_gn_one_pass || g_gn_three_pass || C % G) return g;
+  const int cg = C / G;
+  int cb = cg;
+  while (cb % 8) cb += cg;                 // lcm(cg, 8)
+  if (cb > 128 || C % cb) return g;
+  g.CB = cb; g.VX = cb / 8; g.LPR = g.VX <= 8 ? 8 : 16;
+  const int ppw = 64 / g.LPR;
+  // forward: up to 16 waves (128 VGPRs per lane); backward: up to 8 waves (256 VGPRs: x AND dy stay in registers next to
+  // ~80 registers of per-channel coefficients)
+  const int maxw = bwd ? 8 : 16;
+  int nw = (HW + ppw - 1) / ppw; if (nw > maxw) nw = maxw;
+  g.NW = nw;
+  const int per_iter = nw * ppw;
+  const int nv = (HW + per_iter - 1) / per_iter;
+  g.NV = nv <= 1 ? 1 : nv <= 2 ? 2 : nv <= 4 ? 4 : nv <= 8 ? 8 : 16;
+  g.nblk = C / cb;
+  g.ok = nv <= (esize == 2 ? 16 : 8) && (long)g.nblk * B >= GN1_MIN_WG;
+  return g;
+}
+
+// per-channel sums of two quantities over the workgroup's pixels; result valid for lanes / threads that read chs afterwards
+//   s[e], q[e]: this lane's sums for its 8 channels (lane % LPR = vector index; inactive lanes hold zeros)
+__device__ __forceinline__ void gn1_block_channel_sums(float s[8], float q[8], int LPR, int NW, float* red /*[NW][16][16]*/,
+                                                       float* chs /*[128][2]*/, int VX) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o >= 8; o >>= 1) {
+    if (o >= LPR) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] += __shfl_xor(s[e], o, 64); q[e] += __shfl_xor(q[e], o, 64); }
+    }
+  }
+  if (lane < LPR) {
+    float* r = red + (wave * 16 + lane) * 16;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { r[e] = s[e]; r[8 + e] = q[e]; }
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < VX * 8) {                        // one thread per channel of the block
+    const int vx = t >> 3, e = t & 7;
+    float a = 0.f, b = 0.f;
+    for (int w = 0; w < NW; ++w) { a += red[(w * 16 + vx) * 16 + e]; b += red[(w * 16 + vx) * 16 + 8 + e]; }
+    chs[2 * t] = a; chs[2 * t + 1] = b;
+  }
+  __syncthreads();
+}
+
+template <typename T, bool SILU, int NV>
+__global__ __launch_bounds__(1024) void gn1_fwd_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy, int HW,
+                                                       int C, int G, int CB, int VX, int LPR, int NW, float eps,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ stats) {
+  __shared__ float red[16 * 16 * 16];
+  __shared__ float chs[128 * 2];
+  __shared__ float gst[16 * 2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int vx = lane % LPR, pl = lane / LPR, ppw = 64 / LPR;
+  const int b = blockIdx.y, c0 = blockIdx.x * CB, cg = C / G;
+  const bool act = vx < VX;
+  const int step = NW * ppw;
+  Pack8<T> d[NV];
+  float s[8], q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int p = wave * ppw + pl + i * step;
+    if (act && p < HW) d[i].load(x + ((long)b * HW + p) * ldx + c0 + vx * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int p = wave * ppw + pl + i * step;
+    if (act && p < HW) {
+      float f[8]; d[i].get(f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+    }
+  }
+  gn1_block_channel_sums(s, q, LPR, NW, red, chs, VX);
+  const int ng = CB / cg;
+  if ((int)threadIdx.x < ng) {
+    double S = 0, Q = 0;
+    for (int c = threadIdx.x * cg; c < (threadIdx.x + 1) * cg; ++c) { S += chs[2 * c]; Q += chs[2 * c + 1]; }
+    const double n = (double)HW * cg, mean = S / n;
+    double var = Q / n - mean * mean;
+    if (var < 0) var = 0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    gst[2 * threadIdx.x] = (float)mean; gst[2 * threadIdx.x + 1] = (float)rstd;
+    const int gg = c0 / cg + threadIdx.x;
+    stats[((long)b * G + gg) * 2] = (float)mean;
+    stats[((long)b * G + gg) * 2 + 1] = (float)rstd;
+  }
+  __syncthreads();
+  if (!act) return;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int cl = vx * 8 + e, gi = cl / cg;
+    const double scd = (double)gst[2 * gi + 1] * (double)gamma[c0 + cl];
+    sc[e] = (float)scd;
+    sh[e] = (float)((double)beta[c0 + cl] - (double)gst[2 * gi] * scd);
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int p = wave * ppw + pl + i * step;
+    if (p < HW) {
+      float f[8]; d[i].get(f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float z = f[e] * sc[e] + sh[e];
+        f[e] = SILU ? silu_f(z) : z;
+      }
+      store8(y + ((long)b * HW + p) * ldy + c0 + vx * 8, f);
+    }
+  }
+}
+
+template <typename T, bool SILU, int NV>
+__global__ __launch_bounds__(512) void gn1_bwd_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy, long lddy,
+                                                       const T* __restrict__ accum, long ldacc, T* __restrict__ dx, long lddx,
+                                                       int HW, int C, int G, int CB, int VX, int LPR, int NW,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ stats, float* __restrict__ dgamma,
+                                                       float* __restrict__ dbeta) {
+  __shared__ float red[16 * 16 * 16];
+  __shared__ float chs[128 * 2];
+  __shared__ float gst[16 * 2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int vx = lane % LPR, pl = lane / LPR, ppw = 64 / LPR;
+  const int b = blockIdx.y, c0 = blockIdx.x * CB, cg = C / G;
+  const bool act = vx < VX;
+  const int step = NW * ppw;
+  Pack8<T> dxv[NV], ddv[NV];
+  float ga[8], be[8], mu[8], rs[8], s[8], q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int cl = (act ? vx : 0) * 8 + e, gi = (c0 + cl) / cg;
+    ga[e] = gamma[c0 + cl]; be[e] = beta[c0 + cl];
+    mu[e] = stats[((long)b * G + gi) * 2]; rs[e] = stats[((long)b * G + gi) * 2 + 1];
+    s[e] = 0.f; q[e] = 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int p = wave * ppw + pl + i * step;
+    if (act && p < HW) {
+      dxv[i].load(x + ((long)b * HW + p) * ldx + c0 + vx * 8);
+      ddv[i].load(dy + ((long)b * HW + p) * lddy + c0 + vx * 8);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int p = wave * ppw + pl + i * step;
+    if (act && p < HW) {
+      float f[8], d[8]; dxv[i].get(f); ddv[i].get(d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (f[e] - mu[e]) * rs[e];
+        float dz = d[e];
+        if (SILU) dz *= dsilu_f(xh * ga[e] + be[e]);
+        s[e] += dz; q[e] += dz * xh;
+      }
+    }
+  }
+  gn1_block_channel_sums(s, q, LPR, NW, red, chs, VX);
+  const int ng = CB / cg;
+  if (dgamma && (int)threadIdx.x < CB) {
+    atomicAdd(dgamma + c0 + threadIdx.x, chs[2 * threadIdx.x + 1]);
+    atomicAdd(dbeta + c0 + threadIdx.x, chs[2 * threadIdx.x]);
+  }
+  if ((int)threadIdx.x < ng) {
+    double s1 = 0, s2 = 0;
+    for (int c = threadIdx.x * cg; c < (threadIdx.x + 1) * cg; ++c) {
+      s1 += (double)gamma[c0 + c] * chs[2 * c]; s2 += (double)gamma[c0 + c] * chs[2 * c + 1];
+    }
+    gst[2 * threadIdx.x] = (float)s1; gst[2 * threadIdx.x + 1] = (float)s2;   // gamma-weighted group sums
+  }
+  __syncthreads();
+  if (!act) return;
+  const double n = (double)HW * cg;
+  float k1[8], k2[8], k3[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int cl = vx * 8 + e, gi = cl / cg;
+    const double rstd = rs[e];
+    k1[e] = (float)(rstd * ga[e]);
+    k2[e] = (float)(rstd * (double)gst[2 * gi] / n);
+    k3[e] = (float)(rstd * (double)gst[2 * gi + 1] / n);
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int p = wave * ppw + pl + i * step;
+    if (p < HW) {
+      float f[8], d[8], ac[8]; dxv[i].get(f); ddv[i].get(d);
+      const long row = (long)b * HW + p;
+      if (accum) load8(accum + row * ldacc + c0 + vx * 8, ac);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (f[e] - mu[e]) * rs[e];
+        float dz = d[e];
+        if (SILU) dz *= dsilu_f(xh * ga[e] + be[e]);
+        float r = dz * k1[e] - k2[e] - xh * k3[e];
+        if (accum) r += ac[e];
+        f[e] = r;
+      }
+      store8(dx + row * lddx + c0 + vx * 8, f);
+    }
+  }
+}
+
+template <typename T, bool SILU>
+static void gn1_fwd_launch(const GnArgs& a, const Gn1Geom& g, hipStream_t st) {
+  dim3 grid(g.nblk, a.B), blk(g.NW * 64);
+#define GN1F(N_) hipLaunchKernelGGL((gn1_fwd_kernel<T, SILU, N_>), grid, blk, 0, st, (const T*)a.x, a.ldx, (T*)a.y, a.ldy, a.HW, a.C, \
+                                    a.G, g.CB, g.VX, g.LPR, g.NW, a.eps, a.gamma, a.beta, a.stats)
+  switch (g.NV) { case 1: GN1F(1); break; case 2: GN1F(2); break; case 4: GN1F(4); break; case 8: GN1F(8); break; default: GN1F(16); }
+#undef GN1F
+}
+
+template <typename T, bool SILU>
+static void gn1_bwd_launch(const GnBwdArgs& a, const Gn1Geom& g, hipStream_t st) {
+  dim3 grid(g.nblk, a.B), blk(g.NW * 64);
+#define GN1B(N_) hipLaunchKernelGGL((gn1_bwd_kernel<T, SILU, N_>), grid, blk, 0, st, (const T*)a.x, a.ldx, (const T*)a.dy, a.lddy,  \
+                                    (const T*)a.accum, a.ldacc, (T*)a.dx, a.lddx, a.HW, a.C, a.G, g.CB, g.VX, g.LPR, g.NW, a.gamma, \
+                                    a.beta, a.stats, a.dgamma, a.dbeta)
+  switch (g.NV) { case 1: GN1B(1); break; case 2: GN1B(2); break; case 4: GN1B(4); break; case 8: GN1B(8); break; default: GN1B(16); }
+#undef GN1B
+}
+
 static bool gn_two_pass_ok(const GnGeom& g, int C, int G) {
   return !g_gn_three_pass && C / 8 == g.VX && G <= 64 && g.threads >= G && g.threads >= 64;
 }
 
 template <typename T>
 static int gn_fwd_t(const GnArgs& a, hipStream_t st) {
+  const Gn1Geom g1 = gn1_geom(a.B, a.HW, a.C, a.G, (int)sizeof(T), false);
+  if (g1.ok) {
+    if (a.silu) gn1_fwd_launch<T, true>(a, g1, st); else gn1_fwd_launch<T, false>(a, g1, st);
+    CL_CHECK_LAUNCH();
+    return CL_OK;
+  }
   const GnGeom g = gn_geom(a.B, a.HW, a.C);
   if (gn_two_pass_ok(g, a.C, a.G)) {
     dim3 grid(g.nchunk, a.B);
@@ -561,6 +833,12 @@ __global__ void gn_bwd_gapply_kernel(const T* __restrict__ x, long ldx, const T*
 
 template <typename T>
 static int gn_bwd_t(const GnBwdArgs& a, hipStream_t st) {
+  const Gn1Geom g1 = gn1_geom(a.B, a.HW, a.C, a.G, (int)sizeof(T), true);
+  if (g1.ok) {
+    if (a.silu) gn1_bwd_launch<T, true>(a, g1, st); else gn1_bwd_launch<T, false>(a, g1, st);
+    CL_CHECK_LAUNCH();
+    return CL_OK;
+  }
   const GnGeom g = gn_geom(a.B, a.HW, a.C);
   if (!a.dgamma && gn_two_pass_ok(g, a.C, a.G)) {
     dim3 grid(g.nchunk, a.B);

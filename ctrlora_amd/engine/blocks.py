@@ -141,6 +141,19 @@ def linear_fwd(ctx: Ctx, L: LinearW, x, out=None, residual=None, act=hip.ACT_NON
     return out, t
 
 
+def group_fwd(ctx: Ctx, grp, x):
+    """Every member of a packing.LoraGroup applied to x in two launches: (y [M, G N] (+ bias), t [M, G r] or None)."""
+    M = x.shape[0]
+    y = ctx.new(M, grp.G * grp.N)
+    if grp.Wm is not None and not ctx.record:              # inference executor: W + B A folded, one plain product
+        hip.gemm(x, grp.Wm, y, bias=grp.bias)
+        return y, None
+    t = ctx.new(M, grp.G * grp.r)
+    hip.gemm(x, grp.A, t)
+    hip.gemm(x, grp.W, y, a2=t, w2=grp.B, bias=grp.bias, a2_group_n=grp.N)
+    return y, t
+
+
 def linear_bwd_data(ctx: Ctx, L: LinearW, dy, out=None, accum=None):
     """dx = dy W + (dy B) A (+ accum).  Returns (dx, u = dy B or None)."""
     M = dy.shape[0]
@@ -302,8 +315,8 @@ class ResBlockE:
     def fwd(self, ctx: Ctx, x, semb, B, H, W, out=None, e_pre=None):
         HW = H * W
         h1, st1 = self.gn1.fwd(ctx, x, B, HW)
-        if e_pre is not None:                                             # frozen UNet: formed with all the others
-            e_out, t_e = e_pre, None
+        if e_pre is not None:                                             # formed with all the others at the start of the pass
+            e_out, t_e = e_pre if isinstance(e_pre, tuple) else (e_pre, None)
         else:
             e_out, t_e = linear_fwd(ctx, self.emb, semb)                  # [B, cout]
         h2 = conv3_fwd(ctx, self.conv1, h1, B, H, W, rowbias=e_out)       # + bias + emb (openaimodel.py:272)
@@ -357,8 +370,9 @@ class AttnE:
     used when there is no LoRA (frozen UNet): one GEMM instead of three."""
 
     def __init__(self, to_q: LinearW, to_k: LinearW, to_v: LinearW, to_out: LinearW, heads: int, is_self: bool,
-                 fused_qkv: Optional[LinearW] = None, fused_kv: Optional[LinearW] = None, need_kv_grad=True):
+                 fused_qkv: Optional[LinearW] = None, fused_kv: Optional[LinearW] = None, need_kv_grad=True, group=None):
         self.q, self.k, self.v, self.o = to_q, to_k, to_v, to_out
+        self.group = group       # packing.LoraGroup over (q, k, v) [self] or (k, v) [cross]: grouped LoRA launches
         self.heads, self.is_self = heads, is_self
         self.fused_qkv, self.fused_kv = fused_qkv, fused_kv
         self.need_kv_grad = need_kv_grad
@@ -366,11 +380,34 @@ class AttnE:
         self.dh = self.inner // heads
         self.scale = float(self.dh) ** -0.5
 
+    def _group_fwd(self, ctx: Ctx, x):
+        return group_fwd(ctx, self.group, x)
+
+    def _group_bwd(self, ctx: Ctx, dy, need_dx: bool, accum=None):
+        """dy [M, G N] -> (dx [M, K] (+ accum) or None, u [M, G r])."""
+        grp = self.group
+        M = dy.shape[0]
+        u = ctx.new(M, grp.G * grp.r)
+        if grp.r % 64 == 0:
+            hip.gemm(dy, grp.Bt, u, k1=grp.N, a1_group_n=grp.r)
+        else:                                 # rank below the narrowest tile: one small product per member
+            for g, L in enumerate(grp.members):
+                hip.gemm(dy[:, g * grp.N:(g + 1) * grp.N], L.Bt, u[:, g * grp.r:(g + 1) * grp.r])
+        dx = None
+        if need_dx:
+            dx = ctx.new(M, grp.K)
+            hip.gemm(dy, grp.Wt, dx, a2=u, w2=grp.At, residual=accum, beta=1.0 if accum is not None else 0.0)
+        return dx, u
+
     def project_context(self, ctx: Ctx, c):
         """K / V projections of the text context (identical for every denoising step)."""
         if self.fused_kv is not None:
             kv, _ = linear_fwd(ctx, self.fused_kv, c)
             return kv[:, :self.inner], kv[:, self.inner:], None, None
+        if self.group is not None and not self.is_self:
+            kv, t = self._group_fwd(ctx, c)
+            r = self.group.r
+            return (kv[:, :self.inner], kv[:, self.inner:], None if t is None else t[:, :r], None if t is None else t[:, r:])
         k, tk = linear_fwd(ctx, self.k, c)
         v, tv = linear_fwd(ctx, self.v, c)
         return k, v, tk, tv
@@ -382,6 +419,12 @@ class AttnE:
             if self.fused_qkv is not None:
                 qkv, _ = linear_fwd(ctx, self.fused_qkv, xn)
                 q, k, v = qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:]
+            elif self.group is not None:
+                qkv, t = self._group_fwd(ctx, xn)
+                q, k, v = qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:]
+                if t is not None:
+                    r = self.group.r
+                    tq, tk, tv = t[:, :r], t[:, r:2 * r], t[:, 2 * r:]
             else:
                 q, tq = linear_fwd(ctx, self.q, xn)
                 k, tk = linear_fwd(ctx, self.k, xn)
@@ -416,13 +459,19 @@ class AttnE:
         base_bwd_weight(ctx, self.o, a, dout)
         delta = torch.empty_like(lse)
         want_kv = self.is_self or self.need_kv_grad
-        if self.is_self and self.fused_qkv is not None:
+        grouped = self.group is not None and ctx.dtype == torch.bfloat16
+        dkv = None
+        if self.is_self and (self.fused_qkv is not None or grouped):
             dqkv = ctx.new(B * N, 3 * inner)
             dq, dk, dv = dqkv[:, :inner], dqkv[:, inner:2 * inner], dqkv[:, 2 * inner:]
         else:
             dq = ctx.new(B * N, inner)
-            dk = ctx.new(B * Nkv, inner) if want_kv else None
-            dv = ctx.new(B * Nkv, inner) if want_kv else None
+            if want_kv and grouped:
+                dkv = ctx.new(B * Nkv, 2 * inner)
+                dk, dv = dkv[:, :inner], dkv[:, inner:]
+            else:
+                dk = ctx.new(B * Nkv, inner) if want_kv else None
+                dv = ctx.new(B * Nkv, inner) if want_kv else None
         if ctx.dtype == torch.bfloat16:
             hip.attention_bwd_v2(q, k, v, a, da, lse, delta, dq, dk, dv, B, H, N, Nkv, self.dh, self.scale)
         else:
@@ -439,6 +488,13 @@ class AttnE:
             if self.fused_qkv is not None:
                 dxn, _ = linear_bwd_data(ctx, self.fused_qkv, dqkv, accum=accum_xn)
                 return dxn
+            if grouped:
+                dxn, u = self._group_bwd(ctx, dqkv, True, accum=accum_xn)
+                r = self.group.r
+                for i, (L, d, t_) in enumerate(((self.q, dq, tq), (self.k, dk, tk), (self.v, dv, tv))):
+                    linear_bwd_lora(ctx, L, xn, t_, d, u[:, i * r:(i + 1) * r])
+                    base_bwd_weight(ctx, L, xn, d)
+                return dxn
             dxn, uq = linear_bwd_data(ctx, self.q, dq, accum=accum_xn)
             linear_bwd_lora(ctx, self.q, xn, tq, dq, uq)
             _, uk = linear_bwd_data(ctx, self.k, dk, out=dxn, accum=dxn)
@@ -451,7 +507,12 @@ class AttnE:
         dxn, uq = linear_bwd_data(ctx, self.q, dq, accum=accum_xn)
         linear_bwd_lora(ctx, self.q, xn, tq, dq, uq)
         base_bwd_weight(ctx, self.q, xn, dq)
-        if want_kv and self.k.r:
+        if want_kv and self.k.r and dkv is not None:
+            _, u = self._group_bwd(ctx, dkv, False)
+            r = self.group.r
+            linear_bwd_lora(ctx, self.k, c, tk, dk, u[:, :r])
+            linear_bwd_lora(ctx, self.v, c, tv, dv, u[:, r:])
+        elif want_kv and self.k.r:
             # context is an input (no data gradient needed), only the LoRA factors of to_k / to_v train
             uk = ctx.new(B * Nkv, self.k.r); hip.gemm(dk, self.k.Bt, uk)
             linear_bwd_lora(ctx, self.k, c, tk, dk, uk)

@@ -26,8 +26,8 @@ import torch
 
 from .. import hip
 from .blocks import (AttnE, Ctx, ResBlockE, SpatialTransformerE, base_bwd_weight, conv3_bwd_data, conv3_bwd_weight,
-                     conv3_fwd, dense_bwd_weight, linear_bwd_data, linear_bwd_lora, linear_fwd)
-from .packing import Conv3W, LinearW, NormW, TrainableSet, rup
+                     conv3_fwd, dense_bwd_weight, group_fwd, linear_bwd_data, linear_bwd_lora, linear_fwd)
+from .packing import Conv3W, LinearW, LoraGroup, NormW, TrainableSet, rup
 
 
 @dataclass(frozen=True)
@@ -54,6 +54,10 @@ class NetCfg:
                       num_heads=p["num_heads"], context_dim=p["context_dim"])
 
 
+# A/B switch: CTRLORA_GROUP_LORA=0 keeps one launch per LoRA linear
+GROUP_LORA = os.environ.get("CTRLORA_GROUP_LORA", "1") != "0"
+
+
 def is_trainable_name(n: str) -> bool:
     """Name filter of ControlFinetuneLDM.configure_optimizers (cldm_ctrlora_finetune.py:92-101)."""
     return ("lora_layer" in n) or ("zero_convs" in n) or ("middle_block_out" in n) or ("norm" in n)
@@ -69,6 +73,7 @@ class _Builder:
         self.tr_lora = lora_set if lora_set is not None else trainables
         self.train_all = train_all
         self.fold_lora = False       # set by ControlNetE before building: LoRA linears keep their fp32 base weight
+        self.groups: List[LoraGroup] = []
         self.linears: List[LinearW] = []
         self.norms: List[NormW] = []
         self.convs: List[Conv3W] = []
@@ -165,8 +170,15 @@ class _Builder:
         if not lora:   # frozen UNet: one GEMM for q|k|v and for the context's k|v
             fq = self.fused([f"{tb}.attn1.to_q", f"{tb}.attn1.to_k", f"{tb}.attn1.to_v"])
             fkv = self.fused([f"{tb}.attn2.to_k", f"{tb}.attn2.to_v"])
-        attn1 = AttnE(a1[0], a1[1], a1[2], a1[3], heads, True, fused_qkv=fq)
-        attn2 = AttnE(a2[0], a2[1], a2[2], a2[3], heads, False, fused_kv=fkv, need_kv_grad=lora)
+        g1 = g2 = None
+        if lora and GROUP_LORA and self.dtype != torch.float32 and all(L.r for L in a1[:3] + a2[1:3]):
+            # q | k | v (and the context's k | v) share their input: grouped launches (packing.LoraGroup)
+            g1, g2 = LoraGroup(a1[:3]), LoraGroup(a2[1:3])
+            if self.fold_lora:
+                g1.enable_merge(); g2.enable_merge()
+            self.groups += [g1, g2]
+        attn1 = AttnE(a1[0], a1[1], a1[2], a1[3], heads, True, fused_qkv=fq, group=g1)
+        attn2 = AttnE(a2[0], a2[1], a2[2], a2[3], heads, False, fused_kv=fkv, need_kv_grad=lora, group=g2)
         return SpatialTransformerE(norm, proj_in, ln1, attn1, ln2, attn2, ln3, ff_proj, ff_out, proj_out)
 
 
@@ -174,7 +186,7 @@ class _Builder:
 
 class _Env:
     """Mutable per-pass state threaded through the layers."""
-    __slots__ = ("B", "H", "W", "semb", "c", "Nkv", "dsemb", "emb_grads", "kv", "emb_all", "kv_all")
+    __slots__ = ("B", "H", "W", "semb", "c", "Nkv", "dsemb", "emb_grads", "kv", "emb_all", "kv_all", "emb_pre")
 
     def __init__(self, B, H, W, semb, c, Nkv):
         self.B, self.H, self.W, self.semb, self.c, self.Nkv = B, H, W, semb, c, Nkv
@@ -183,6 +195,7 @@ class _Env:
         self.kv = None
         self.emb_all = None      # frozen UNet: every ResBlock's emb_layers output, one product [B, sum cout]
         self.kv_all = None       # frozen UNet: every cross-attention's K / V of the context, one product
+        self.emb_pre = None      # ControlNet: {id(_Res): (emb_layers output, x A^T)} formed by grouped launches up front
 
 
 class _Res:
@@ -193,7 +206,9 @@ class _Res:
 
     def fwd(self, ctx, x, env, out=None):
         pre = None
-        if env.emb_all is not None and self.emb_off is not None:
+        if env.emb_pre is not None:
+            pre = env.emb_pre.get(id(self))
+        elif env.emb_all is not None and self.emb_off is not None:
             pre = env.emb_all[:, self.emb_off:self.emb_off + self.cout]
         return self.blk.fwd(ctx, x, env.semb, env.B, env.H, env.W, out=out, e_pre=pre)
 
@@ -368,6 +383,20 @@ class ControlNetE:
             marks.append(len(self.tr.items))
 
         self.blocks, self.chans, self.mid, _ = _encoder_layers(b, cfg, lora=True, after_block=after_block)
+        # The ResBlocks' emb_layers (LoRA'd Linear on silu(emb), M = batch) depend on nothing but the time embedding: the ones
+        # of equal width run as ONE grouped LoRA product at the start of the trunk (2 launches per width instead of 2 per block)
+        self.emb_groups = []
+        if self.lora and GROUP_LORA and dtype != torch.float32 and not train_all:   # (trainable biases alias the flat masters)
+            by_n: Dict[int, list] = {}
+            for l in [l for blk in list(self.blocks) + [self.mid] for l in blk if isinstance(l, _Res)]:
+                if l.blk.emb.r:
+                    by_n.setdefault(l.blk.emb.N, []).append(l)
+            for n_, ls in sorted(by_n.items()):
+                if len(ls) >= 2 and n_ % 64 == 0:
+                    grp = LoraGroup([l.blk.emb for l in ls])
+                    if self.merge_lora:
+                        grp.enable_merge()
+                    self.emb_groups.append((grp, ls))
         stage_items = [self.tr.items[marks[i]:marks[i + 1]] for i in range(len(marks) - 1)]
         time_items = self.tr.items[:marks[0]]
         # flat buffer in backward-completion order: middle stage first, time_embed last
@@ -426,8 +455,9 @@ class ControlNetE:
                 prefix.append(prefix[-1] + ((R + 31) // 32) * ((C + 31) // 32))
 
             def mat(t, R, C, dst, dstT):
+                # explicit row strides: members of a LoraGroup are views of the group's buffers
                 add([t.offset, (R << 32) | C, 0 if dst is None else dst.data_ptr(), 0 if dstT is None else dstT.data_ptr(),
-                     0, 0, 0, 0])
+                     0, 0 if dst is None else dst.stride(0), 0 if dstT is None else dstT.stride(0), 0])
 
             for L in self._b.linears:
                 if L.tA is not None and ts.by_name.get(L.tA.name) is L.tA:
@@ -482,6 +512,13 @@ class ControlNetE:
         semb, tsv = self.time.fwd(ctx, t)
         env = _Env(B, H, W, semb, c, c.shape[0] // B)
         env.kv = kv
+        if self.emb_groups:
+            env.emb_pre = {}
+            for grp, ls in self.emb_groups:
+                y, tt = group_fwd(ctx, grp, semb)
+                for i, l in enumerate(ls):
+                    env.emb_pre[id(l)] = (y[:, i * grp.N:(i + 1) * grp.N],
+                                          None if tt is None else tt[:, i * grp.r:(i + 1) * grp.r])
         h = hint_tok
         saved, hs, dims = [], [], []
         for k, layers in enumerate(self.blocks):

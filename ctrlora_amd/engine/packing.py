@@ -190,6 +190,57 @@ class LinearW:
                 self.bias = self.tb.master
 
 
+class LoraGroup:
+    """G LoRACompatibleLinears with the SAME input and shape (to_q | to_k | to_v of a self-attention, to_k | to_v of a
+    cross-attention: cldm/lora.py:285-291, attention.py:163-170) packed side by side, so that the G products run as grouped
+    launches (csrc/gemm.h: a2_group_n / a1_group_n) instead of G launches each:
+
+        forward    t   = x [A_1; ..; A_G]^T                        one down-projection launch, x read once
+                   y   = [x | t_g] . [W_g | B_g]^T  for all g      one launch, output [M, G N]
+        backward   u   = [dy_g B_g]_g                               one launch (first segment grouped)
+                   dx  = [dy | u] . [W_1^T .. W_G^T | A_1^T .. A_G^T]   one launch, K = G N + G r
+
+    The members' packed tensors become VIEWS of the group's buffers: re-packing (cl_repack writes through the members'
+    pointers with explicit row strides), reload_frozen and merge_lora keep working on the members."""
+
+    def __init__(self, members: "List[LinearW]"):
+        L0 = members[0]
+        assert all(L.N == L0.N and L.K == L0.K and L.r == L0.r and L.r > 0 for L in members)
+        assert all((L.bias is None) == (L0.bias is None) for L in members)
+        self.members = list(members)
+        # biases side by side (frozen fp32 vectors; members keep views so reload_frozen writes through)
+        self.bias = None
+        if L0.bias is not None:
+            self.bias = torch.cat([L.bias for L in members], 0).contiguous()
+            for g, L in enumerate(members):
+                L.bias = self.bias[g * L0.N:(g + 1) * L0.N]
+        G, N, K, r = len(members), L0.N, L0.K, L0.r
+        self.G, self.N, self.K, self.r = G, N, K, r
+        dev, dt_ = L0.W.device, L0.dtype
+        need_bwd = L0.Wt is not None
+        self.W = torch.cat([L.W for L in members], 0).contiguous()                       # [G N, K]
+        self.Wt = torch.cat([L.Wt for L in members], 1).contiguous() if need_bwd else None   # [K, G N]
+        self.A = torch.empty(G * r, K, dtype=dt_, device=dev)
+        self.At = torch.empty(K, G * r, dtype=dt_, device=dev)
+        self.B = torch.empty(G * N, r, dtype=dt_, device=dev)
+        self.Bt = torch.empty(G * r, N, dtype=dt_, device=dev)
+        self.Wm = None
+        for g, L in enumerate(members):
+            L.W = self.W[g * N:(g + 1) * N]
+            if need_bwd:
+                L.Wt = self.Wt[:, g * N:(g + 1) * N]
+            L.A, L.At = self.A[g * r:(g + 1) * r], self.At[:, g * r:(g + 1) * r]
+            L.B, L.Bt = self.B[g * N:(g + 1) * N], self.Bt[g * r:(g + 1) * r]
+            L.group = self
+
+    def enable_merge(self):
+        """Inference executors (W + B A folded): the members' merged weights live side by side -> ONE product for the group."""
+        if self.Wm is None:
+            self.Wm = torch.empty(self.G * self.N, self.K, dtype=self.members[0].dtype, device=self.W.device)
+            for g, L in enumerate(self.members):
+                L.Wm = self.Wm[g * self.N:(g + 1) * self.N]
+
+
 class Conv3W:
     """3x3 conv in implicit-GEMM form; channels padded to multiples of 32 where needed."""
 

@@ -47,6 +47,7 @@ class GemmParams(C.Structure):
         ("alpha", C.c_float), ("beta", C.c_float), ("act", C.c_int),
         ("C", C.c_void_p), ("ldc", C.c_long),
         ("out_f32", C.c_int), ("atomic", C.c_int), ("splitk", C.c_int),
+        ("a1_group_n", C.c_int), ("a2_group_n", C.c_int),
     ]
 
 
@@ -132,6 +133,8 @@ def lib():
             L.cl_attention_force_variant(16)
         if os.environ.get("CTRLORA_GN_THREE_PASS", "0") == "1":       # A/B switch: GroupNorm with the finalize launch
             L.cl_attention_force_variant(32)
+        if os.environ.get("CTRLORA_GN_ONE_PASS", "1") == "0":        # A/B switch: no one-launch (register-resident) GroupNorm
+            L.cl_attention_force_variant(34)
         if os.environ.get("CTRLORA_GEMM_TUNED", "1") != "0":
             load_gemm_table(os.environ.get("CTRLORA_GEMM_TABLE", GEMM_TABLE_PATH))
     return _lib
@@ -247,7 +250,7 @@ def zero_page(device) -> torch.Tensor:
 
 def gemm(a1, w1, out, *, a2=None, w2=None, bias=None, rowbias=None, rows_per_batch=0, residual=None,
          alpha=1.0, beta=0.0, act=ACT_NONE, mode=LINEAR, conv=None, k1=None, out_f32=False, atomic=False,
-         splitk=1, M=None, N=None, dtype=None):
+         splitk=1, M=None, N=None, dtype=None, a1_group_n=0, a2_group_n=0):
     """out[M,N] = act(a1.w1^T + a2.w2^T + bias + rowbias[m // rows_per_batch]) * alpha + beta * residual.
 
     a1: [M,K1] (LINEAR) or the NHWC activation [B*Hin*Win, C] (conv modes, conv=(B,Hin,Win,Hout,Wout)).
@@ -259,7 +262,8 @@ def gemm(a1, w1, out, *, a2=None, w2=None, bias=None, rowbias=None, rows_per_bat
     p.A1 = a1.data_ptr(); p.lda1 = ld(a1); p.K1 = a1.shape[1] if k1 is None else k1
     p.W1 = w1.data_ptr(); p.ldw1 = ld(w1)
     if a2 is not None:
-        p.A2 = a2.data_ptr(); p.lda2 = ld(a2); p.K2 = a2.shape[1]; p.W2 = w2.data_ptr(); p.ldw2 = ld(w2)
+        p.A2 = a2.data_ptr(); p.lda2 = ld(a2); p.W2 = w2.data_ptr(); p.ldw2 = ld(w2)
+        p.K2 = w2.shape[1] if a2_group_n else a2.shape[1]        # grouped: a2 holds one K2-wide block per output group
     p.M = out.shape[0] if M is None else M
     p.N = out.shape[1] if N is None else N
     p.mode = mode
@@ -274,6 +278,7 @@ def gemm(a1, w1, out, *, a2=None, w2=None, bias=None, rowbias=None, rows_per_bat
     p.alpha = alpha; p.beta = beta; p.act = act
     p.C = out.data_ptr(); p.ldc = ld(out)
     p.out_f32 = int(out_f32); p.atomic = int(atomic); p.splitk = splitk
+    p.a1_group_n = a1_group_n; p.a2_group_n = a2_group_n
     _chk(lib().cl_gemm(C.byref(p), dty, stream()), "cl_gemm")
     return out
 

@@ -98,6 +98,12 @@ typedef struct cl_gemm_params {
   int out_f32;                        /* store fp32 regardless of dtype                      */
   int atomic;                         /* fp32 atomicAdd into C (gradient accumulation)       */
   int splitk;                         /* K splits in atomic mode; otherwise chosen internally */
+  /* Grouped K segments (linear mode; ABI 5): G LoRA linears that share their input (to_q | to_k | to_v of one
+   * CrossAttention, cldm/lora.py:285-291 x3) as ONE product with the outputs side by side.  a2_group_n = width of one
+   * linear's output: columns [g*a2_group_n, (g+1)*a2_group_n) read their second segment from columns [g*K2, (g+1)*K2)
+   * of A2 (A2 = [x Aq^T | x Ak^T | x Av^T], W2 = [Bq; Bk; Bv]).  a1_group_n: the same for the FIRST segment
+   * (u = [dq Bq | dk Bk | dv Bv] from dy = [dq | dk | dv]: A1 columns [g*K1, (g+1)*K1)).  0 = ungrouped. */
+  int a1_group_n, a2_group_n;
 } cl_gemm_params;
 
 /* Generic entry; the named operators below are thin fillers of cl_gemm_params. */

@@ -291,3 +291,110 @@ def test_pretraining_bf16_error_is_flat_on_the_fp32_parameter_trajectory():
     _record("pretrain_bf16_on_fp32_trajectory", worst_per_step=[w[0] for w in worst], names=[w[1] for w in worst])
     assert max(w[0] for w in worst) < 7.5e-2, worst          # measured 5.4e-2 / 4.6e-2 / 5.6e-2
     assert worst[-1][0] < 1.5 * worst[0][0] + 1e-2, worst          # no growth along the trajectory
+
+
+# ------------------------------------------------------------------------------ grouped LoRA products (q | k | v in one launch)
+
+@pytest.mark.parametrize("M,K,N,r,G", [(32768, 320, 320, 128, 3), (8192, 640, 640, 128, 3), (2048, 1280, 1280, 128, 3),
+                                       (616, 768, 640, 128, 2), (616, 768, 320, 128, 2), (512, 1280, 1280, 128, 3),
+                                       (4096, 320, 320, 32, 3), (1000, 64, 64, 32, 2)])
+def test_grouped_lora_products_vs_fp64(M, K, N, r, G):
+    """cl_gemm with grouped K segments (csrc/gemm.h a2_group_n / a1_group_n): G LoRACompatibleLinears that share their input
+    (cldm/lora.py:285-291; to_q | to_k | to_v) as one forward launch, one u = [dy_g B_g] launch and one dx launch, vs fp64
+    on the same bf16 values, at the production shapes of the three attention levels, the text-context projections
+    (M = 8 x 77), rank 32 (second segment below a 128-byte line) and a tiny ragged case."""
+    _need_gpu()
+    from ctrlora_amd import hip
+    g = torch.Generator().manual_seed(M + N + r + G)
+    bf = lambda *s, sc=1.0: _bf(torch.randn(*s, generator=g) * sc).cuda()
+    x = bf(M, K)
+    W, A, Bm = bf(G * N, K, sc=K ** -0.5), bf(G * r, K, sc=K ** -0.5), bf(G * N, r, sc=0.05)
+    dy = bf(M, G * N, sc=0.1)
+    t = torch.empty(M, G * r, dtype=torch.bfloat16, device="cuda")
+    y = torch.empty(M, G * N, dtype=torch.bfloat16, device="cuda")
+    hip.gemm(x, A, t)
+    hip.gemm(x, W, y, a2=t, w2=Bm, a2_group_n=N)
+    x64, W64, A64, B64, dy64 = x.double(), W.double(), A.double(), Bm.double(), dy.double()
+    t64 = t.double()                                              # the kernel's own bf16 t (what the second segment reads)
+    y_ref = torch.cat([x64 @ W64[i * N:(i + 1) * N].T + t64[:, i * r:(i + 1) * r] @ B64[i * N:(i + 1) * N].T for i in range(G)], 1)
+    e_t = rel_l2(t, x64 @ A64.T)
+    e_y = rel_l2(y, y_ref)
+    # backward: u_g = dy_g B_g ; dx = sum_g dy_g W_g + u_g A_g
+    Bt = torch.cat([Bm[i * N:(i + 1) * N].t().contiguous() for i in range(G)], 0)        # [G r, N]
+    Wt = W.view(G, N, K).permute(2, 0, 1).reshape(K, G * N).contiguous()                  # [K, G N]
+    At = A.t().contiguous()                                                              # [K, G r]
+    u = torch.empty(M, G * r, dtype=torch.bfloat16, device="cuda")
+    e_u = None
+    if r % 64 == 0:
+        hip.gemm(dy, Bt, u, k1=N, a1_group_n=r)
+        u_ref = torch.cat([dy64[:, i * N:(i + 1) * N] @ B64[i * N:(i + 1) * N] for i in range(G)], 1)
+        e_u = rel_l2(u, u_ref)
+    else:
+        with pytest.raises(hip.HipError):                          # no tile narrower than the group: the engine falls back
+            hip.gemm(dy, Bt, u, k1=N, a1_group_n=r)
+        for i in range(G):
+            hip.gemm(dy[:, i * N:(i + 1) * N], Bt[i * r:(i + 1) * r], u[:, i * r:(i + 1) * r])
+    dx = torch.empty(M, K, dtype=torch.bfloat16, device="cuda")
+    hip.gemm(dy, Wt, dx, a2=u, w2=At)
+    dx_ref = dy64 @ W64 + u.double() @ A64
+    e_dx = rel_l2(dx, dx_ref)
+    _record("grouped_lora", shape=[M, K, N, r, G], t=e_t, y=e_y, u=e_u, dx=e_dx)
+    tol = 2.5e-3                                                   # one bf16 rounding of the result (2^-9 = 1.95e-3 worst, ~1.7e-3 rms)
+    assert e_t < tol and e_y < tol and e_dx < tol and (e_u is None or e_u < tol), (e_t, e_y, e_u, e_dx)
+
+
+# ------------------------------------------------------------------------------ one-launch GroupNorm (register-resident slab)
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("C,HW,silu,train", [(640, 1024, True, False), (1280, 1024, False, True), (1920, 256, True, False),
+                                             (960, 1024, True, False), (1280, 256, False, True), (2560, 64, True, False),
+                                             (2560, 256, True, False), (640, 256, True, True), (1280, 60, True, True)])
+def test_groupnorm_one_launch_production_shapes(dtype, C, HW, silu, train):
+    """GroupNorm32 (+SiLU) forward / backward at the 32x32, 16x16 and 8x8 levels of SD1.5 (B = 8), where the one-launch
+    kernels (csrc/norm.hip gn1_*: the (sample, channel-block) slab stays in registers between statistics and apply) take
+    over from the two-launch form: vs torch in fp64, and the two forms against each other (A/B hook 34 / 35); a ragged
+    pixel count too.  ldm/modules/diffusionmodules/util.py:217-219, openaimodel.py:201-202, attention.py:88-89."""
+    _need_gpu()
+    from ctrlora_amd import hip
+    B, eps = 8, (1e-5 if silu else 1e-6)
+    g = torch.Generator().manual_seed(C + HW)
+    x = (torch.randn(B * HW, C, generator=g) * 1.5 + 0.3).to(dtype)
+    dy = torch.randn(B * HW, C, generator=g).to(dtype)
+    acc = torch.randn(B * HW, C, generator=g).to(dtype)
+    gamma = 1 + 0.2 * torch.randn(C, generator=g); beta = 0.2 * torch.randn(C, generator=g)
+    dev = torch.device("cuda")
+    xr = x.to(dev).double().reshape(B, HW, C).permute(0, 2, 1).requires_grad_(True)
+    gr, br = gamma.to(dev).double().requires_grad_(True), beta.to(dev).double().requires_grad_(True)
+    yr = torch.nn.functional.group_norm(xr, 32, gr, br, eps)
+    if silu:
+        yr = torch.nn.functional.silu(yr)
+    yr.backward(dy.to(dev).double().reshape(B, HW, C).permute(0, 2, 1))
+    y_ref = yr.detach().permute(0, 2, 1).reshape(B * HW, C)
+    dx_ref = xr.grad.permute(0, 2, 1).reshape(B * HW, C) + acc.to(dev).double()
+    xd, dyd, accd, gd, bd = x.to(dev), dy.to(dev), acc.to(dev), gamma.to(dev), beta.to(dev)
+    out = {}
+    for form in (35, 34):                    # one-launch on / off
+        hip.lib().cl_attention_force_variant(form)
+        try:
+            y = torch.empty_like(xd); dx = torch.empty_like(xd)
+            stats = torch.empty(B, 32, 2, device=dev); ws = torch.zeros(hip.groupnorm_ws(B, HW, C), device=dev)
+            dgam, dbet = (torch.zeros(C, device=dev), torch.zeros(C, device=dev)) if train else (None, None)
+            hip.groupnorm_fwd(xd, y, gd, bd, B, HW, eps, silu, stats, ws)
+            hip.groupnorm_bwd(xd, dyd, dx, gd, bd, stats, B, HW, silu, ws, accum=accd, dgamma=dgam, dbeta=dbet)
+            torch.cuda.synchronize()
+            out[form] = (y, dx, stats, dgam, dbet)
+        finally:
+            hip.lib().cl_attention_force_variant(35)
+    y, dx, stats, dgam, dbet = out[35]
+    tol = 1e-5 if dtype == torch.float32 else 6e-3
+    e_y, e_dx = rel_l2(y, y_ref), rel_l2(dx, dx_ref)
+    mean_ref = xr.detach().reshape(B, 32, -1).mean(-1)
+    e_mu = float((stats[:, :, 0].double() - mean_ref).abs().max())
+    _record("groupnorm_one_launch", dtype=str(dtype), shape=[C, HW, silu, train], y=e_y, dx=e_dx, mean_abs=e_mu,
+            y_vs_two_launch=rel_l2(y, out[34][0]), dx_vs_two_launch=rel_l2(dx, out[34][1]))
+    assert e_y < tol and e_dx < 2 * tol and e_mu < 1e-4, (e_y, e_dx, e_mu)
+    assert rel_l2(stats, out[34][2]) < 1e-5
+    assert rel_l2(y, out[34][0]) < tol and rel_l2(dx, out[34][1]) < 2 * tol
+    if train:
+        assert rel_l2(dgam, gr.grad) < (2e-5 if dtype == torch.float32 else 1e-2)
+        assert rel_l2(dbet, br.grad) < (2e-5 if dtype == torch.float32 else 1e-2)
