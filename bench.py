@@ -333,10 +333,35 @@ def pretrain_bench(device, dtype, B=8, steps=9, warmup=9, tiny=False):
     for i in range(steps):
         loss = step(warmup + i)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    dt_eager = (time.perf_counter() - t0) / steps
     assert torch.isfinite(loss)
+    # the same step as per-task hipGraph replays (ctrlora_amd.train.GraphedPretrainStep): one pass captures the nine graphs
+    # (each capture call runs its step eagerly), then `steps` timed replays in task round-robin
+    launch, dt = "eager", dt_eager
+    try:
+        from ctrlora_amd.train import GraphedPretrainStep
+        gstep = GraphedPretrainStep(model, opt, data["z"][0], data["ctx"][0], data["hint"][0], data["t"][0], data["noise"][0])
+        run = lambda i: gstep(tasks[i % len(tasks)], data["z"][i % 2], data["ctx"][i % 2], data["hint"][i % 2], data["t"][i % 2],
+                              data["noise"][i % 2])
+        for i in range(len(tasks)):
+            loss = run(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss = run(len(tasks) + i)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        assert torch.isfinite(loss) and len(gstep.graphs) == len(tasks)
+        launch = f"hipGraph replay, one graph per task ({len(gstep.graphs)} graphs, one memory pool)"
+    except Exception as e:
+        print(f"[bench] pre-training graph capture failed ({type(e).__name__}: {e}); reporting the eager figure", file=sys.stderr)
     ntrain = sum(p.numel() for p in model.control_model.parameters())
-    return dict(metric="Base-ControlNet multi-task pre-training images/sec (1 GPU, eager)", value=round(B / dt, 2),
+    # algorithmic FLOPs per image: the fine-tuning figure (forward CN + UNet, data gradients) + the ControlNet's dense weight
+    # gradients (every conv / linear of the ControlNet once more: ~F_cn = 0.30 TF) instead of LoRA-only ones
+    tf_img = 1.996 + 0.30
+    return dict(metric="Base-ControlNet multi-task pre-training images/sec (1 GPU)", value=round(B / dt, 2), launch=launch,
+                eager_ms_per_step=round(dt_eager * 1e3, 2), mfma_frac=round(tf_img * B / dt / PEAK_BF16_TFLOPS, 4),
+                tflop_per_image=tf_img,
                 unit="images/s", ms_per_step=round(dt * 1e3, 2), batch=B, tasks=len(tasks), steps=steps, warmup=warmup,
                 trainable_params_M=round(ntrain / 1e6, 1), loss=round(float(loss.detach()), 5),
                 peak_mem_GB=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), dtype=str(dtype).replace("torch.", ""),

@@ -175,6 +175,20 @@ class ControlPretrainLDM(ControlLDM):
                 self.dp.note_used(cond["task"])
         return self._run(x_noisy, t, cond_txt, [self._hint_latent(cond)])
 
+    @torch.no_grad()
+    def engine_train_step(self, x_start, cond, t, noise):
+        """p_losses + backward without torch.autograd (ControlFinetuneLDM.engine_train_step), after selecting the task's
+        LoRA bank: capturable as a hipGraph (ctrlora_amd.train.GraphedPretrainStep keeps one graph per task)."""
+        from cldm.cldm_ctrlora_finetune import ControlFinetuneLDM
+        task = cond["task"]
+        self.control_model.switch_lora(task)
+        opt = self.__dict__.get("_opt")
+        if opt is not None:
+            opt.mark_used(task)
+        if isinstance(self.dp, _PretrainDP):
+            self.dp.note_used(task)
+        return ControlFinetuneLDM.engine_train_step(self, x_start, cond, t, noise)
+
     def init_data_parallel(self):
         """Install the bank-sparse gradient exchange (call after torch.distributed is initialised)."""
         self.dp = _PretrainDP(self.control_model)

@@ -430,17 +430,20 @@ class ControlNetE:
         self._b.reload_frozen({k: v for k, v in sd.items()})
         self.repack()
 
-    def switch_bank(self, lora_set: TrainableSet):
+    def switch_bank(self, lora_set: TrainableSet, repack: bool = True, force: bool = False):
         """Pre-training: make `lora_set` (same names / shapes, its own flat master + gradient buffers) the active LoRA
-        bank (ControlNetPretrain.switch_lora, cldm_ctrlora_pretrain.py:68-76) and re-pack the LoRA copies from it."""
+        bank (ControlNetPretrain.switch_lora, cldm_ctrlora_pretrain.py:68-76) and re-pack the LoRA copies from it.
+        repack=False: only the host-side pointers move (a replayed hipGraph has already re-packed that bank);
+        force=True: re-pack even if the bank is already the active one (first kernel of a captured per-task step)."""
         assert self.train_all
-        if lora_set is self.tr_lora:
+        if lora_set is self.tr_lora and not force:
             return
         for L in self._b.linears:
             if L.tA is not None:
                 L.tA, L.tB = lora_set.by_name[L.tA.name], lora_set.by_name[L.tB.name]
         self.tr_lora = lora_set
-        self.repack(only=lora_set)
+        if repack:
+            self.repack(only=lora_set)
 
     def _repack_table(self, ts: TrainableSet):
         key = id(ts)

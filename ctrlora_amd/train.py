@@ -212,7 +212,8 @@ class PretrainAdamW(torch.optim.Optimizer):
         loss = closure() if closure is not None else None
         if self.pre_step_hook is not None:
             self.pre_step_hook()
-        self.sync_hyper()
+        if not torch.cuda.is_available() or not torch.cuda.is_current_stream_capturing():
+            self.sync_hyper()
         ex = self.executor
         hip.tick(self._base["step"])
         hip.adamw_dev(ex.tr.flat, ex.tr.flat_grad, self._base["m"], self._base["v"], self._hyper, self._base["step"])
@@ -443,3 +444,72 @@ def replay_with_exchange(segments, g_opt, execs, reduce_fn):
             w.wait()
     if g_opt is not None:
         g_opt.replay()
+
+
+class GraphedPretrainStep:
+    """One optimizer step of multi-task Base-ControlNet pre-training (cldm/cldm_ctrlora_pretrain.py:95-111,174-182) as a
+    hipGraph replay: ONE GRAPH PER TASK, all in one memory pool.  A task's graph is self-contained:
+
+        re-pack of that task's LoRA bank into the shared packed copies (the bank switch)  ->  zero_grad  ->  p_losses
+        forward + hand-written backward (base weights + that bank)  ->  PretrainAdamW (base + every active bank)  ->  re-pack
+
+    so replaying graphs in any task order is the eager sequence.  PretrainAdamW updates every bank that has EVER received a
+    gradient, so the set of active banks is part of what a graph captured: while banks are still joining (a task's first
+    step) the step runs eagerly, and graphs are (re-)captured once the active set is what they would bake in.  After a
+    replay the host-side bank pointers are moved without another re-pack, so eager code that follows sees a consistent
+    executor.  Single process (the data-parallel exchange of pre-training is eager: `_PretrainDP`)."""
+
+    def __init__(self, model, opt, z, cond_txt, hint, t, noise):
+        self.model, self.opt = model, opt
+        self.s_z, self.s_ctx, self.s_hint = z.clone(), cond_txt.clone(), hint.clone()
+        self.s_t, self.s_noise = t.clone(), noise.clone()
+        self.graphs = {}             # task -> (graph, loss 3-vector)
+        self._active_at_capture = None
+        self._pool = None
+        self.eager_steps = 0
+
+    def _step(self, task):
+        cm = self.model.control_model
+        cm.switch_lora(task)
+        cm.executor().switch_bank(cm.bank(task), force=True)      # the graph's first kernel: this bank -> packed copies
+        self.opt.zero_grad()
+        cond = {"c_crossattn": [self.s_ctx], "c_concat": [self.s_hint], "task": task}
+        loss3 = self.model.engine_train_step(self.s_z, cond, self.s_t, self.s_noise)
+        self.opt.step()
+        return loss3
+
+    def __call__(self, task, z, cond_txt, hint, t, noise):
+        self.s_z.copy_(z); self.s_ctx.copy_(cond_txt); self.s_hint.copy_(hint)
+        self.s_t.copy_(t); self.s_noise.copy_(noise)
+        opt, cm = self.opt, self.model.control_model
+        if task not in opt.active:                      # the bank joins the optimizer in this step: eager
+            self.eager_steps += 1
+            return self._step(task)[2]
+        if self._active_at_capture != tuple(opt.active):   # the active set changed: every captured optimizer piece is stale
+            self.graphs.clear()
+            self._active_at_capture = tuple(opt.active)
+        ent = self.graphs.get(task)
+        if ent is None:
+            opt.sync_hyper()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                done = self._step(task).clone()         # warm-up of this task's allocation pattern: it IS this call's step
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.eager_steps += 1
+            with torch.cuda.graph(g, pool=self._pool):
+                loss3 = self._step(task)                # capture does not execute
+            if self._pool is None:
+                self._pool = g.pool()
+            self.graphs[task] = (g, loss3)
+            return done[2]
+        opt.sync_hyper()
+        ent[0].replay()
+        cm._task = task
+        for lin, lora in zip(cm._lora_linears, cm.loras_dict[task]):
+            lin.set_lora_layer(lora)
+        cm.executor().switch_bank(cm.bank(task), repack=False)
+        return ent[1][2]

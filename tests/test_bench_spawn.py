@@ -1,0 +1,58 @@
+"""`python bench.py --gpus N` without a launcher starts its own ranks: the command it builds, the
+pass-through of rank 0's JSON line, and the single retry with --no-graph when the hipGraph data-parallel run fails.
+No GPU, no processes: subprocess.run is replaced."""
+import json
+import subprocess
+import sys
+import types
+
+import bench
+
+
+def _fake_run(results, calls):
+    def run(cmd, env=None, stdout=None, text=None):
+        calls.append((list(cmd), dict(env or {})))
+        rc, out = results[min(len(calls) - 1, len(results) - 1)]
+        return types.SimpleNamespace(returncode=rc, stdout=out)
+    return run
+
+
+def test_spawn_builds_the_torchrun_command_and_passes_the_line_through(monkeypatch, capsys):
+    calls = []
+    line = json.dumps({"metric": "512x512 LoRA-finetune images/sec", "value": 1.0, "n_gpus": 4})
+    monkeypatch.setattr(subprocess, "run", _fake_run([(0, "Optimizable params: 36.9M\n" + line + "\n")], calls))
+    rc = bench.spawn_ranks(4, ["--gpus", "4", "--steps", "7", "--warmup", "2"])
+    assert rc == 0 and len(calls) == 1
+    cmd, env = calls[0]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"] and cmd[-7].endswith("bench.py")
+    assert env.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+    assert capsys.readouterr().out.strip() == line          # exactly ONE JSON line on stdout
+
+
+def test_spawn_retries_once_without_graphs_when_the_graph_run_fails(monkeypatch, capsys):
+    calls = []
+    line = json.dumps({"metric": "m", "value": 2.0, "config": {"launch": "eager"}})
+    monkeypatch.setattr(subprocess, "run", _fake_run([(1, "Traceback ...\n"), (0, line + "\n")], calls))
+    rc = bench.spawn_ranks(8, ["--gpus", "8"])
+    assert rc == 0 and len(calls) == 2
+    assert "--no-graph" not in calls[0][0] and calls[1][0][-1] == "--no-graph"
+    assert capsys.readouterr().out.strip() == line
+    # a second failure is reported, not retried again
+    calls.clear()
+    monkeypatch.setattr(subprocess, "run", _fake_run([(1, "boom\n")], calls))
+    assert bench.spawn_ranks(2, ["--gpus", "2"]) != 0 and len(calls) == 2
+
+
+def test_main_self_spawns_only_without_a_launcher(monkeypatch):
+    seen = {}
+    monkeypatch.setattr(bench, "spawn_ranks", lambda n, argv: seen.setdefault("n", n) and 0 or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    monkeypatch.delenv("RANK", raising=False); monkeypatch.delenv("WORLD_SIZE", raising=False)
+    try:
+        bench.main()
+    except SystemExit as e:
+        assert e.code == 0
+    assert seen.get("n") == 2

@@ -1,0 +1,158 @@
+"""SURVEY.md 8 f4 under the driver's GPU run: the training / sampling entry points end to end on an MI355X with the REAL
+first stage (AutoencoderKL on the engine's VAE executors, not Identity), the CLIP text encoder (HF module from config,
+synthetic tokenizer: there are no vocabulary files offline) and the data pipeline, at narrow width on synthetic assets
+(tests/tools/make_synthetic_assets.py):
+
+  * scripts/train_ctrlora_finetune.py main() for two optimizer steps (Trainer.fit, ImageLogger, CheckpointEveryNSteps):
+    finite losses, the engine's VAE encoder was used, a checkpoint is written;
+  * Trainer's training_step is the direct path: model.training_step(batch) == model.shared_step(batch) == p_losses on
+    get_input's tensors under the same RNG state;
+  * the checkpoint round-trips (strict load into a fresh model reproduces every tensor) and a resumed fit continues from
+    its step;
+  * scripts/sample.py's per-item loop on that checkpoint (DDIM on the engine, VAE decode on the engine) writes finite images;
+  * Base-ControlNet pre-training as per-task hipGraph replays (ctrlora_amd.train.GraphedPretrainStep) follows the eager
+    trajectory.
+
+Reference: scripts/train_ctrlora_finetune.py:63-129, cldm/logger.py:12-126, scripts/sample.py:22-113,
+cldm/cldm_ctrlora_pretrain.py:95-111."""
+import glob
+import importlib.util
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+from tests.util import ROOT, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _script(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "scripts", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="module")
+def assets(tmp_path_factory):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    out = str(tmp_path_factory.mktemp("synth"))
+    spec = importlib.util.spec_from_file_location("make_synthetic_assets", os.path.join(ROOT, "tests", "tools", "make_synthetic_assets.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv, sys.argv = sys.argv, ["make_synthetic_assets.py", "--out", out, "--n", "4"]
+    try:
+        mod.main()
+    finally:
+        sys.argv = argv
+    return out
+
+
+def test_finetune_script_two_steps_checkpoint_roundtrip_resume_and_sample(assets, tmp_path, monkeypatch):
+    monkeypatch.setenv("CTRLORA_SYNTHETIC_TOKENIZER", "1")
+    monkeypatch.chdir(tmp_path)
+    train = _script("train_ctrlora_finetune")
+    cfg = os.path.join(assets, "finetune_narrow.yaml")
+    args = ["--dataroot", os.path.join(assets, "custom"), "--config", cfg, "--sd_ckpt", os.path.join(assets, "sd_synth.ckpt"),
+            "--cn_ckpt", os.path.join(assets, "basecn_synth.ckpt"), "--bs", "2", "--max_steps", "2", "--precision", "16",
+            "--ckpt_logger_freq", "2", "--img_logger_freq", "2", "--lr", "1e-4", "-n", "f4"]
+    train.main(args)
+    cks = sorted(glob.glob(os.path.join("runs", "f4", "**", "*.ckpt"), recursive=True))
+    assert cks, "CheckpointEveryNSteps wrote nothing"
+    pngs = glob.glob(os.path.join("runs", "f4", "**", "*.png"), recursive=True)
+    assert pngs, "ImageLogger wrote nothing"
+    ck = torch.load(cks[-1], map_location="cpu", weights_only=False)
+    assert int(ck["global_step"]) == 2
+    # ---- a fresh model: strict load reproduces every tensor of the checkpoint
+    from cldm.model import create_model
+    model = create_model(cfg).cpu()
+    model.load_state_dict(ck["state_dict"], strict=True)
+    sd = model.state_dict()
+    assert set(sd) == set(ck["state_dict"])
+    assert all(torch.equal(sd[k].cpu(), v.cpu()) for k, v in ck["state_dict"].items())
+    lora_up = [v for k, v in ck["state_dict"].items() if k.endswith("lora_layer.up.weight")]
+    assert lora_up and all(torch.isfinite(v).all() for v in lora_up)
+    # ---- Trainer's step is the direct path
+    model = model.cuda().train()
+    model.set_engine_dtype(torch.bfloat16)
+    model.learning_rate = 1e-4
+    _, loader = train.build_dataloader(train.get_parser().parse_args(args), 1, 0)
+    batch = next(iter(loader))
+    torch.manual_seed(11)
+    l_train = model.training_step(batch, 0)
+    torch.manual_seed(11)
+    l_shared, _ = model.shared_step(batch)
+    torch.manual_seed(11)
+    x, c = model.get_input(batch, model.first_stage_key)
+    t = torch.randint(0, model.num_timesteps, (x.shape[0],), device=model.device).long()
+    l_direct, _ = model.p_losses(x, c, t)
+    assert torch.isfinite(l_train)
+    assert float(l_train) == float(l_shared) == float(l_direct), (float(l_train), float(l_shared), float(l_direct))
+    assert "_enc" in model.first_stage_model.__dict__, "the first stage did not run on the engine's VAE encoder"
+    # ---- resume: the fit continues from step 2 to step 3 with the saved optimizer state
+    from ctrlora_amd.trainer import Trainer
+    del model
+    model2 = create_model(cfg).cpu()
+    model2.learning_rate = 1e-4
+    tr = Trainer(max_steps=3, precision=16, default_root_dir=os.path.join("runs", "f4_resume"))
+    tr.fit(model2, loader, ckpt_path=cks[-1])
+    assert tr.global_step == 3 and int(tr.optimizer._step) == 3
+    # ---- sampling loop of scripts/sample.py on the checkpoint
+    sample = _script("sample")
+    sargs = sample.get_parser().parse_args(["--dataroot", os.path.join(assets, "custom"), "--config", cfg, "--ckpt", cks[-1],
+                                            "--n_samples", "1", "--save_dir", str(tmp_path / "samples"), "--ddim_steps", "4"])
+    from cldm.ddim_hacked import DDIMSampler
+    from datasets.custom_dataset import CustomDataset
+    from torch.utils.data import Subset
+    m3 = model2.cuda().eval()
+    n = sample.sample_dataset(m3, DDIMSampler(m3), Subset(CustomDataset(os.path.join(assets, "custom")), range(1)), sargs)
+    outs = glob.glob(str(tmp_path / "samples" / "sample" / "*.png"))
+    assert outs and (n is None or n >= 1)
+    from PIL import Image
+    import numpy as np
+    img = np.asarray(Image.open(outs[0]))
+    assert img.shape[-1] == 3 and img.std() > 0, "the sampled image is constant"
+    assert "_dec" in m3.first_stage_model.__dict__, "the decode did not run on the engine's VAE decoder"
+
+
+def test_pretraining_graph_replays_follow_the_eager_trajectory():
+    """GraphedPretrainStep (one hipGraph per task: bank re-pack, zero_grad, forward, backward, PretrainAdamW, re-pack) vs
+    the eager loop on a twin model: same task sequence and inputs -> same losses and parameters."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from ctrlora_amd.train import GraphedPretrainStep
+    from tests.golden.make_golden_pretrain import LR, step_inputs
+    from tests.test_pretrain import _model
+    seq = ["hed", "canny", "hed", "hed", "canny", "canny", "hed", "canny"]
+    cu = lambda v: v.cuda()
+    results = []
+    for graphed in (False, True):
+        m, cfg = _model(torch.bfloat16)
+        m.learning_rate = LR * 0.1
+        opt = m.configure_optimizers()
+        inp0 = step_inputs(cfg, 0)
+        g = GraphedPretrainStep(m, opt, cu(inp0["z"]), cu(inp0["ctx"]), cu(inp0["hint_z"]), cu(inp0["t"]), cu(inp0["noise"])) if graphed else None
+        losses = []
+        for i, task in enumerate(seq):
+            inp = step_inputs(cfg, i % 3)
+            z, ctx, hint, t, noise = cu(inp["z"]), cu(inp["ctx"]), cu(inp["hint_z"]), cu(inp["t"]), cu(inp["noise"])
+            if graphed:
+                losses.append(float(g(task, z, ctx, hint, t, noise)))
+            else:
+                opt.zero_grad()
+                loss3 = m.engine_train_step(z, {"c_crossattn": [ctx], "c_concat": [hint], "task": task}, t, noise)
+                opt.step()
+                losses.append(float(loss3[2]))
+        torch.cuda.synchronize()
+        params = {n: p.detach().float().cpu().clone() for n, p in m.control_model.named_parameters()}
+        results.append((losses, params, None if g is None else (len(g.graphs), g.eager_steps)))
+        del m, opt, g
+    (l_e, p_e, _), (l_g, p_g, info) = results
+    assert info[0] == 2 and info[1] <= 4, info            # two tasks captured; only the joining / capture steps ran eagerly
+    assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(l_e, l_g)), (l_e, l_g)
+    worst = max(rel_l2(p_g[n], p_e[n]) for n in p_e)
+    assert worst < 1e-5, worst
