@@ -613,7 +613,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnFwdArgs p, cons
 
 // =============================================================================== dK / dV
 // TAIL: N is not a multiple of 64 (query masking)
-template <int DH, int KF, bool TAIL>
+template <int DH, int KF, bool TAIL, bool PRIO = false>
 __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_tr_kernel(AttnBwdArgs p) {
   using G = Geo<DH>;
   constexpr int CPR = G::CPR, KSTEPS = G::KSTEPS, DN = G::DN, ROWB = G::ROWB, TILE = G::TILE, TI = G::TI;
@@ -701,8 +701,10 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_tr_kerne
 #pragma unroll
         for (int kf = 0; kf < KF; ++kf) {
           f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
           for (int ks = 0; ks < KSTEPS; ++ks) { Mma<bf16_t>::run(qa[ks], kb[kf][ks], sc); Mma<bf16_t>::run(da[ks], vb[kf][ks], dp); }
+          if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
           // P = exp2(s * sl2 - lse), dS = P (dP - delta); the d_head^-0.5 factor of dS is applied once to dK in the
           // epilogue (linear).  Two rows per packed instruction.
 #pragma unroll
@@ -734,10 +736,12 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_tr_kerne
       oa[0] = tr_frag<ROWB, 0>(adO + troff + i * 32); oa[1] = tr_frag<ROWB, 1>(adO + troff + i * 32);
       qt[0] = tr_frag<ROWB, 0>(aQ + troff + i * 32); qt[1] = tr_frag<ROWB, 1>(aQ + troff + i * 32);
       lds_wait();
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kf = 0; kf < KF; ++kf)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) { Mma<bf16_t>::run(oa[s2], pb[kf][s2], dvt[kf][i]); Mma<bf16_t>::run(qt[s2], sb[kf][s2], dkt[kf][i]); }
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     }
   }
   // ---- store dK / dV rows (4 consecutive d per lane)
@@ -766,7 +770,7 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_tr_kerne
 // DELTA: delta[q] = sum_d dO[q,d] O[q,d] is formed here from the dO fragments the kernel holds anyway (+ one read of the
 // O rows) and stored for the dK/dV kernel, which then has to be launched AFTER this one: saves the separate
 // attn_delta launch (32 per training step, ~13 us each at the 64x64 level).
-template <int DH, int QF, bool TAIL, bool DELTA = false>
+template <int DH, int QF, bool TAIL, bool DELTA = false, bool PRIO = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_tr_kernel(AttnBwdArgs p) {
   using G = Geo<DH>;
   constexpr int CPR = G::CPR, KSTEPS = G::KSTEPS, DN = G::DN, ROWB = G::ROWB, TILE = G::TILE;
@@ -865,8 +869,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_tr_kernel(AttnBwdArgs p) {
 #pragma unroll
         for (int f = 0; f < QF; ++f) {
           f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
           for (int ks = 0; ks < KSTEPS; ++ks) { Mma<bf16_t>::run(ka[ks], qb[f][ks], sc); Mma<bf16_t>::run(va[ks], ob[f][ks], dp); }
+          if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
           // dS^T = P (dP - delta), two keys per packed instruction; d_head^-0.5 goes onto dQ in the epilogue
 #pragma unroll
           for (int h2 = 0; h2 < 2; ++h2) {
@@ -893,10 +899,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_tr_kernel(AttnBwdArgs p) {
       u32x4_t kc[2];
       kc[0] = tr_frag<ROWB, 0>(aK + troff + i * 32); kc[1] = tr_frag<ROWB, 1>(aK + troff + i * 32);
       lds_wait();
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int f = 0; f < QF; ++f)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) Mma<bf16_t>::run(kc[s2], sb[f][s2], dqt[f][i]);
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     }
   }
 #pragma unroll
@@ -1391,7 +1399,11 @@ static bool launch_fwd_pp(const AttnFwdArgs& a, const void* V, long ldv, hipStre
       case 7: *rc = launch_fwd_pp_t<DH, 4, 0, false, 2>(a, V, ldv, st); break;     // static priority for the younger group
       case 8: *rc = launch_fwd_pp_t<DH, 4, 0, false, 4>(a, V, ldv, st); break;     // single-issue fp32 softmax math
       case 9: *rc = launch_fwd_pp_t<DH, 4, 0, false, 7>(a, V, ldv, st); break;     // all three
-      default: *rc = launch_fwd_pp_t<DH, 4, 0>(a, V, ldv, st); break;
+      case 10: *rc = launch_fwd_pp_t<DH, 4, 0, false, 3>(a, V, ldv, st); break;    // setprio + static priority
+      case 12: *rc = launch_fwd_pp_t<DH, 4, 0>(a, V, ldv, st); break;              // round-2 form (no priorities)
+      // default since round 3: static priority 1 for the second-dispatched wave group (measured -7 .. -15 % over the
+      // three production shapes, profiles/r03_attention_variants.json)
+      default: *rc = launch_fwd_pp_t<DH, 4, 0, false, 2>(a, V, ldv, st); break;
     }
     return true;
   }
@@ -1511,14 +1523,16 @@ static int launch_bwd_tr_sync(const AttnBwdArgs& a, hipStream_t st, bool skip_dq
   if (fused_delta) {   // dQ (+ delta) first, then dK/dV
     static bool done = false;
     if (!done) {
-      if (set_lds(&attn_bwd_dq_tr_kernel<DH, KF, TK, true>, LDS_DQ) || set_lds(&attn_bwd_dq_tr_kernel<DH, 1, TK, true>, LDS_DQ))
+      if (set_lds(&attn_bwd_dq_tr_kernel<DH, KF, TK, true>, LDS_DQ) || set_lds(&attn_bwd_dq_tr_kernel<DH, 1, TK, true>, LDS_DQ) ||
+          set_lds(&attn_bwd_dq_tr_kernel<DH, KF, TK, true, true>, LDS_DQ) || set_lds(&attn_bwd_dkv_tr_kernel<DH, KF, TQ, true>, LDS_DKV))
         return CL_ELAUNCH;
       done = true;
     }
     const long qb2 = (long)((a.N + 64 * KF - 1) / (64 * KF)) * a.H * a.B;
     if (KF == 2 && qb2 >= 512) {
       dim3 grid((a.N + 127) / 128, a.H, a.B);
-      hipLaunchKernelGGL((attn_bwd_dq_tr_kernel<DH, KF, TK, true>), grid, dim3(256), LDS_DQ, st, a);
+      if (g_attn_variant == 11) hipLaunchKernelGGL((attn_bwd_dq_tr_kernel<DH, KF, TK, true, true>), grid, dim3(256), LDS_DQ, st, a);
+      else hipLaunchKernelGGL((attn_bwd_dq_tr_kernel<DH, KF, TK, true>), grid, dim3(256), LDS_DQ, st, a);
     } else {
       dim3 grid((a.N + 63) / 64, a.H, a.B);
       hipLaunchKernelGGL((attn_bwd_dq_tr_kernel<DH, 1, TK, true>), grid, dim3(256), LDS_DQ, st, a);
@@ -1530,7 +1544,8 @@ static int launch_bwd_tr_sync(const AttnBwdArgs& a, hipStream_t st, bool skip_dq
     const long blocks2 = (long)((a.Nkv + 64 * KF - 1) / (64 * KF)) * a.H * a.B;
     if (KF == 2 && blocks2 >= 512) {
       dim3 grid((a.Nkv + 127) / 128, a.H, a.B);
-      hipLaunchKernelGGL((attn_bwd_dkv_tr_kernel<DH, KF, TQ>), grid, dim3(256), LDS_DKV, st, a);
+      if (g_attn_variant == 11) hipLaunchKernelGGL((attn_bwd_dkv_tr_kernel<DH, KF, TQ, true>), grid, dim3(256), LDS_DKV, st, a);
+      else hipLaunchKernelGGL((attn_bwd_dkv_tr_kernel<DH, KF, TQ>), grid, dim3(256), LDS_DKV, st, a);
     } else {
       dim3 grid((a.Nkv + 63) / 64, a.H, a.B);
       hipLaunchKernelGGL((attn_bwd_dkv_tr_kernel<DH, 1, TQ>), grid, dim3(256), LDS_DKV, st, a);
