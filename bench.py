@@ -227,7 +227,11 @@ def family_census(model, opt, data, reps=10):
                                 kernels="GroupNorm(+SiLU) / LayerNorm / GEGLU forward + backward, column sums; every operand "
                                         "counted once; timed per signature in isolation with HIP events",
                                 per_kernel={k: dict(calls=v[0], ms=round(v[2] * 1e-3, 3), GBps=round(v[1] / v[2] * 1e-3, 1))
-                                            for k, v in per.items()})
+                                            for k, v in per.items()},
+                                # where the family's time is: the five signatures with the largest time x calls
+                                top=[dict(kernel=k[0], rows_cols=list(k[1]), accum=k[2], trainable=k[3], calls=e[0], us=round(e[4], 1),
+                                          GBps=round(e[3] / e[4] * 1e-3, 1))
+                                     for k, e in sorted(tab.items(), key=lambda kv: -kv[1][4] * kv[1][0])[:6]])
             continue
         if tot_us > 0:
             tf = tot_fl / tot_us * 1e-6

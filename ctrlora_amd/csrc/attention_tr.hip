@@ -1401,9 +1401,10 @@ static bool launch_fwd_pp(const AttnFwdArgs& a, const void* V, long ldv, hipStre
       case 9: *rc = launch_fwd_pp_t<DH, 4, 0, false, 7>(a, V, ldv, st); break;     // all three
       case 10: *rc = launch_fwd_pp_t<DH, 4, 0, false, 3>(a, V, ldv, st); break;    // setprio + static priority
       case 12: *rc = launch_fwd_pp_t<DH, 4, 0>(a, V, ldv, st); break;              // round-2 form (no priorities)
-      // default since round 3: static priority 1 for the second-dispatched wave group (measured -7 .. -15 % over the
-      // three production shapes, profiles/r03_attention_variants.json)
-      default: *rc = launch_fwd_pp_t<DH, 4, 0, false, 2>(a, V, ldv, st); break;
+      // default since round 3: s_setprio(1) around the matrix phase + static priority 1 for the second-dispatched wave
+      // group: 310.6 -> 246.1 us at B 8 x H 8, N 4096, d_head 40 (-21 %), 1065.6 -> 973.5 us at B = 32 (the DDIM shape),
+      // 153.1 -> 141.4 us at d_head 80 / B = 32 (profiles/r03_attention_variants*.json, one box, interleaved)
+      default: *rc = launch_fwd_pp_t<DH, 4, 0, false, 3>(a, V, ldv, st); break;
     }
     return true;
   }

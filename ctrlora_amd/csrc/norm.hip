@@ -59,7 +59,8 @@ __global__ void gn_partial_kernel(const T* __restrict__ x, long ldx, int HW, int
     float s[8], q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
-    for (int p = p0 + py; p < p1; p += PY) {
+  #pragma unroll 4
+  for (int p = p0 + py; p < p1; p += PY) {
       float f[8];
       load8(x + ((long)b * HW + p) * ldx + v * 8, f);
 #pragma unroll
@@ -140,7 +141,8 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, long ldx, T* __restrict
     const float* cf = coef + ((long)b * C + v * 8) * 2;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sc[e] = cf[2 * e]; sh[e] = cf[2 * e + 1]; }
-    for (int p = p0 + py; p < p1; p += PY) {
+  #pragma unroll 4
+  for (int p = p0 + py; p < p1; p += PY) {
       float f[8];
       const long row = (long)b * HW + p;
       load8(x + row * ldx + v * 8, f);
@@ -171,6 +173,7 @@ __global__ void gn_gpartial_kernel(const T* __restrict__ x, long ldx, int HW, in
   float s[8], q[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+#pragma unroll 4
   for (int p = p0 + py; p < p1; p += PY) {
     float f[8];
     load8(x + ((long)b * HW + p) * ldx + vx * 8, f);
@@ -260,6 +263,7 @@ __global__ void gn_gapply_kernel(const T* __restrict__ x, long ldx, T* __restric
     sc[e] = (float)scd;
     sh[e] = (float)((double)beta[c] - tot[gi][0] * scd);
   }
+#pragma unroll 4
   for (int p = p0 + py; p < p1; p += PY) {
     float f[8];
     const long row = (long)b * HW + p;
@@ -612,7 +616,8 @@ __global__ void gn_bwd_partial_kernel(const T* __restrict__ x, long ldx, const T
       mu[e] = stats[((long)b * G + g) * 2]; rs[e] = stats[((long)b * G + g) * 2 + 1];
       s[e] = 0.f; q[e] = 0.f;
     }
-    for (int p = p0 + py; p < p1; p += PY) {
+  #pragma unroll 4
+  for (int p = p0 + py; p < p1; p += PY) {
       float f[8], d[8];
       const long row = (long)b * HW + p;
       load8(x + row * ldx + v * 8, f);
@@ -708,7 +713,8 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, long ldx, const T* 
       const float* o = bcoef + ((long)b * C + c) * 4;
       k1[e] = o[0]; k2[e] = o[1]; k3[e] = o[2];
     }
-    for (int p = p0 + py; p < p1; p += PY) {
+  #pragma unroll 4
+  for (int p = p0 + py; p < p1; p += PY) {
       float f[8], d[8], ac[8];
       const long row = (long)b * HW + p;
       load8(x + row * ldx + v * 8, f);
@@ -748,6 +754,7 @@ __global__ void gn_bwd_gpartial_kernel(const T* __restrict__ x, long ldx, const 
     mu[e] = stats[((long)b * G + gi) * 2]; rs[e] = stats[((long)b * G + gi) * 2 + 1];
     s[e] = 0.f; q[e] = 0.f;
   }
+#pragma unroll 4
   for (int p = p0 + py; p < p1; p += PY) {
     float f[8], d[8];
     const long row = (long)b * HW + p;
@@ -812,6 +819,7 @@ __global__ void gn_bwd_gapply_kernel(const T* __restrict__ x, long ldx, const T*
     k2[e] = (float)(rstd * tot[gi][0] / n);
     k3[e] = (float)(rstd * tot[gi][1] / n);
   }
+#pragma unroll 4
   for (int p = p0 + py; p < p1; p += PY) {
     float f[8], d[8], ac[8];
     const long row = (long)b * HW + p;

@@ -3,7 +3,7 @@ first stage (AutoencoderKL on the engine's VAE executors, not Identity), the CLI
 synthetic tokenizer: there are no vocabulary files offline) and the data pipeline, at narrow width on synthetic assets
 (tests/tools/make_synthetic_assets.py):
 
-  * scripts/train_ctrlora_finetune.py main() for two optimizer steps (Trainer.fit, ImageLogger, CheckpointEveryNSteps):
+  * scripts/train_ctrlora_finetune.py main() for three optimizer steps (Trainer.fit, ImageLogger, CheckpointEveryNSteps):
     finite losses, the engine's VAE encoder was used, a checkpoint is written;
   * Trainer's training_step is the direct path: model.training_step(batch) == model.shared_step(batch) == p_losses on
     get_input's tensors under the same RNG state;
@@ -58,7 +58,7 @@ def test_finetune_script_two_steps_checkpoint_roundtrip_resume_and_sample(assets
     train = _script("train_ctrlora_finetune")
     cfg = os.path.join(assets, "finetune_narrow.yaml")
     args = ["--dataroot", os.path.join(assets, "custom"), "--config", cfg, "--sd_ckpt", os.path.join(assets, "sd_synth.ckpt"),
-            "--cn_ckpt", os.path.join(assets, "basecn_synth.ckpt"), "--bs", "2", "--max_steps", "2", "--precision", "16",
+            "--cn_ckpt", os.path.join(assets, "basecn_synth.ckpt"), "--bs", "2", "--max_steps", "3", "--precision", "16",
             "--ckpt_logger_freq", "2", "--img_logger_freq", "2", "--lr", "1e-4", "-n", "f4"]
     train.main(args)
     cks = sorted(glob.glob(os.path.join("runs", "f4", "**", "*.ckpt"), recursive=True))
@@ -66,7 +66,7 @@ def test_finetune_script_two_steps_checkpoint_roundtrip_resume_and_sample(assets
     pngs = glob.glob(os.path.join("runs", "f4", "**", "*.png"), recursive=True)
     assert pngs, "ImageLogger wrote nothing"
     ck = torch.load(cks[-1], map_location="cpu", weights_only=False)
-    assert int(ck["global_step"]) == 2
+    assert int(ck["global_step"]) == 3          # the reference's callback saves when (step + 1) % freq == 0 (cldm/logger.py:22-23): steps 1, 3
     # ---- a fresh model: strict load reproduces every tensor of the checkpoint
     from cldm.model import create_model
     model = create_model(cfg).cpu()
@@ -93,14 +93,14 @@ def test_finetune_script_two_steps_checkpoint_roundtrip_resume_and_sample(assets
     assert torch.isfinite(l_train)
     assert float(l_train) == float(l_shared) == float(l_direct), (float(l_train), float(l_shared), float(l_direct))
     assert "_enc" in model.first_stage_model.__dict__, "the first stage did not run on the engine's VAE encoder"
-    # ---- resume: the fit continues from step 2 to step 3 with the saved optimizer state
+    # ---- resume: the fit continues from step 3 to step 4 with the saved optimizer state
     from ctrlora_amd.trainer import Trainer
     del model
     model2 = create_model(cfg).cpu()
     model2.learning_rate = 1e-4
-    tr = Trainer(max_steps=3, precision=16, default_root_dir=os.path.join("runs", "f4_resume"))
+    tr = Trainer(max_steps=4, precision=16, default_root_dir=os.path.join("runs", "f4_resume"))
     tr.fit(model2, loader, ckpt_path=cks[-1])
-    assert tr.global_step == 3 and int(tr.optimizer._step) == 3
+    assert tr.global_step == 4 and int(tr.optimizer._step) == 4
     # ---- sampling loop of scripts/sample.py on the checkpoint
     sample = _script("sample")
     sargs = sample.get_parser().parse_args(["--dataroot", os.path.join(assets, "custom"), "--config", cfg, "--ckpt", cks[-1],

@@ -36,7 +36,7 @@ def _model(dtype):
     return m, cfg
 
 
-@pytest.mark.parametrize("dtype,tol_g,tol_p", [(torch.float32, 1e-3, 5e-3), (torch.bfloat16, 2e-1, 3e-1)])
+@pytest.mark.parametrize("dtype,tol_g,tol_p", [(torch.float32, 1e-3, 5e-3), (torch.bfloat16, 2.6e-1, 3e-1)])
 def test_pretraining_three_steps_two_tasks_vs_reference(dtype, tol_g, tol_p):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
@@ -89,7 +89,13 @@ def test_pretraining_three_steps_two_tasks_vs_reference(dtype, tol_g, tol_p):
             worst.append((e, n))
         worst.sort(reverse=True)
         print(f"[pretrain {dtype} step {i} {task}] loss {float(loss):.6f} (ref {g['loss']:.6f}); worst grad errors {worst[:3]}")
-        assert worst[0][0] < tol_g, worst[:5]
+        # bf16: the first step measures the kernels (6e-2 at this d_head-8 width); from the second step on the two parameter
+        # trajectories have drifted apart (AdamW's first updates are lr * sign(g), lr = 1e-3 on 0.02-scale weights), which
+        # test_pretraining_bf16_error_is_flat_on_the_fp32_parameter_trajectory separates from kernel error: on the fp32
+        # trajectory the error stays at 5e-2.  Free-running it was measured at 1.3e-1 / 1.8e-1 .. 2.0e-1 (chaotic in the
+        # last digit of every bf16 rounding), hence the looser gate for steps 1, 2.
+        gate = tol_g if (dtype == torch.float32 or i > 0) else 8e-2
+        assert worst[0][0] < gate, worst[:5]
         opt.step()
     assert opt.active == ["hed", "canny"]
     ref = unpack(gold["after"])
