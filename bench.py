@@ -182,6 +182,11 @@ def family_census(model, opt, data, reps=10):
     hip.gemm, hip.attention_fwd_v2, hip.attention_bwd_v2 = rec_gemm, rec_af, rec_ab
     for n, fn in hbm_orig.items():
         setattr(hip, n, _mk_hbm(n, fn))
+    # rank 0 runs this alone: no collective may be issued from the recorded step (eager data-parallel hooks off)
+    dp = getattr(model, "dp", None)
+    dp_was = None if dp is None else dp.enabled
+    if dp is not None:
+        dp.enabled = False
     try:
         opt.zero_grad()
         cond = {"c_crossattn": [data["ctx"][0]], "c_concat": [data["hint"][0]]}
@@ -191,6 +196,8 @@ def family_census(model, opt, data, reps=10):
         hip.gemm, hip.attention_fwd_v2, hip.attention_bwd_v2 = o_gemm, o_af, o_ab
         for n, fn in hbm_orig.items():
             setattr(hip, n, fn)
+        if dp is not None:
+            dp.enabled = dp_was
     out = {}
     for fam, tab in calls.items():
         tot_us, tot_fl, n, ideal_us, mem_us = 0.0, 0.0, 0, 0.0, 0.0
@@ -500,8 +507,10 @@ def main():
     if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import datetime
-        # a collective that never completes aborts the job after 5 minutes instead of hanging the node for the default 10+
-        dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=300))
+        # N ranks build their 1.3 G-parameter model on the host at the same time: share the cores instead of N-fold
+        # oversubscription (the first collective waits for the slowest rank)
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
+        dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=900))
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     if args.ddim_only:
         print(json.dumps(ddim_bench(device, dtype, tiny=args.tiny)))

@@ -611,6 +611,268 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnFwdArgs p, cons
   }
 }
 
+// =============================================================================== forward, ping-pong + 32x32 Q.K^T
+// Same schedule as attn_fwd_pp_kernel (two wave groups one phase apart, 3-stage K/V ring, lazy maximum, softmax
+// denominator out of the matrix pipe for d_head 40), with S^T = K Q^T formed by v_mfma_f32_32x32x16_bf16:
+//   * d_head 40 costs a 48-deep walk (3 instructions of 32 cycles per 32 keys x 32 queries) instead of the 64-deep walk of
+//     the 16x16x32 form (8 instructions of 16 cycles): 192 instead of 256 matrix cycles per 64-key step, and 6 instead of
+//     8 ds_read_b128 of K per wave and step (one fragment feeds a 32 x 32 tile);
+//   * a lane then holds 32 scores of ONE query (lane & 31; the two half-waves split the keys), so the running maximum
+//     is per lane and the row maximum needs one cross-lane step, in the rare rescale branch only;
+//   * P^T changes hands to the 16x16x32 P.V product (d_head 40 -> 48 output rows: the 32x32 form would pad to 64) by
+//     v_permlane16_swap: C registers (2k, 2k+1) are packed to bf16 pairs P_k; swapping lane rows 1 / 3 of P_a with rows
+//     0 / 2 of P_b puts the two query halves of the 32-wide tile into two 16-query B operands whose four 16-lane groups hold
+//     keys {b, .., b+3, b+16, .., b+19} + 32 s with b = 0, 8, 4, 12 -- the order the V^T transpose reads are addressed in.
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+template <int DH, int LA = 3>
+__global__ __launch_bounds__(512, 2) void attn_fwd_hyb_kernel(AttnFwdArgs p, const void* __restrict__ V, long ldv,
+                                                              int nqb, int remap) {
+  using G = Geo<DH>;
+  constexpr int CPR = G::CPR, DN = G::DN, ROWB = G::ROWB, TILE = G::TILE;
+  constexpr int STAGE = 2 * TILE, QW = 2;
+  constexpr int NK = (DH + 15) / 16;           // 16-deep steps of the 32x32x16 product over the head dim
+  constexpr bool ONES = (DH % 16) != 0;
+  constexpr bool PADONES = ONES && G::CPRP > G::CPR;
+  static_assert(!ONES || PADONES, "spare V^T rows come from the padded LDS pitch");
+  static_assert(2 * NK <= G::CPRP, "K fragment reads stay inside the LDS row");
+  constexpr int LROW = DH % 16;
+  constexpr float RESCALE_THR = 6.0f;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  const int g = lane >> 4, lq = lane & 15, l31 = lane & 31, hi = lane >> 5;
+  int bh, qb;
+  {
+    const int id = blockIdx.x;
+    if (remap) { const int xcd = id & 7, slot = id >> 3; bh = xcd + 8 * (slot / nqb); qb = slot - (slot / nqb) * nqb; }
+    else { bh = id / nqb; qb = id - bh * nqb; }
+  }
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int q0 = qb * 256 + wave * 32;
+  const float sl2 = p.scale * 1.4426950408889634f;
+
+  for (int i = tid; i < (16 * ROWB + 64) / 4; i += 512) reinterpret_cast<uint32_t*>(smem + 3 * STAGE)[i] = 0u;
+  init_pads<DH>(smem, 6, 0u, 0x3F803F80u, tid, 512);   // K pad = 0 (meets Q zeros); V pad = 1.0: rows DH.. of V^T
+
+  // Q as the B operand of the 32x32x16 product: col = query l31, k = 16 j + 8 hi .. +7
+  u32x4_t qh[NK];
+  {
+    const char* qp = (const char*)p.Q + (((long)b * p.N + q0 + l31) * p.ldq + (long)h * DH) * 2;
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+      const int c = 2 * j + hi;
+      qh[j] = (c < CPR) ? *reinterpret_cast<const u32x4_t*>(qp + c * 16) : u32x4_t{0u, 0u, 0u, 0u};
+    }
+  }
+  const char* kbase = (const char*)p.K + ((long)b * p.Nkv * p.ldk + (long)h * DH) * 2;
+  const char* vbase = (const char*)V + ((long)b * p.Nkv * ldv + (long)h * DH) * 2;
+
+  f32x4_t ot[DN][QW];
+#pragma unroll
+  for (int i = 0; i < DN; ++i)
+#pragma unroll
+    for (int f = 0; f < QW; ++f) ot[i][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_run = -1e30f, l_run = 0.f;           // of query l31 (both half-waves keep the same maximum)
+  f32x16_t st[2];                              // S^T tiles: keys 32 s + (r & 3) + 8 (r >> 2) + 4 hi, query l31
+  u32x4_t pb[2][QW];
+
+  constexpr int CPRP = G::CPRP, NJ = (CPRP + 7) / 8;
+  int koff[NJ], voff[NJ];
+  bool real[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = (wave + 8 * j) * 64 + lane, r = c / CPRP, col = c - r * CPRP;
+    real[j] = col < CPR;
+    const int cc = (real[j] ? col : 0) * 16;
+    koff[j] = r * (int)(p.ldk * 2) + cc;
+    voff[j] = r * (int)(ldv * 2) + cc;
+  }
+  auto issue = [&](int t, int stage) {
+    const char* kb = kbase + (long)t * 64 * p.ldk * 2;
+    const char* vb = vbase + (long)t * 64 * ldv * 2;
+    char* dst = smem + stage * STAGE;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      if (wave + 8 * j < CPRP && real[j]) {
+        glds16(kb + koff[j], dst + (wave + 8 * j) * 1024);
+        glds16(vb + voff[j], dst + TILE + (wave + 8 * j) * 1024);
+      }
+  };
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const uint32_t krow = l31 * ROWB + hi * 16;                                  // b128: key row l31 of a 32-key tile, chunk 2 j + hi
+  const uint32_t troff = (8 * (g & 1) + 4 * (g >> 1) + ((lane >> 2) & 3)) * ROWB + (lane & 3) * 8;   // key rows b_g + j (+16)
+  const int nt = p.Nkv / 64;
+
+  // ---- matrix phase: PV of the previous tile (PREV), then the two 32-key S^T tiles of this one
+  auto phaseM = [&](auto PREVc, uint32_t kt, uint32_t vt) {
+    constexpr bool PREV = decltype(PREVc)::value;
+    constexpr int NV = PREV ? DN : 0, NG = NV + 2;
+    u32x4_t va[LA][2], ka[LA][NK];
+    auto cnt_of = [](int j) constexpr { return j < NV ? 4 : NK; };
+    auto read_group = [&](auto Jc) {
+      constexpr int J = decltype(Jc)::value;
+      if constexpr (J < NV) {
+        va[J % LA][0] = tr_frag<ROWB, 0>(vt + troff + J * 32);
+        va[J % LA][1] = tr_frag<ROWB, 1>(vt + troff + J * 32);
+      } else if constexpr (J < NG) {
+        constexpr int s = J - NV;
+        static_for<0, NK>([&](auto Kc) {
+          constexpr int j = decltype(Kc)::value;
+          ka[s % LA][j] = lds_read_b128_off<s * 32 * ROWB + j * 32>(kt + krow);
+        });
+      }
+    };
+    static_for<0, LA - 1>([&](auto Jc) { read_group(Jc); });
+    __builtin_amdgcn_s_setprio(1);
+    static_for<0, NG>([&](auto Jc) {
+      constexpr int J = decltype(Jc)::value;
+      read_group(std::integral_constant<int, J + LA - 1>{});
+      constexpr int pending = [&]() constexpr { int n = 0; for (int k = J + 1; k < J + LA && k < NG; ++k) n += cnt_of(k); return n; }();
+      lgkm_wait<(pending > 15 ? 15 : pending)>();
+      if constexpr (J < NV) {
+        pin(va[J % LA][0]); pin(va[J % LA][1]);
+#pragma unroll
+        for (int f = 0; f < QW; ++f) Mma<bf16_t>::run(va[J % LA][0], pb[0][f], ot[J][f]);
+#pragma unroll
+        for (int f = 0; f < QW; ++f) Mma<bf16_t>::run(va[J % LA][1], pb[1][f], ot[J][f]);
+      } else {
+        constexpr int s = J - NV;
+#pragma unroll
+        for (int j = 0; j < NK; ++j) pin(ka[s % LA][j]);
+        f32x16_t acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NK; ++j)
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ka[s % LA][j]),
+                                                        __builtin_bit_cast(bf16x8_t, qh[j]), acc, 0, 0, 0);
+        st[s] = acc;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- vector phase: online softmax of st -> pb (registers only)
+  auto phaseV = [&]() {
+    float mx = st[0][0];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[s][r]);
+    const bool need = mx * sl2 > m_run + RESCALE_THR;
+    if (__any(need)) {   // wave-uniform, rare after the first tiles
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                 // the other half-wave holds the other keys of this query
+      const float m_new = fmaxf(m_run, mx * sl2);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int f = 0; f < QW; ++f) {
+        const float af = __shfl(alpha, 16 * f + lq, 64);      // O^T fragment f, column lq = query 16 f + lq
+#pragma unroll
+        for (int i = 0; i < DN; ++i) ot[i][f] *= af;
+      }
+    }
+    float ls = 0.f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      uint32_t pk[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const f32x2_t x = f32x2_t{st[s][2 * k], st[s][2 * k + 1]} * sl2 - m_run;
+        const float e0 = __builtin_amdgcn_exp2f(x.x), e1 = __builtin_amdgcn_exp2f(x.y);
+        if constexpr (!ONES) ls += e0 + e1;
+        pk[k] = pack2bf(e0, e1);
+      }
+      // (P0,P2) (P1,P3) (P4,P6) (P5,P7): rows 1 / 3 of the first <-> rows 0 / 2 of the second
+      const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0], pk[2], false, false);
+      const auto s1 = __builtin_amdgcn_permlane16_swap(pk[1], pk[3], false, false);
+      const auto s2 = __builtin_amdgcn_permlane16_swap(pk[4], pk[6], false, false);
+      const auto s3 = __builtin_amdgcn_permlane16_swap(pk[5], pk[7], false, false);
+      pb[s][0] = u32x4_t{s0[0], s1[0], s2[0], s3[0]};
+      pb[s][1] = u32x4_t{s0[1], s1[1], s2[1], s3[1]};
+    }
+    if constexpr (!ONES) l_run += ls;
+  };
+
+  issue(0, 0);
+  issue(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int sk = 0;
+  if (grp == 1) __builtin_amdgcn_s_setprio(1);         // (phaseM ends with setprio(0): the static form is re-armed below)
+  auto pv_tail = [&](uint32_t vt) {
+    u32x4_t va[2];
+#pragma unroll
+    for (int i = 0; i < DN; ++i) {
+      va[0] = tr_frag<ROWB, 0>(vt + troff + i * 32); va[1] = tr_frag<ROWB, 1>(vt + troff + i * 32);
+      lds_wait();
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int f = 0; f < QW; ++f) Mma<bf16_t>::run(va[s], pb[s][f], ot[i][f]);
+    }
+  };
+  if (grp == 0) {
+    int sp = 2;
+    for (int u = 0; u < nt; ++u) {
+      const int sn = (sk == 2) ? 0 : sk + 1;
+      if (u >= 1 && u + 1 < nt) issue(u + 1, sn);
+      if (u == 0) phaseM(std::false_type{}, lds0 + sk * STAGE, 0u);
+      else phaseM(std::true_type{}, lds0 + sk * STAGE, lds0 + sp * STAGE + TILE);
+      __builtin_amdgcn_s_barrier();
+      phaseV();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      sp = sk; sk = sn;
+    }
+    pv_tail(lds0 + sp * STAGE + TILE);
+    __builtin_amdgcn_s_barrier();
+  } else {
+    int sp = 2;
+    __builtin_amdgcn_s_barrier();
+    for (int u = 0; u < nt; ++u) {
+      const int sn = (sk == 2) ? 0 : sk + 1, sn2 = (sn == 2) ? 0 : sn + 1;
+      if (u == 0) phaseM(std::false_type{}, lds0 + sk * STAGE, 0u);
+      else phaseM(std::true_type{}, lds0 + sk * STAGE, lds0 + sp * STAGE + TILE);
+      __builtin_amdgcn_s_setprio(1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (u + 2 < nt) issue(u + 2, sn2);
+      phaseV();
+      __builtin_amdgcn_s_barrier();
+      sp = sk; sk = sn;
+    }
+    pv_tail(lds0 + sp * STAGE + TILE);
+  }
+
+  // ---- epilogue: normalise, store O rows, log-sum-exp (log2 domain)
+  float l_full = l_run;
+  if constexpr (!ONES) l_full += __shfl_xor(l_full, 32, 64);
+#pragma unroll
+  for (int f = 0; f < QW; ++f) {
+    float l;
+    if constexpr (ONES) l = __shfl(ot[DN - 1][f][LROW & 3], lq + 16 * (LROW >> 2), 64);
+    else l = __shfl(l_full, 16 * f + lq, 64);
+    const float m = __shfl(m_run, 16 * f + lq, 64);
+    const float inv = 1.0f / l;
+    const int row = q0 + f * 16 + lq;
+    bf16_t* op = reinterpret_cast<bf16_t*>(p.O) + ((long)b * p.N + row) * p.ldo + (long)h * DH;
+#pragma unroll
+    for (int i = 0; i < DN; ++i) {
+      const int d0 = i * 16 + 4 * g;
+      if (d0 < DH) {
+        float v[4] = {ot[i][f][0] * inv, ot[i][f][1] * inv, ot[i][f][2] * inv, ot[i][f][3] * inv};
+        store4(op + d0, v);
+      }
+    }
+    if (p.LSE && g == 0) p.LSE[((long)b * p.H + h) * p.lse_stride + row] = m + __builtin_amdgcn_logf(l);
+  }
+}
+
 // =============================================================================== dK / dV
 // TAIL: N is not a multiple of 64 (query masking)
 template <int DH, int KF, bool TAIL, bool PRIO = false>
@@ -1387,12 +1649,30 @@ static int launch_fwd_pp_t(const AttnFwdArgs& a, const void* V, long ldv, hipStr
   return CL_OK;
 }
 
+template <int DH, int LA>
+static int launch_fwd_hyb_t(const AttnFwdArgs& a, const void* V, long ldv, hipStream_t st) {
+  constexpr int LDS = 3 * 2 * Geo<DH>::TILE + 16 * Geo<DH>::ROWB + 64;
+  static bool done = false;
+  if (!done) {
+    if (set_lds(&attn_fwd_hyb_kernel<DH, LA>, LDS)) return CL_ELAUNCH;
+    done = true;
+  }
+  const int nqb = a.N / 256;
+  const long grid = (long)nqb * a.H * a.B;
+  const int remap = ((a.B * a.H) % 8 == 0) ? 1 : 0;
+  hipLaunchKernelGGL((attn_fwd_hyb_kernel<DH, LA>), dim3((unsigned)grid), dim3(512), LDS, st, a, V, ldv, nqb, remap);
+  CL_CHECK_LAUNCH();
+  return CL_OK;
+}
+
 template <int DH>
 static bool launch_fwd_pp(const AttnFwdArgs& a, const void* V, long ldv, hipStream_t st, int* rc) {
   if constexpr (DH == 40 || DH == 80) {
     const long grid = (long)(a.N / 256) * a.H * a.B;
     if (g_attn_variant == 1 || a.N % 256 || a.Nkv % 64 || a.Nkv < 128 || grid < 256) return false;
-    switch (g_attn_variant) {          // 2, 5: A/B probes (tests/tools/attn_bench.py); 3 = ping-pong backward too
+    switch (g_attn_variant) {
+      case 13: *rc = launch_fwd_hyb_t<DH, 3>(a, V, ldv, st); break;                // 32x32x16 Q.K^T, lookahead 3 groups
+      case 14: *rc = launch_fwd_hyb_t<DH, 2>(a, V, ldv, st); break;                // ... lookahead 2          // 2, 5: A/B probes (tests/tools/attn_bench.py); 3 = ping-pong backward too
       case 2: *rc = launch_fwd_pp_t<DH, 2, 0>(a, V, ldv, st); break;
       case 5: *rc = launch_fwd_pp_t<DH, 4, 0, true>(a, V, ldv, st); break;
       case 6: *rc = launch_fwd_pp_t<DH, 4, 0, false, 1>(a, V, ldv, st); break;     // setprio around the matrix phase
