@@ -31,7 +31,7 @@ def timeit(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) / iters
 
 
-def case(dh, N, Nkv, B, variants, bwd, check=True):
+def case(dh, N, Nkv, B, variants, bwd, check=True, rounds=1):
     H = 8
     inner = H * dh
     g = torch.Generator().manual_seed(dh + N)
@@ -53,6 +53,46 @@ def case(dh, N, Nkv, B, variants, bwd, check=True):
             ref.update(dq=back(qr.grad, N), dk=back(kr.grad, Nkv), dv=back(vr.grad, Nkv))
         del s, orf
     flops_f = 4.0 * B * H * N * Nkv * dh
+    if rounds > 1:
+        # interleaved A/B (guide rule 24): the FIRST variant timed in a process measures 15-20 % slow (clock ramp after the
+        # fp64 reference), so single-pass numbers are order-dependent.  Here every variant is timed once per round,
+        # round-robin, after a warm-up, and the median / min over the rounds is reported; correctness once per variant.
+        o = torch.empty_like(q)
+        lse = torch.empty(B, H, rp, dtype=torch.float32, device="cuda")
+        delta = torch.empty_like(lse)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        runs = {}
+        for name, var in variants:
+            hip.lib().cl_attention_force_variant(var)
+            hip.attention_fwd_v2(q, k, v, o, lse, B, H, N, Nkv, dh, scale)
+            r = {}
+            if ref is not None:
+                torch.cuda.synchronize()
+                r["o_err"] = rel(o, ref["o"]); r["lse_err"] = rel(lse[:, :, :N] * 0.6931471805599453, ref["lse"])
+            if bwd:
+                hip.attention_bwd_v2(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, N, Nkv, dh, scale)
+                if ref is not None:
+                    torch.cuda.synchronize()
+                    r.update(dq_err=rel(dq, ref["dq"]), dk_err=rel(dk, ref["dk"]), dv_err=rel(dv, ref["dv"]))
+            runs[name] = dict(r, f=[], b=[])
+        hip.lib().cl_attention_force_variant(variants[0][1])
+        timeit(lambda: hip.attention_fwd_v2(q, k, v, o, lse, B, H, N, Nkv, dh, scale), iters=60, warm=10)   # clocks up
+        for _ in range(rounds):
+            for name, var in variants:
+                hip.lib().cl_attention_force_variant(var)
+                runs[name]["f"].append(timeit(lambda: hip.attention_fwd_v2(q, k, v, o, lse, B, H, N, Nkv, dh, scale), iters=10, warm=2))
+                if bwd:
+                    runs[name]["b"].append(timeit(lambda: hip.attention_bwd_v2(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, N, Nkv, dh, scale), iters=10, warm=2))
+        for name, r in runs.items():
+            f = sorted(r.pop("f")); bb = sorted(r.pop("b"))
+            r["fwd_us_median"] = round(f[len(f) // 2] * 1e3, 1); r["fwd_us_min"] = round(f[0] * 1e3, 1)
+            r["fwd_tflops"] = round(flops_f / f[len(f) // 2] * 1e-9, 1)
+            if bb:
+                r["bwd_us_median"] = round(bb[len(bb) // 2] * 1e3, 1); r["bwd_us_min"] = round(bb[0] * 1e3, 1)
+                r["bwd_tflops"] = round(2.5 * flops_f / bb[len(bb) // 2] * 1e-9, 1)
+            out[name] = r
+        hip.lib().cl_attention_force_variant(0)
+        return out
     for name, var in variants:
         hip.lib().cl_attention_force_variant(var)
         o = torch.empty_like(q)
@@ -92,13 +132,14 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--variants", default="1,0", help="comma list of cl_attention_force_variant values")
     ap.add_argument("--shapes", default="40,4096,4096,8;80,1024,1024,8;40,4096,4096,32;80,1024,1024,32;40,1024,1024,2;40,256,128,8")
+    ap.add_argument("--rounds", type=int, default=1, help="> 1: interleaved A/B, median / min over the rounds")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     variants = [(NAMES.get(int(v), f"v{v}"), int(v)) for v in args.variants.split(",")]
     res = []
     for sh in args.shapes.split(";"):
         dh, N, Nkv, B = (int(x) for x in sh.split(","))
-        r = case(dh, N, Nkv, B, variants, args.bwd, check=(B <= 8 and not args.no_check))
+        r = case(dh, N, Nkv, B, variants, args.bwd, check=(B <= 8 and not args.no_check), rounds=args.rounds)
         print(json.dumps(r), flush=True)
         res.append(r)
     if args.out:
