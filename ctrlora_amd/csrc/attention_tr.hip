@@ -1681,10 +1681,12 @@ static bool launch_fwd_pp(const AttnFwdArgs& a, const void* V, long ldv, hipStre
       case 9: *rc = launch_fwd_pp_t<DH, 4, 0, false, 7>(a, V, ldv, st); break;     // all three
       case 10: *rc = launch_fwd_pp_t<DH, 4, 0, false, 3>(a, V, ldv, st); break;    // setprio + static priority
       case 12: *rc = launch_fwd_pp_t<DH, 4, 0>(a, V, ldv, st); break;              // round-2 form (no priorities)
-      // default since round 3: s_setprio(1) around the matrix phase + static priority 1 for the second-dispatched wave
-      // group: 310.6 -> 246.1 us at B 8 x H 8, N 4096, d_head 40 (-21 %), 1065.6 -> 973.5 us at B = 32 (the DDIM shape),
-      // 153.1 -> 141.4 us at d_head 80 / B = 32 (profiles/r03_attention_variants*.json, one box, interleaved)
-      default: *rc = launch_fwd_pp_t<DH, 4, 0, false, 3>(a, V, ldv, st); break;
+      // default since round 3: the hybrid kernel (32x32x16 Q.K^T).  INTERLEAVED A/B on one box, 7 rounds, medians
+      // (profiles/r03_attention/interleaved_*.json): B 8 x H 8, N 4096, d_head 40: 248.8 us (round-2 kernel) -> 240.4 us;
+      // B = 32 (the DDIM shape) 972.9 -> 960.0 us; d_head 80: 38.1 -> 36.6 us / 129.0 -> 126.2 us.  The wave-priority
+      // variants 6 / 7 / 10 are within +-1.5 % of the round-2 kernel and the single-issue softmax (8) is 9 % slower; the
+      // 15-20 % "gains" a single-pass comparison showed for them were the first-variant clock ramp of the probe.
+      default: *rc = launch_fwd_hyb_t<DH, 2>(a, V, ldv, st); break;
     }
     return true;
   }
