@@ -147,7 +147,8 @@ def family_census(model, opt, data, reps=10):
         N = out.shape[1] if kw.get("N") is None else kw["N"]
         k1 = a1.shape[1] if kw.get("k1") is None else kw["k1"]
         mode, a2 = kw.get("mode", hip.LINEAR), kw.get("a2")
-        k2 = 0 if a2 is None else a2.shape[1]
+        # grouped second segment: an output column sees ONE group's K2 (= columns of W2), not the whole of A2
+        k2 = 0 if a2 is None else (kw["w2"].shape[1] if kw.get("a2_group_n") else a2.shape[1])
         key = (mode, M, N, k1, k2, kw.get("conv"), kw.get("residual") is not None, bool(kw.get("out_f32", False)),
                kw.get("act", 0))
         if not kw.get("atomic", False):
@@ -158,7 +159,9 @@ def family_census(model, opt, data, reps=10):
             conv = kw.get("conv")
             a_rows = M if conv is None else conv[0] * conv[1] * conv[2]
             n_out = N // 2 if kw.get("act", 0) == hip.ACT_GEGLU else N
-            by = esz * (a_rows * k1 + M * k2 + N * (taps * k1 + k2)) + M * n_out * (4 if kw.get("out_f32") else esz)
+            a1_cols = k1 * (N // kw["a1_group_n"]) if kw.get("a1_group_n") else k1      # grouped first segment reads every group's columns once
+            a2_cols = k2 * (N // kw["a2_group_n"]) if kw.get("a2_group_n") else k2
+            by = esz * (a_rows * a1_cols + M * a2_cols + N * (taps * k1 + k2)) + M * n_out * (4 if kw.get("out_f32") else esz)
             if kw.get("residual") is not None:
                 by += M * n_out * esz
             e = calls["gemm"].setdefault(key, [0, fl, lambda: o_gemm(a1, w1, out, **kw), by])

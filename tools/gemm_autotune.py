@@ -25,7 +25,8 @@ os.environ["CTRLORA_GEMM_TUNED"] = "0"
 import bench  # noqa: E402
 from ctrlora_amd import hip  # noqa: E402
 
-FL = (10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21)   # full-line (LDS-DMA, 128-byte K lines) configurations
+FL = (10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 31, 32)   # full-line (LDS-DMA, 128-byte K lines) configurations
+W80 = (31, 32)                                           # 128 x 80 tiles (linear products, N % 80 == 0)
 PERSIST = (25, 26, 27, 28, 29, 30)                      # persistent forms of 16 / 17 / 20 / 21 / 10 / 11 (linear only)
 W160 = (2, 5, 10, 12, 14, 16, 18, 20, 23, 25, 27, 29)   # 160-column tiles
 W128 = (1, 7, 11, 13, 15, 17, 19, 21, 22, 26, 28, 30)   # 128-column tiles
@@ -47,7 +48,8 @@ class Recorder:
             N = out.shape[1] if kw.get("N") is None else kw["N"]
             k1 = a1.shape[1] if kw.get("k1") is None else kw["k1"]
             mode, a2 = kw.get("mode", hip.LINEAR), kw.get("a2")
-            k2 = 0 if a2 is None else a2.shape[1]
+            # grouped second segment (a2_group_n): the launcher's signature carries the per-group K2 = columns of W2
+            k2 = 0 if a2 is None else (kw["w2"].shape[1] if kw.get("a2_group_n") else a2.shape[1])
             geglu = 1 if kw.get("act", 0) == hip.ACT_GEGLU else 0
             if not kw.get("atomic", False):
                 key = (hip.dt(a1), int(mode), int(M), int(N), int(k1), int(k2), geglu)
@@ -103,6 +105,8 @@ def candidates(key):
             continue                      # persistent walk only where a workgroup would own several tiles
         if c in W160 and N % 160:
             continue
+        if c in W80 and (N % 80 or mode != hip.LINEAR or M > 16384):
+            continue
         if c in W128 and N % 128 and N % 160 == 0:
             continue                      # keep the tile width the heuristic would use for this N
         cfgs.append(c)
@@ -119,6 +123,12 @@ def main():
     ap.add_argument("--ranks", default="128", help="comma-separated LoRA ranks whose training step is recorded "
                     "(configs/ctrlora_finetune_sd15_rank<r>.yaml); DDIM / VAE workloads use rank 128")
     ap.add_argument("--merge", default=None, help="existing table: its entries are kept, only NEW signatures are searched")
+    ap.add_argument("--only-new", action="store_true", help="with --merge: search every signature that is not in the table "
+                    "(no rank filter) -- e.g. after the engine started issuing new product shapes")
+    ap.add_argument("--retry-cfgs", default="", help="with --merge: comma list of NEW tile configurations to offer to signatures "
+                    "that already have an entry (or keep the rules): only these (at split 0, 1, 2) are timed against the current choice")
+    ap.add_argument("--budget-s", type=float, default=0.0, help="stop searching after this many seconds (0 = no limit) and write "
+                    "the table with what was found so far (GPU minutes are metered)")
     ap.add_argument("--gain", type=float, default=0.03)
     ap.add_argument("--reps", type=int, default=16)
     ap.add_argument("--out", default=os.path.join(ROOT, "ctrlora_amd", "gemm_tuned_gfx950.json"))
@@ -195,18 +205,36 @@ def main():
     log = open(args.log, "w")
     entries, rows = [], []
     t_start = time.time()
-    for key, e in rec.calls.items():
-        if key in known:                                 # --merge: measured before, entry kept as it is
-            continue
-        if args.merge and not (key[5] or key[3] in rank_set or key[4] in rank_set):
+    # heaviest signatures first, so that a time budget cuts the tail
+    order = sorted(rec.calls.items(), key=lambda kv: -sum(kv[1]["n"].values()) * kv[0][2] * kv[0][3] * (kv[0][4] + kv[0][5]))
+    for key, e in order:
+        if args.budget_s and time.time() - t_start > args.budget_s:
+            log.write(f"time budget of {args.budget_s:.0f} s reached: {key} and the lighter signatures keep their current launch\n")
+            break
+        retry = [int(c) for c in args.retry_cfgs.split(",") if c]
+        only = None
+        if key in known or (args.merge and args.retry_cfgs and key not in known and not args.only_new):
+            if not retry:
+                continue                                 # --merge: measured before, entry kept as it is
+            cfgs0, _ = candidates(key)
+            only = [c for c in retry if c in cfgs0]
+            if not only:
+                continue
+        elif args.merge and not args.only_new and not (key[5] or key[3] in rank_set or key[4] in rank_set):
             continue                                     # --merge: rank-independent signature, searched when the table was made
         run, out = e["run"], e["out"]
-        L.cl_gemm_force_config(-1); L.cl_gemm_force_splitk(0)
+        cur = next((r for r in kept if tuple(r[:7]) == key), None)
+        if only is not None and cur is not None:         # the current choice is the table's entry, not the rules
+            L.cl_gemm_force_config(cur[7]); L.cl_gemm_force_splitk(cur[8])
+        else:
+            L.cl_gemm_force_config(-1); L.cl_gemm_force_splitk(0)
         run(); torch.cuda.synchronize()
         ref = out.float().clone()
         scale = float(ref.abs().max()) + 1e-20
         base = time_us(run, args.reps)
         cfgs, sks = candidates(key)
+        if only is not None:
+            cfgs, sks = only, [0, 1, 2]
         best = (base, -1, 0)
         per_cfg = []
         for c in cfgs:                                   # tile configuration at the launcher's own split rule
@@ -235,7 +263,10 @@ def main():
             run(); torch.cuda.synchronize()
             err = float((out.float() - ref).abs().max()) / scale
             us2 = time_us(run, 2 * args.reps)
-            L.cl_gemm_force_config(-1); L.cl_gemm_force_splitk(0)
+            if only is not None and cur is not None:
+                L.cl_gemm_force_config(cur[7]); L.cl_gemm_force_splitk(cur[8])
+            else:
+                L.cl_gemm_force_config(-1); L.cl_gemm_force_splitk(0)
             base2 = time_us(run, 2 * args.reps)
             ok = err < 2e-2 and us2 < base2 * (1.0 - args.gain)
             log.write(f"  confirm {key} cfg {c} sk {sk}: {us2:.1f} vs {base2:.1f} us, err {err:.2e} -> {'take' if ok else 'drop'}\n")
@@ -280,7 +311,8 @@ def main():
             "gain_threshold": args.gain, "predicted_saving_ms": summary}
     with open(args.out, "w") as f:          # one entry per line: reviewable diffs
         f.write("{" + ", ".join(f"{json.dumps(k)}: {json.dumps(v)}" for k, v in head.items()) + ',\n"entries": [\n')
-        f.write(",\n".join(json.dumps(r) for r in sorted(kept + entries)))
+        fresh = {tuple(r[:7]) for r in entries}           # a retried signature's new choice replaces its old entry
+        f.write(",\n".join(json.dumps(r) for r in sorted([r for r in kept if tuple(r[:7]) not in fresh] + entries)))
         f.write("\n]}\n")
     log.close()
 
