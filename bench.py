@@ -488,6 +488,8 @@ def main():
     ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--ddim-only", action="store_true", help="profiling aid: run only the DDIM leg")
+    ap.add_argument("--ddim-loops", type=int, default=5, help="timed S = 50 loops of the DDIM leg")
+    ap.add_argument("--ddim-warm", type=int, default=10, help="warm-up loops of the DDIM leg")
     ap.add_argument("--force-split-graphs", action="store_true",
                     help="test aid: use the multi-rank structure (segment graphs with bucketed all-reduces in between, "
                          "then the AdamW graph) even with one rank")
@@ -516,7 +518,7 @@ def main():
         dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=900))
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     if args.ddim_only:
-        print(json.dumps(ddim_bench(device, dtype, tiny=args.tiny)))
+        print(json.dumps(ddim_bench(device, dtype, tiny=args.tiny, loops=args.ddim_loops, warm_loops=args.ddim_warm)))
         return
     if args.probe_only:
         print(json.dumps(conv_kernel_probe(device, dtype, iters=200)))
@@ -691,7 +693,7 @@ def main():
         del graphed, model, opt
         torch.cuda.empty_cache()
         try:
-            ddim = ddim_bench(device, dtype, tiny=args.tiny)
+            ddim = ddim_bench(device, dtype, tiny=args.tiny, loops=args.ddim_loops, warm_loops=args.ddim_warm)
             if world > 1:
                 tt = torch.tensor([ddim["S"] / ddim["value"]], device=device, dtype=torch.float64)   # seconds per loop
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
