@@ -622,7 +622,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnFwdArgs p, cons
 //   * P^T changes hands to the 16x16x32 P.V product (d_head 40 -> 48 output rows: the 32x32 form would pad to 64) by
 //     v_permlane16_swap: C registers (2k, 2k+1) are packed to bf16 pairs P_k; swapping lane rows 1 / 3 of P_a with rows
 //     0 / 2 of P_b puts the two query halves of the 32-wide tile into two 16-query B operands whose four 16-lane groups hold
-//     keys {b, .., b+3, b+16, .., b+19} + 32 s with b = 0, 8, 4, 12 -- the order the V^T transpose reads are addressed in.
+//     MFMA rows {b, .., b+3, b+16, .., b+19} with b = 0, 8, 4, 12; the K fragment rows are permuted (bits 2 and 3 exchanged) so that
+//     these are the LDS key rows {4g .. 4g+3, 16+4g ..} the V^T transpose reads address.
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
 template <int DH, int LA = 3>
@@ -703,8 +704,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hyb_kernel(AttnFwdArgs p, con
   };
 
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  const uint32_t krow = l31 * ROWB + hi * 16;                                  // b128: key row l31 of a 32-key tile, chunk 2 j + hi
-  const uint32_t troff = (8 * (g & 1) + 4 * (g >> 1) + ((lane >> 2) & 3)) * ROWB + (lane & 3) * 8;   // key rows b_g + j (+16)
+  // MFMA row i of the S^T tile takes LDS key row pi(i) = i with bits 2 and 3 exchanged: lane group g of the P operand then
+  // holds LDS rows {4g .. 4g+3, 16+4g .. 16+4g+3}, i.e. the V^T transpose reads address the same CONSECUTIVE rows as in the
+  // 16x16 kernel (8 rows of a half-wave 24 banks apart: conflict-free at the 96-byte pitch; with pi = identity the rows
+  // {0-3, 8-11} collided pairwise: SQ_LDS_BANK_CONFLICT was 50 % of SQ_LDS_IDX_ACTIVE, profiles/r03_final/pmc_attn_fwd_hyb.txt)
+  const int kr = (l31 & 19) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+  const uint32_t krow = kr * ROWB + hi * 16;                                   // b128: key row pi(l31) of a 32-key tile, chunk 2 j + hi
+  const uint32_t troff = (4 * g + ((lane >> 2) & 3)) * ROWB + (lane & 3) * 8;  // key rows 4g + j (+16)
   const int nt = p.Nkv / 64;
 
   // ---- matrix phase: PV of the previous tile (PREV), then the two 32-key S^T tiles of this one

@@ -938,81 +938,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, lo
   }
 }
 
-// Forward with RPI rows in flight per wave (round 3): a row is only D * 2 bytes (40 of 64 lanes at D = 320), so one row per
-// wave iteration leaves the kernel on the load -> reduce -> reduce -> store latency chain (14.7 us for the 42 MB of a 64x64
-// LayerNorm = 2.8 TB/s).  Same arithmetic as ln_fwd_kernel (two-pass variance), RPI independent rows interleaved.
-template <typename T, int NV, int RPI>
-__global__ __launch_bounds__(256) void ln_fwd_rows_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
-                                                          int M, int D, float eps, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float* __restrict__ stats) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int D8 = D / 8;
-  float ga[NV][8], be[NV][8];
-#pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    const int v = lane + 64 * k;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { ga[k][e] = v < D8 ? gamma[v * 8 + e] : 0.f; be[k][e] = v < D8 ? beta[v * 8 + e] : 0.f; }
-  }
-  for (long row0 = ((long)blockIdx.x * 4 + wave) * RPI; row0 < M; row0 += (long)gridDim.x * 4 * RPI) {
-    float f[RPI][NV][8], s[RPI], q[RPI];
-#pragma unroll
-    for (int r = 0; r < RPI; ++r) {
-      const long row = row0 + r < M ? row0 + r : M - 1;
-#pragma unroll
-      for (int k = 0; k < NV; ++k) {
-        const int v = lane + 64 * k;
-        if (v < D8) load8(x + row * ldx + v * 8, f[r][k]);
-        else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) f[r][k][e] = 0.f;
-        }
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < RPI; ++r) {
-      s[r] = 0.f;
-#pragma unroll
-      for (int k = 0; k < NV; ++k)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s[r] += f[r][k][e];
-    }
-#pragma unroll
-    for (int r = 0; r < RPI; ++r) s[r] = wave_sum(s[r]) / D;          // mean
-#pragma unroll
-    for (int r = 0; r < RPI; ++r) {
-      q[r] = 0.f;
-#pragma unroll
-      for (int k = 0; k < NV; ++k) {
-        const int v = lane + 64 * k;
-        if (v < D8) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { const float d = f[r][k][e] - s[r]; q[r] += d * d; }
-        }
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < RPI; ++r) q[r] = rsqrtf(wave_sum(q[r]) / D + eps);   // rstd
-#pragma unroll
-    for (int r = 0; r < RPI; ++r) {
-      const long row = row0 + r;
-      if (row < M) {
-        if (lane == 0 && stats) { stats[row * 2] = s[r]; stats[row * 2 + 1] = q[r]; }
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-          const int v = lane + 64 * k;
-          if (v < D8) {
-            float o[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (f[r][k][e] - s[r]) * q[r] * ga[k][e] + be[k][e];
-            store8(y + row * ldy + v * 8, o);
-          }
-        }
-      }
-    }
-  }
-}
-
+// (Round 3 tried RPI = 4 / 2 / 1 rows per wave in flight in the FORWARD as the backward does: measured slower -- 21.2 us
+// instead of 14.7 us for the 42 MB of a 64x64 LayerNorm, 1.04 instead of 0.72 ms per step -- and removed:
+// profiles/r03_final/ln_rows_negative.txt.  With one row per wave the grid already keeps 32 waves per CU streaming.)
 // dx = rstd * (dyh - mean(dyh) - xh * mean(dyh * xh)),  dyh = dy * gamma ; optional (+ accum)
 // WG: dgamma += sum_rows dy * xh ; dbeta += sum_rows dy  (per-lane column sums -> LDS across the 4 waves
 // -> block partial row, or one fp32 atomic per column per workgroup)
@@ -1162,17 +1090,6 @@ static int ln_grid(int M) {
 
 int ln_fwd(const LnArgs& a, int dtype, hipStream_t st) {
   if (a.D % 8 || a.D > 64 * LN_MAXV * 8 || a.ldx % 8 || a.ldy % 8) return CL_EINVAL;
-  if (dtype == CL_BF16 && !g_gn_three_pass && a.M >= 1024) {     // several rows per wave in flight (A/B hook 32 restores one)
-    const int nv = (a.D / 8 + 63) / 64;
-    const int rpi = nv == 1 ? 4 : nv == 2 ? 2 : 1;
-    int grid = (a.M + 4 * rpi - 1) / (4 * rpi); if (grid > 2048) grid = 2048;
-#define LNF(NV_, RPI_) hipLaunchKernelGGL((ln_fwd_rows_kernel<bf16_t, NV_, RPI_>), dim3(grid), dim3(256), 0, st, (const bf16_t*)a.x, \
-                                          a.ldx, (bf16_t*)a.y, a.ldy, a.M, a.D, a.eps, a.gamma, a.beta, a.stats)
-    if (nv == 1) LNF(1, 4); else if (nv == 2) LNF(2, 2); else LNF(3, 1);
-#undef LNF
-    CL_CHECK_LAUNCH();
-    return CL_OK;
-  }
   if (dtype == CL_BF16)
     hipLaunchKernelGGL((ln_fwd_kernel<bf16_t>), dim3(ln_grid(a.M)), dim3(256), 0, st, (const bf16_t*)a.x, a.ldx,
                        (bf16_t*)a.y, a.ldy, a.M, a.D, a.eps, a.gamma, a.beta, a.stats);
