@@ -579,8 +579,7 @@ int qsample(const float* z, const float* noise, const long* t, const float* sqrt
   CL_CHECK_LAUNCH(); return CL_OK;
 }
 int mse_loss(const float* eps, const float* target, float* d_eps, float* loss, long n, float gscale, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
-  if (e != hipSuccess) return CL_ELAUNCH;
+  if (int rc = zero_bytes(loss, sizeof(float), st)) return rc;
   hipLaunchKernelGGL(mse_kernel, dim3(ew_grid(n) < 256 ? ew_grid(n) : 256), dim3(256), 0, st, eps, target, d_eps, loss, n, gscale);
   CL_CHECK_LAUNCH(); return CL_OK;
 }
@@ -620,9 +619,25 @@ int softmax_rows(int dtype, const float* S, long lds_, void* P, long ldp, long M
   else hipLaunchKernelGGL((softmax_rows_kernel<float>), dim3((unsigned)M), dim3(256), 0, st, S, lds_, (float*)P, ldp, N, scale);
   CL_CHECK_LAUNCH(); return CL_OK;
 }
+// Clears are KERNEL nodes, not hipMemsetAsync: a step captured as SEVERAL consecutive hipGraphs in one memory pool
+// (the data-parallel segments, train.py) replayed memset nodes of small buffers out of order with their neighbours on
+// ROCm 7.2 -- garbage in exactly the gradients that are accumulated into freshly cleared scratch
+// (tests/tools/debug_segmented.py).  A fill kernel is ordered like every other launch and costs the same bytes.
+__global__ __launch_bounds__(256) void zero_kernel(unsigned char* __restrict__ p, long head, long nvec, long tail) {
+  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  uint4* body = reinterpret_cast<uint4*>(p + head);
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (long i = i0; i < nvec; i += (long)gridDim.x * blockDim.x) body[i] = z;
+  if (i0 < head) p[i0] = 0;
+  if (i0 < tail) p[head + nvec * 16 + i0] = 0;
+}
 int zero_bytes(void* p, long nbytes, hipStream_t st) {
   if (nbytes <= 0) return CL_OK;
-  return hipMemsetAsync(p, 0, (size_t)nbytes, st) == hipSuccess ? CL_OK : CL_ELAUNCH;
+  long head = (long)((16 - ((uintptr_t)p & 15)) & 15);
+  if (head > nbytes) head = nbytes;
+  const long nvec = (nbytes - head) / 16, tail = nbytes - head - nvec * 16;
+  hipLaunchKernelGGL(zero_kernel, dim3(ew_grid(nvec > 16 ? nvec : 16)), dim3(256), 0, st, (unsigned char*)p, head, nvec, tail);
+  CL_CHECK_LAUNCH(); return CL_OK;
 }
 int tick(int* counter, hipStream_t st) {
   hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(1), 0, st, counter);
