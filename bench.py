@@ -668,6 +668,9 @@ def main():
                             kernel="gemm_fl / gemm kernel family (implicit-GEMM 3x3 conv + linear + LoRA-fused linear), "
                                    "time-weighted over all shapes of one step",
                             family=gf)
+            # `traffic` (contract field): PMC-measured HBM bytes per launch of the family's dominant kernel (its best_shape entry)
+            roof["traffic"] = dk["traffic"]
+            roof["traffic_of"] = "best_shape launch (43.8 MB algorithmic per launch); see best_shape.traffic_kind"
             roof["best_shape"] = dict(kernel=dk["kernel"], achieved=dk["achieved"], frac=dk["frac"], ms_per_launch=dk["ms"],
                                       traffic=dk["traffic"],
                                       traffic_kind="static: rocprofv3 TCC_EA passes on this launch (profiles/dominant_kernel_traffic.json), "

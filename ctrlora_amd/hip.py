@@ -510,7 +510,7 @@ def softmax_rows(scores_f32, probs, scale=1.0):
 
 
 def zero_(t):
-    """In-place clear of a contiguous tensor as a memset node on the current stream (no ATen launch)."""
+    """In-place clear of a contiguous tensor: a fill kernel on the current stream (no ATen launch, no memset node: DESIGN.md 5)."""
     assert t.is_contiguous()
     _chk(lib().cl_zero(t.data_ptr(), t.numel() * t.element_size(), stream()), "cl_zero")
     return t

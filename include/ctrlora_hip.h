@@ -260,7 +260,8 @@ int cl_mse_loss(const float* eps, const float* target, float* d_eps, float* loss
 int cl_p_losses_mse(const float* eps, const float* target, float* d_eps, const long* t, const float* lvlb, float* out,
                     float* per_sample, float* scratch, int B, long per_sample_elems, float gscale, float w_simple,
                     float w_elbo, void* stream);
-/* optimizer.zero_grad() / accumulator clears without an ATen launch: memset node on `stream` */
+/* optimizer.zero_grad() / accumulator clears without an ATen launch: a fill KERNEL on `stream` (not hipMemsetAsync: memset
+   nodes of small buffers were mis-ordered when a step is replayed as several consecutive hipGraphs) */
 int cl_zero(void* p, long nbytes, void* stream);
 /* DDIMSampler.p_sample_ddim update (cldm/ddim_hacked.py:192,203-231); coef = device [S][4] fp32 table
  * {a_t, a_prev, sigma_t, sqrt(1-a_t)}; e_u = NULL disables classifier-free guidance. */
