@@ -215,9 +215,19 @@ __device__ __forceinline__ void gn_group_totals(const float* __restrict__ gparti
   int KL = blockDim.x / G; if (KL > 8) KL = 8;
   const int g = tid % G, kl = tid / G;
   if (kl < KL) {
+    // four independent L2 loads in flight per lane: this walk (nchunk / KL ~ 18 partials) is the prologue of every apply
+    // workgroup and, one load at a time, cost about as long as the workgroup's whole pixel loop
     double s = 0, q = 0;
-    for (int k = kl; k < nchunk; k += KL) {
-      const float2 p = *reinterpret_cast<const float2*>(gpartial + (((long)b * nchunk + k) * G + g) * 2);
+    const float2* src = reinterpret_cast<const float2*>(gpartial) + (long)b * nchunk * G + g;
+    int k = kl;
+    for (; k + 3 * KL < nchunk; k += 4 * KL) {
+      const float2 p0 = src[(long)k * G], p1 = src[(long)(k + KL) * G];
+      const float2 p2 = src[(long)(k + 2 * KL) * G], p3 = src[(long)(k + 3 * KL) * G];
+      s += ((double)p0.x + (double)p1.x) + ((double)p2.x + (double)p3.x);
+      q += ((double)p0.y + (double)p1.y) + ((double)p2.y + (double)p3.y);
+    }
+    for (; k < nchunk; k += KL) {
+      const float2 p = src[(long)k * G];
       s += p.x; q += p.y;
     }
     part[kl][g][0] = s; part[kl][g][1] = q;

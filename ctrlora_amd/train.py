@@ -314,8 +314,8 @@ class GraphedTrainStep:
             opt.zero_grad()
             cond = {"c_crossattn": [self.s_ctx], "c_concat": [self.s_hint]}
             if direct is not None:
-                # p_losses + backward without autograd: the captured region holds hand-written kernels and memset
-                # nodes only (no ATen launch); out = {loss_simple, loss_vlb, loss}
+                # p_losses + backward without autograd: the captured region holds hand-written kernel nodes only
+                # (no ATen launch, no memset node); out = {loss_simple, loss_vlb, loss}
                 self.loss3 = direct(self.s_z, cond, self.s_t, self.s_noise)
                 return self.loss3[2]
             loss, _ = model.p_losses(self.s_z, cond, self.s_t, noise=self.s_noise)
@@ -410,6 +410,17 @@ class GraphedTrainStep:
                 self.segments.append((g_last, "tails", tails, 0))
             torch.cuda.current_stream().wait_stream(stream)
             torch.cuda.synchronize()
+        except BaseException:
+            # leave no stream in capture mode behind: the caller falls back to eager launches on this device
+            g_open, state["g"] = state["g"], None
+            if g_open is not None:
+                try:
+                    with torch.cuda.stream(stream):
+                        g_open.capture_end()
+                except Exception:
+                    pass
+            self.segments = []
+            raise
         finally:
             for ex, h in zip(execs, saved_hooks):
                 ex.on_stage_done = h

@@ -20,6 +20,7 @@ import importlib.util
 import json
 import os
 import sys
+import time
 
 import pytest
 import torch
@@ -55,12 +56,17 @@ def assets(tmp_path_factory):
 def test_finetune_script_two_steps_checkpoint_roundtrip_resume_and_sample(assets, tmp_path, monkeypatch):
     monkeypatch.setenv("CTRLORA_SYNTHETIC_TOKENIZER", "1")
     monkeypatch.chdir(tmp_path)
+    t0 = time.time()
+
+    def lap(what):          # stage clock (visible with -s): this is the longest test of the GPU suite
+        print(f"[f4 {time.time() - t0:6.1f} s] {what}", flush=True)
     train = _script("train_ctrlora_finetune")
     cfg = os.path.join(assets, "finetune_narrow.yaml")
     args = ["--dataroot", os.path.join(assets, "custom"), "--config", cfg, "--sd_ckpt", os.path.join(assets, "sd_synth.ckpt"),
             "--cn_ckpt", os.path.join(assets, "basecn_synth.ckpt"), "--bs", "2", "--max_steps", "3", "--precision", "16",
             "--ckpt_logger_freq", "2", "--img_logger_freq", "2", "--lr", "1e-4", "-n", "f4"]
     train.main(args)
+    lap("train_ctrlora_finetune.main: 3 steps, image logger, checkpoints")
     cks = sorted(glob.glob(os.path.join("runs", "f4", "**", "*.ckpt"), recursive=True))
     assert cks, "CheckpointEveryNSteps wrote nothing"
     pngs = glob.glob(os.path.join("runs", "f4", "**", "*.png"), recursive=True)
@@ -74,6 +80,7 @@ def test_finetune_script_two_steps_checkpoint_roundtrip_resume_and_sample(assets
     sd = model.state_dict()
     assert set(sd) == set(ck["state_dict"])
     assert all(torch.equal(sd[k].cpu(), v.cpu()) for k, v in ck["state_dict"].items())
+    lap("checkpoint loaded into a fresh model, tensors compared")
     lora_up = [v for k, v in ck["state_dict"].items() if k.endswith("lora_layer.up.weight")]
     assert lora_up and all(torch.isfinite(v).all() for v in lora_up)
     # ---- Trainer's step is the direct path
@@ -93,6 +100,7 @@ def test_finetune_script_two_steps_checkpoint_roundtrip_resume_and_sample(assets
     assert torch.isfinite(l_train)
     assert float(l_train) == float(l_shared) == float(l_direct), (float(l_train), float(l_shared), float(l_direct))
     assert "_enc" in model.first_stage_model.__dict__, "the first stage did not run on the engine's VAE encoder"
+    lap("training_step == shared_step == p_losses")
     # ---- resume: the fit continues from step 3 to step 4 with the saved optimizer state
     from ctrlora_amd.trainer import Trainer
     del model
@@ -101,6 +109,7 @@ def test_finetune_script_two_steps_checkpoint_roundtrip_resume_and_sample(assets
     tr = Trainer(max_steps=4, precision=16, default_root_dir=os.path.join("runs", "f4_resume"))
     tr.fit(model2, loader, ckpt_path=cks[-1])
     assert tr.global_step == 4 and int(tr.optimizer._step) == 4
+    lap("resumed fit to step 4")
     # ---- sampling loop of scripts/sample.py on the checkpoint
     sample = _script("sample")
     sargs = sample.get_parser().parse_args(["--dataroot", os.path.join(assets, "custom"), "--config", cfg, "--ckpt", cks[-1],
@@ -117,6 +126,7 @@ def test_finetune_script_two_steps_checkpoint_roundtrip_resume_and_sample(assets
     img = np.asarray(Image.open(outs[0]))
     assert img.shape[-1] == 3 and img.std() > 0, "the sampled image is constant"
     assert "_dec" in m3.first_stage_model.__dict__, "the decode did not run on the engine's VAE decoder"
+    lap("sample.py loop")
 
 
 def test_pretraining_graph_replays_follow_the_eager_trajectory():
