@@ -42,6 +42,9 @@ def get_parser():
                    "the engine's attention never materialises the score matrix)")
     p.add_argument("--img_logger_freq", type=int, default=1000, help="img logger freq")
     p.add_argument("--ckpt_logger_freq", type=int, default=1000, help="ckpt logger freq")
+    p.add_argument("--num_workers", type=int, default=None,
+                   help="DataLoader worker processes (default: the reference's 16, capped at the host's cores); every epoch "
+                        "forks them again, which is slow from a process with a large address space")
     return p
 
 
@@ -83,7 +86,8 @@ def build_dataloader(args, world_size: int, rank: int):
     if args.subset > 0:
         dataset = Subset(dataset, range(args.subset))
     sampler = DistributedSampler(dataset, num_replicas=world_size, rank=rank, shuffle=True) if world_size > 1 else None
-    loader = DataLoader(dataset, num_workers=min(16, os.cpu_count() or 1), batch_size=args.bs, shuffle=sampler is None,
+    workers = min(16, os.cpu_count() or 1) if getattr(args, "num_workers", None) is None else max(0, args.num_workers)
+    loader = DataLoader(dataset, num_workers=workers, batch_size=args.bs, shuffle=sampler is None,
                         sampler=sampler, drop_last=True)
     return dataset, loader
 
