@@ -256,7 +256,8 @@ class DDIMSampler(object):
         if self.reuse_graph and graph is not None:
             # the graph reads the cached K/V products and the conditioning tensors by address: hold them
             self._graph_state = dict(key=key, graph=graph, x=x, pred_x0=pred_x0, ts=ts, cursor=cursor, table=table, kv=kv_keep,
-                                     conds=(cond, uncond, both), coef=self.coef_table)
+                                     conds=(cond, uncond, both), coef=self.coef_table,
+                                     eng=eng)     # keeps id(engine) in `key` from being recycled by a rebuilt engine
         del graph
         return out, intermediates
 
