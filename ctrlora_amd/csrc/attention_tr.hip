@@ -879,6 +879,334 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hyb_kernel(AttnFwdArgs p, con
   }
 }
 
+// =============================================================================== forward, per-wave software pipeline
+// Round-3 probe (tools/probe_interleave.hip): with the LDS operand reads in the stream, the barrier-phased
+// ping-pong above is the slowest way to arrange one step's 18 MFMAs and ~100 softmax VALU (899 cycles per wave and step in the
+// probe, 975 in the kernel); a wave that interleaves its OWN vector work between its OWN MFMAs takes 712.  The real streams are
+// dependent (softmax(u) needs S(u), P.V(u) needs softmax(u)), so the wave keeps two tiles in flight: iteration u issues
+//      MFMAs    P.V of tile u-1  (P from iteration u-1, V^T of tile u-1)   and   S^T = K Q^T of tile u+1
+//      VALU     online softmax of tile u  (S from iteration u-1)
+// -- three mutually independent pieces.  The max pass rides on the first four P.V MFMAs, the lazy-rescale decision follows,
+// the exp2 / cvt / swap pass rides on the remaining P.V MFMAs and the six S MFMAs; a rescale of O (rare) is applied after the
+// iteration's last P.V MFMA.  One s_barrier per tile (tile u+1 visible, slot of tile u-2 free), no wave-group stagger; K / V
+// tiles live in a 4-slot ring (tile t is read in iterations t-1 .. t+1, its DMA is issued in iteration t-2).  All operand
+// fragments of an iteration are requested up front (V^T at the top, K after the first MFMAs: never more than 15 LDS reads in
+// flight) so that their latency is covered by the wave's own work.  Same arithmetic, layouts and epilogue as
+// attn_fwd_hyb_kernel; S is double-buffered in registers, hence 8 waves per CU (256 VGPRs) instead of 16.
+template <int DH, int NWAVES = 8, int AHEAD = 2, int RING = 4>
+__global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8 ? 1 : 3)) void attn_fwd_il_kernel(AttnFwdArgs p, const void* __restrict__ V, long ldv, int nqb, int remap) {
+  using G = Geo<DH>;
+  constexpr int CPR = G::CPR, DN = G::DN, ROWB = G::ROWB, TILE = G::TILE;
+  constexpr int STAGE = 2 * TILE, QW = 2;
+  constexpr int NK = (DH + 15) / 16;
+  constexpr bool ONES = (DH % 16) != 0;
+  constexpr bool PADONES = ONES && G::CPRP > G::CPR;
+  static_assert(!ONES || PADONES, "spare V^T rows come from the padded LDS pitch");
+  static_assert(2 * NK <= G::CPRP, "K fragment reads stay inside the LDS row");
+  constexpr int LROW = DH % 16;
+  constexpr float RESCALE_THR = 6.0f;
+  // K / V ring: iteration u requests tile u + AHEAD; a tile is last read (its V) in iteration t + 1, so tiles u - 1 .. u + AHEAD
+  // are live: AHEAD + 2 of RING slots (power of two).  NWAVES = 8: one workgroup of 256 queries per CU (2 waves per SIMD);
+  // NWAVES = 4: 128 queries per workgroup, three workgroups per CU (3 waves per SIMD, three independent barrier domains).
+  static_assert(AHEAD >= 2 && AHEAD + 2 <= RING && (RING & (RING - 1)) == 0, "ring depth");
+  constexpr int NTHR = 64 * NWAVES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, lq = lane & 15, l31 = lane & 31, hi = lane >> 5;
+  int bh, qb;
+  {
+    const int id = blockIdx.x;
+    if (remap) { const int xcd = id & 7, slot = id >> 3; bh = xcd + 8 * (slot / nqb); qb = slot - (slot / nqb) * nqb; }
+    else { bh = id / nqb; qb = id - bh * nqb; }
+  }
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int q0 = qb * (32 * NWAVES) + wave * 32;
+  const float sl2 = p.scale * 1.4426950408889634f;
+
+  for (int i = tid; i < (16 * ROWB + 64) / 4; i += NTHR) reinterpret_cast<uint32_t*>(smem + RING * STAGE)[i] = 0u;
+  init_pads<DH>(smem, 2 * RING, 0u, 0x3F803F80u, tid, NTHR);   // K pad = 0 (meets Q zeros); V pad = 1.0: rows DH.. of V^T
+
+  u32x4_t qh[NK];
+  {
+    const char* qp = (const char*)p.Q + (((long)b * p.N + q0 + l31) * p.ldq + (long)h * DH) * 2;
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+      const int c = 2 * j + hi;
+      qh[j] = (c < CPR) ? *reinterpret_cast<const u32x4_t*>(qp + c * 16) : u32x4_t{0u, 0u, 0u, 0u};
+    }
+  }
+  const char* kbase = (const char*)p.K + ((long)b * p.Nkv * p.ldk + (long)h * DH) * 2;
+  const char* vbase = (const char*)V + ((long)b * p.Nkv * ldv + (long)h * DH) * 2;
+
+  f32x4_t ot[DN][QW];
+#pragma unroll
+  for (int i = 0; i < DN; ++i)
+#pragma unroll
+    for (int f = 0; f < QW; ++f) ot[i][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_run = -1e30f, l_run = 0.f;
+  f32x16_t sa[2], sb[2];                       // S^T of the tile being soft-maxed / of the next one (roles alternate)
+  u32x4_t pb[2][QW];                           // P^T operands of the tile whose P.V is pending
+
+  constexpr int CPRP = G::CPRP, NJ = (CPRP + NWAVES - 1) / NWAVES;
+  int koff[NJ], voff[NJ];
+  bool real[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = (wave + NWAVES * j) * 64 + lane, r = c / CPRP, col = c - r * CPRP;
+    real[j] = col < CPR;
+    const int cc = (real[j] ? col : 0) * 16;
+    koff[j] = r * (int)(p.ldk * 2) + cc;
+    voff[j] = r * (int)(ldv * 2) + cc;
+  }
+  auto issue = [&](int t, int slot) {
+    const char* kb = kbase + (long)t * 64 * p.ldk * 2;
+    const char* vb = vbase + (long)t * 64 * ldv * 2;
+    char* dst = smem + slot * STAGE;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      if (wave + NWAVES * j < CPRP && real[j]) {
+        glds16(kb + koff[j], dst + (wave + NWAVES * j) * 1024);
+        glds16(vb + voff[j], dst + TILE + (wave + NWAVES * j) * 1024);
+      }
+  };
+
+  // wait until at most `tiles` of this wave's most recent tile requests are still in flight.  A wave issues 2 DMA instructions
+  // (K, V) per tile for every j with wave + NWAVES j < CPRP: the count differs between waves, the branch is wave-uniform.
+  int per = 0;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) per += (wave + NWAVES * j < CPRP) ? 2 : 0;
+  auto dma_wait = [&](int tiles) {
+    const int n = (tiles > AHEAD - 1 ? AHEAD - 1 : tiles) * per;
+    switch (n) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;      // (over-waiting is always safe)
+    }
+  };
+  static_assert(NJ <= 2, "dma_wait cases");
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const int kr = (l31 & 19) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);             // see attn_fwd_hyb_kernel
+  const uint32_t krow = kr * ROWB + hi * 16;
+  const uint32_t troff = (4 * g + ((lane >> 2) & 3)) * ROWB + (lane & 3) * 8;
+  const int nt = p.Nkv / 64;
+
+  auto qk_tile = [&](auto Sc, const u32x4_t (&ka)[2][NK], f32x16_t& dst) {   // S^T of one 32-key half: NK MFMAs
+    constexpr int s_ = decltype(Sc)::value;
+    f32x16_t acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NK; ++j)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ka[s_][j]), __builtin_bit_cast(bf16x8_t, qh[j]), acc, 0, 0, 0);
+    dst = acc;
+  };
+
+  // ---- one iteration.  cur = S(u) (complete), nxt receives S(u+1); HAS_PV: u >= 1; HAS_QK: u + 1 < nt
+  auto body = [&](auto PVc, auto QKc, f32x16_t (&cur)[2], f32x16_t (&nxt)[2], int u) {
+    constexpr bool HAS_PV = decltype(PVc)::value, HAS_QK = decltype(QKc)::value;
+    {   // tile u + 1 must have landed; tiles u + 2 .. u + AHEAD - 1 (those that exist) may still be in flight
+      const int later = min(u + AHEAD - 1, nt - 1) - (u + 1);
+      dma_wait(later < 0 ? 0 : later);
+    }
+    __builtin_amdgcn_s_barrier();
+    if (u + AHEAD < nt) issue(u + AHEAD, (u + AHEAD) & (RING - 1));
+    const uint32_t kt = lds0 + ((u + 1) & (RING - 1)) * STAGE, vt = lds0 + ((u + RING - 1) & (RING - 1)) * STAGE + TILE;   // K(u+1), V(u-1)
+    u32x4_t va[DN][2], ka[2][NK];
+    if constexpr (HAS_PV) {
+      static_for<0, DN>([&](auto Jc) {
+        constexpr int J = decltype(Jc)::value;
+        va[J][0] = tr_frag<ROWB, 0>(vt + troff + J * 32);
+        va[J][1] = tr_frag<ROWB, 1>(vt + troff + J * 32);
+      });
+    }
+    constexpr int NVR = HAS_PV ? 4 * DN : 0;             // LDS instructions in flight for V^T (2 per fragment, 2 fragments per group)
+    constexpr int NKR = HAS_QK ? 2 * NK : 0;
+    static_assert(4 * (DN - 1) + 2 * NK <= 15, "LDS reads in flight");
+
+    // ---- part A: running maximum of the 32 scores of this lane's query, beside the first P.V group
+    float mx = cur[0][0];
+    auto max_slice = [&](auto Ic) {
+      constexpr int i = decltype(Ic)::value;                  // 4 slices of 8 scores
+#pragma unroll
+      for (int r = 0; r < 8; ++r) mx = fmaxf(mx, cur[i >> 1][(i & 1) * 8 + r]);
+    };
+    if constexpr (HAS_PV) {
+      lgkm_wait<(NVR - 4 > 15 ? 15 : NVR - 4)>();
+      pin(va[0][0]); pin(va[0][1]);
+      static_for<0, 4>([&](auto Ic) {
+        constexpr int i = decltype(Ic)::value;
+        Mma<bf16_t>::run(va[0][i >> 1], pb[i >> 1][i & 1], ot[0][i & 1]);
+        max_slice(Ic);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    } else {
+      static_for<0, 4>([&](auto Ic) { max_slice(Ic); });
+    }
+    if constexpr (HAS_QK) {
+      static_for<0, 2>([&](auto Sc) {
+        constexpr int s_ = decltype(Sc)::value;
+        static_for<0, NK>([&](auto Kc) {
+          constexpr int j = decltype(Kc)::value;
+          ka[s_][j] = lds_read_b128_off<s_ * 32 * ROWB + j * 32>(kt + krow);
+        });
+      });
+    }
+    // ---- lazy rescale decision (wave-uniform branch, rare after the first tiles); O is rescaled at the END of the iteration
+    float alpha = 1.0f;
+    const bool resc = __any(mx * sl2 > m_run + RESCALE_THR);
+    if (resc) {
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx * sl2);
+      alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+    }
+    // ---- part B: exp2 / pack / swap in 18 chunks of 4 instructions, beside the remaining P.V groups and the S MFMAs
+    float ls = 0.f;
+    uint32_t pk[2][8];
+    auto chunk = [&](auto Cc) {
+      constexpr int c = decltype(Cc)::value;
+      constexpr int s_ = c / 9, k = c % 9;
+      if constexpr (k < 8) {
+        const f32x2_t x = f32x2_t{cur[s_][2 * k], cur[s_][2 * k + 1]} * sl2 - m_run;
+        const float e0 = __builtin_amdgcn_exp2f(x.x), e1 = __builtin_amdgcn_exp2f(x.y);
+        if constexpr (!ONES) ls += e0 + e1;
+        pk[s_][k] = pack2bf(e0, e1);
+      } else {
+        const auto s0 = __builtin_amdgcn_permlane16_swap(pk[s_][0], pk[s_][2], false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(pk[s_][1], pk[s_][3], false, false);
+        const auto s2 = __builtin_amdgcn_permlane16_swap(pk[s_][4], pk[s_][6], false, false);
+        const auto s3 = __builtin_amdgcn_permlane16_swap(pk[s_][5], pk[s_][7], false, false);
+        pb[s_][0] = u32x4_t{s0[0], s1[0], s2[0], s3[0]};
+        pb[s_][1] = u32x4_t{s0[1], s1[1], s2[1], s3[1]};
+      }
+    };
+    // MFMA slots of part B: (DN - 1) * 4 P.V MFMAs (weight 1 each), then 2 * NK S MFMAs (weight 2 each); the 18 chunks are
+    // spread over them by weight.  The swap chunks (8 and 17) overwrite pb: chunk 8 must follow the last P.V MFMA.
+    constexpr int NPV = HAS_PV ? (DN - 1) * 4 : 0, NQK = HAS_QK ? 2 * NK : 0, NM = NPV + NQK;
+    constexpr int WTOT = NPV + 2 * NQK;
+    auto cend = [](int i) constexpr {                  // chunks [cend(i - 1), cend(i)) follow MFMA slot i
+      const int npv = HAS_PV ? (DN - 1) * 4 : 0, nqk = HAS_QK ? 2 * NK : 0, wtot = npv + 2 * nqk;
+      const int w = (i + 1 <= npv) ? (i + 1) : npv + 2 * (i + 1 - npv);
+      int e = (18 * w) / wtot;
+      if (i + 1 <= npv && e > 8) e = 8;              // no swap chunk before the last P.V MFMA has been issued
+      if (i + 1 == npv + nqk) e = 18;
+      return e;
+    };
+    static_assert(NM > 0 && WTOT > 0, "an iteration has matrix work");
+    static_for<0, NM>([&](auto Ic) {
+      constexpr int i = decltype(Ic)::value;
+      if constexpr (i < NPV) {
+        constexpr int J = 1 + i / 4, q = i % 4;
+        if constexpr (q == 0) {
+          constexpr int left = NVR - 4 * (J + 1) + NKR;     // LDS reads issued after this group's
+          lgkm_wait<(left > 15 ? 15 : left)>();
+          pin(va[J][0]); pin(va[J][1]);
+        }
+        Mma<bf16_t>::run(va[J][q >> 1], pb[q >> 1][q & 1], ot[J][q & 1]);
+      } else {
+        constexpr int m = i - NPV, s_ = m / NK, j = m % NK;
+        if constexpr (j == 0) {
+          lgkm_wait<(s_ == 0 ? NK : 0)>();
+#pragma unroll
+          for (int jj = 0; jj < NK; ++jj) pin(ka[s_][jj]);
+        }
+        // (one accumulator chain per 32-key half; the first MFMA of a half starts from zero)
+        if constexpr (j == 0) nxt[s_] = f32x16_t{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        nxt[s_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ka[s_][j]), __builtin_bit_cast(bf16x8_t, qh[j]), nxt[s_], 0, 0, 0);
+      }
+      constexpr int lo = i == 0 ? 0 : cend(i - 1), hi_ = cend(i);
+      static_for<lo, hi_>([&](auto Cc) { chunk(Cc); });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if constexpr (!ONES) l_run += ls;
+    if (resc) {                                          // after the iteration's last P.V MFMA: O(u-1) -> alpha O(u-1)
+#pragma unroll
+      for (int f = 0; f < QW; ++f) {
+        const float af = __shfl(alpha, 16 * f + lq, 64);
+#pragma unroll
+        for (int i = 0; i < DN; ++i) ot[i][f] *= af;
+      }
+    }
+  };
+
+#pragma unroll
+  for (int t = 0; t < AHEAD; ++t)
+    if (t < nt) issue(t, t);
+  dma_wait(min(AHEAD, nt) - 1);            // tile 0
+  __syncthreads();
+  {   // S(0)
+    u32x4_t ka[2][NK];
+    static_for<0, 2>([&](auto Sc) {
+      constexpr int s_ = decltype(Sc)::value;
+      static_for<0, NK>([&](auto Kc) {
+        constexpr int j = decltype(Kc)::value;
+        ka[s_][j] = lds_read_b128_off<s_ * 32 * ROWB + j * 32>(lds0 + krow);
+      });
+    });
+    lgkm_wait<0>();
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+      for (int j = 0; j < NK; ++j) pin(ka[s_][j]);
+    qk_tile(std::integral_constant<int, 0>{}, ka, sa[0]);
+    qk_tile(std::integral_constant<int, 1>{}, ka, sa[1]);
+  }
+  // nt >= 2 (launcher): first iteration without P.V, last without S, roles of sa / sb alternate
+  body(std::false_type{}, std::true_type{}, sa, sb, 0);
+  int u = 1;
+  for (; u + 2 < nt; u += 2) {
+    body(std::true_type{}, std::true_type{}, sb, sa, u);
+    body(std::true_type{}, std::true_type{}, sa, sb, u + 1);
+  }
+  if (u + 1 < nt) {        // two iterations left: u (full) and u + 1 (last)
+    body(std::true_type{}, std::true_type{}, sb, sa, u);
+    body(std::true_type{}, std::false_type{}, sa, sb, u + 1);
+  } else {                 // one left
+    body(std::true_type{}, std::false_type{}, sb, sa, u);
+  }
+  {   // P.V of the last tile
+    const uint32_t vt = lds0 + ((nt - 1) & (RING - 1)) * STAGE + TILE;
+    u32x4_t va[2];
+#pragma unroll
+    for (int i = 0; i < DN; ++i) {
+      va[0] = tr_frag<ROWB, 0>(vt + troff + i * 32); va[1] = tr_frag<ROWB, 1>(vt + troff + i * 32);
+      lds_wait();
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+        for (int f = 0; f < QW; ++f) Mma<bf16_t>::run(va[s_], pb[s_][f], ot[i][f]);
+    }
+  }
+
+  // ---- epilogue: normalise, store O rows, log-sum-exp (log2 domain)
+  float l_full = l_run;
+  if constexpr (!ONES) l_full += __shfl_xor(l_full, 32, 64);
+#pragma unroll
+  for (int f = 0; f < QW; ++f) {
+    float l;
+    if constexpr (ONES) l = __shfl(ot[DN - 1][f][LROW & 3], lq + 16 * (LROW >> 2), 64);
+    else l = __shfl(l_full, 16 * f + lq, 64);
+    const float m = __shfl(m_run, 16 * f + lq, 64);
+    const float inv = 1.0f / l;
+    const int row = q0 + f * 16 + lq;
+    bf16_t* op = reinterpret_cast<bf16_t*>(p.O) + ((long)b * p.N + row) * p.ldo + (long)h * DH;
+#pragma unroll
+    for (int i = 0; i < DN; ++i) {
+      const int d0 = i * 16 + 4 * g;
+      if (d0 < DH) {
+        float v[4] = {ot[i][f][0] * inv, ot[i][f][1] * inv, ot[i][f][2] * inv, ot[i][f][3] * inv};
+        store4(op + d0, v);
+      }
+    }
+    if (p.LSE && g == 0) p.LSE[((long)b * p.H + h) * p.lse_stride + row] = m + __builtin_amdgcn_logf(l);
+  }
+}
+
 // =============================================================================== dK / dV
 // TAIL: N is not a multiple of 64 (query masking)
 template <int DH, int KF, bool TAIL, bool PRIO = false>
@@ -1671,6 +1999,22 @@ static int launch_fwd_hyb_t(const AttnFwdArgs& a, const void* V, long ldv, hipSt
   return CL_OK;
 }
 
+template <int DH, int NWAVES, int AHEAD, int RING>
+static int launch_fwd_il_t(const AttnFwdArgs& a, const void* V, long ldv, hipStream_t st) {
+  constexpr int LDS = RING * 2 * Geo<DH>::TILE + 16 * Geo<DH>::ROWB + 64;
+  static bool done = false;
+  if (!done) {
+    if (set_lds(&attn_fwd_il_kernel<DH, NWAVES, AHEAD, RING>, LDS)) return CL_ELAUNCH;
+    done = true;
+  }
+  const int nqb = a.N / (32 * NWAVES);
+  const long grid = (long)nqb * a.H * a.B;
+  const int remap = ((a.B * a.H) % 8 == 0) ? 1 : 0;
+  hipLaunchKernelGGL((attn_fwd_il_kernel<DH, NWAVES, AHEAD, RING>), dim3((unsigned)grid), dim3(64 * NWAVES), LDS, st, a, V, ldv, nqb, remap);
+  CL_CHECK_LAUNCH();
+  return CL_OK;
+}
+
 template <int DH>
 static bool launch_fwd_pp(const AttnFwdArgs& a, const void* V, long ldv, hipStream_t st, int* rc) {
   if constexpr (DH == 40 || DH == 80) {
@@ -1678,6 +2022,17 @@ static bool launch_fwd_pp(const AttnFwdArgs& a, const void* V, long ldv, hipStre
     if (g_attn_variant == 1 || a.N % 256 || a.Nkv % 64 || a.Nkv < 128 || grid < 256) return false;
     switch (g_attn_variant) {
       case 13: *rc = launch_fwd_hyb_t<DH, 3>(a, V, ldv, st); break;                // 32x32x16 Q.K^T, lookahead 3 groups
+      // 15 / 16 / 17: per-wave software pipeline (round-4 candidates, d_head 40 only: its fragment-read budget).  Measured at the
+      // end of round 3 (profiles/r03_attention/fwd_wave_pipeline_v*.json): results bit-identical to the hybrid kernel; 8 waves per
+      // workgroup, one workgroup per CU: 265 us (tile requests 1 ahead, variant 15) / 271 us (3 ahead, 17) against 244-247 us.
+      // 16 = four waves per workgroup, three workgroups per CU (3 waves per SIMD): built, NOT yet run on a GPU.
+      case 15: case 16: case 17:
+        if constexpr (DH == 40) {
+          if (g_attn_variant == 15) *rc = launch_fwd_il_t<DH, 8, 2, 4>(a, V, ldv, st);
+          else if (g_attn_variant == 16) *rc = launch_fwd_il_t<DH, 4, 2, 4>(a, V, ldv, st);
+          else *rc = launch_fwd_il_t<DH, 8, 4, 8>(a, V, ldv, st);
+        } else *rc = launch_fwd_hyb_t<DH, 2>(a, V, ldv, st);
+        break;
       case 14: *rc = launch_fwd_hyb_t<DH, 2>(a, V, ldv, st); break;                // ... lookahead 2          // 2, 5: A/B probes (tests/tools/attn_bench.py); 3 = ping-pong backward too
       case 2: *rc = launch_fwd_pp_t<DH, 2, 0>(a, V, ldv, st); break;
       case 5: *rc = launch_fwd_pp_t<DH, 4, 0, true>(a, V, ldv, st); break;
