@@ -893,8 +893,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hyb_kernel(AttnFwdArgs p, con
 // fragments of an iteration are requested up front (V^T at the top, K after the first MFMAs: never more than 15 LDS reads in
 // flight) so that their latency is covered by the wave's own work.  Same arithmetic, layouts and epilogue as
 // attn_fwd_hyb_kernel; S is double-buffered in registers, hence 8 waves per CU (256 VGPRs) instead of 16.
-template <int DH, int NWAVES = 8, int AHEAD = 2, int RING = 4>
-__global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8 ? 1 : 3)) void attn_fwd_il_kernel(AttnFwdArgs p, const void* __restrict__ V, long ldv, int nqb, int remap) {
+template <int DH, int NWAVES = 8, int AHEAD = 2, int RING = 4, bool SINGLE = false>
+__global__ __launch_bounds__(64 * NWAVES, (SINGLE ? 4 : NWAVES == 8 ? 1 : 3)) void attn_fwd_il_kernel(AttnFwdArgs p, const void* __restrict__ V, long ldv, int nqb, int remap) {
   using G = Geo<DH>;
   constexpr int CPR = G::CPR, DN = G::DN, ROWB = G::ROWB, TILE = G::TILE;
   constexpr int STAGE = 2 * TILE, QW = 2;
@@ -908,7 +908,11 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8 ? 1 : 3)) void attn_fwd_i
   // K / V ring: iteration u requests tile u + AHEAD; a tile is last read (its V) in iteration t + 1, so tiles u - 1 .. u + AHEAD
   // are live: AHEAD + 2 of RING slots (power of two).  NWAVES = 8: one workgroup of 256 queries per CU (2 waves per SIMD);
   // NWAVES = 4: 128 queries per workgroup, three workgroups per CU (3 waves per SIMD, three independent barrier domains).
+  // SINGLE: S is NOT double-buffered (32 registers less: 4 waves per SIMD again, two 8-wave workgroups per CU).  The S MFMAs of
+  // tile u + 1 then overwrite S(u) in place, half by half, each half as soon as the exp2 pass has consumed it: the first half's
+  // three MFMAs run beside the exp2 pass of the second half, the second half's beside the last swap chunk only.
   static_assert(AHEAD >= 2 && AHEAD + 2 <= RING && (RING & (RING - 1)) == 0, "ring depth");
+  static_assert(!SINGLE || DH == 40, "the in-place schedule is laid out for NK = 3");
   constexpr int NTHR = 64 * NWAVES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -1015,15 +1019,27 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8 ? 1 : 3)) void attn_fwd_i
     __builtin_amdgcn_s_barrier();
     if (u + AHEAD < nt) issue(u + AHEAD, (u + AHEAD) & (RING - 1));
     const uint32_t kt = lds0 + ((u + 1) & (RING - 1)) * STAGE, vt = lds0 + ((u + RING - 1) & (RING - 1)) * STAGE + TILE;   // K(u+1), V(u-1)
-    u32x4_t va[DN][2], ka[2][NK];
-    if constexpr (HAS_PV) {
-      static_for<0, DN>([&](auto Jc) {
-        constexpr int J = decltype(Jc)::value;
-        va[J][0] = tr_frag<ROWB, 0>(vt + troff + J * 32);
-        va[J][1] = tr_frag<ROWB, 1>(vt + troff + J * 32);
+    // Fragment requests.  Default: everything up front (V^T here, K after part A).  SINGLE (128-register budget): just in time
+    // -- V^T groups 0, 1 here, group 2 after part A into group 0's registers, K half 0 before the last P.V group, K half 1
+    // before the S MFMAs of half 0 -- at most two groups / halves are live at any time.
+    constexpr int NVG = SINGLE ? 2 : DN;
+    static_assert(!SINGLE || DN == 3, "just-in-time fragment schedule");
+    u32x4_t va[NVG][2], ka[2][NK];
+    auto req_v = [&](auto Jc) {
+      constexpr int J = decltype(Jc)::value;
+      va[J % NVG][0] = tr_frag<ROWB, 0>(vt + troff + J * 32);
+      va[J % NVG][1] = tr_frag<ROWB, 1>(vt + troff + J * 32);
+    };
+    auto req_k = [&](auto Sc) {
+      constexpr int s_ = decltype(Sc)::value;
+      static_for<0, NK>([&](auto Kc) {
+        constexpr int j = decltype(Kc)::value;
+        ka[s_][j] = lds_read_b128_off<s_ * 32 * ROWB + j * 32>(kt + krow);
       });
-    }
-    constexpr int NVR = HAS_PV ? 4 * DN : 0;             // LDS instructions in flight for V^T (2 per fragment, 2 fragments per group)
+    };
+    if constexpr (HAS_PV) static_for<0, NVG>([&](auto Jc) { req_v(Jc); });
+    else if constexpr (SINGLE && HAS_QK) req_k(std::integral_constant<int, 0>{});
+    constexpr int NVR = HAS_PV ? 4 * NVG : 0;            // LDS instructions in flight for V^T (2 per fragment, 2 fragments per group)
     constexpr int NKR = HAS_QK ? 2 * NK : 0;
     static_assert(4 * (DN - 1) + 2 * NK <= 15, "LDS reads in flight");
 
@@ -1046,14 +1062,11 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8 ? 1 : 3)) void attn_fwd_i
     } else {
       static_for<0, 4>([&](auto Ic) { max_slice(Ic); });
     }
-    if constexpr (HAS_QK) {
-      static_for<0, 2>([&](auto Sc) {
-        constexpr int s_ = decltype(Sc)::value;
-        static_for<0, NK>([&](auto Kc) {
-          constexpr int j = decltype(Kc)::value;
-          ka[s_][j] = lds_read_b128_off<s_ * 32 * ROWB + j * 32>(kt + krow);
-        });
-      });
+    if constexpr (SINGLE) {
+      if constexpr (HAS_PV) req_v(std::integral_constant<int, 2>{});         // into group 0's registers (its MFMAs are issued)
+    } else if constexpr (HAS_QK) {
+      req_k(std::integral_constant<int, 0>{});
+      req_k(std::integral_constant<int, 1>{});
     }
     // ---- lazy rescale decision (wave-uniform branch, rare after the first tiles); O is rescaled at the END of the iteration
     float alpha = 1.0f;
@@ -1091,26 +1104,52 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8 ? 1 : 3)) void attn_fwd_i
     constexpr int WTOT = NPV + 2 * NQK;
     auto cend = [](int i) constexpr {                  // chunks [cend(i - 1), cend(i)) follow MFMA slot i
       const int npv = HAS_PV ? (DN - 1) * 4 : 0, nqk = HAS_QK ? 2 * NK : 0, wtot = npv + 2 * nqk;
-      const int w = (i + 1 <= npv) ? (i + 1) : npv + 2 * (i + 1 - npv);
-      int e = (18 * w) / wtot;
-      if (i + 1 <= npv && e > 8) e = 8;              // no swap chunk before the last P.V MFMA has been issued
+      int e;
+      if (SINGLE && HAS_QK) {
+        // chunks 0-7 read S half 0, 9-16 read half 1; slot npv starts overwriting half 0, slot npv + NK half 1
+        if (i + 1 <= npv) e = i + 1 < 8 ? i + 1 : 8;
+        else { const int kq = i - npv; e = kq < NK ? 8 + ((kq + 1) * 9) / NK : 18; }
+        if (i + 1 <= npv && i + 1 == npv && e < 8) e = 8;
+      } else {
+        const int w = (i + 1 <= npv) ? (i + 1) : npv + 2 * (i + 1 - npv);
+        e = (18 * w) / wtot;
+        if (i + 1 <= npv && e > 8) e = 8;            // no swap chunk before the last P.V MFMA has been issued
+      }
       if (i + 1 == npv + nqk) e = 18;
       return e;
     };
+    constexpr int PRE = (SINGLE && HAS_QK && !HAS_PV) ? 8 : 0;     // first iteration, in place: half 0 is consumed before its MFMAs
+    static_for<0, PRE>([&](auto Cc) { chunk(Cc); });
     static_assert(NM > 0 && WTOT > 0, "an iteration has matrix work");
     static_for<0, NM>([&](auto Ic) {
       constexpr int i = decltype(Ic)::value;
       if constexpr (i < NPV) {
         constexpr int J = 1 + i / 4, q = i % 4;
         if constexpr (q == 0) {
-          constexpr int left = NVR - 4 * (J + 1) + NKR;     // LDS reads issued after this group's
-          lgkm_wait<(left > 15 ? 15 : left)>();
-          pin(va[J][0]); pin(va[J][1]);
+          if constexpr (SINGLE) {
+            if constexpr (J == 1) lgkm_wait<4>();                               // group 2 still in flight
+            else {
+              if constexpr (HAS_QK) req_k(std::integral_constant<int, 0>{});
+              lgkm_wait<(HAS_QK ? NK : 0)>();
+            }
+          } else {
+            constexpr int left = NVR - 4 * (J + 1) + NKR;     // LDS reads issued after this group's
+            lgkm_wait<(left > 15 ? 15 : left)>();
+          }
+          pin(va[J % NVG][0]); pin(va[J % NVG][1]);
         }
-        Mma<bf16_t>::run(va[J][q >> 1], pb[q >> 1][q & 1], ot[J][q & 1]);
+        Mma<bf16_t>::run(va[J % NVG][q >> 1], pb[q >> 1][q & 1], ot[J][q & 1]);
       } else {
         constexpr int m = i - NPV, s_ = m / NK, j = m % NK;
-        if constexpr (j == 0) {
+        if constexpr (SINGLE) {
+          // half 1's fragment j is requested right after half 0's MFMA j (whose fragment is dead by then): 12 fragment registers
+          if constexpr (s_ == 0 && j == 0) {
+            lgkm_wait<0>();
+#pragma unroll
+            for (int jj = 0; jj < NK; ++jj) pin(ka[0][jj]);
+          }
+          if constexpr (s_ == 1) { lgkm_wait<NK - 1 - j>(); pin(ka[1][j]); }
+        } else if constexpr (j == 0) {
           lgkm_wait<(s_ == 0 ? NK : 0)>();
 #pragma unroll
           for (int jj = 0; jj < NK; ++jj) pin(ka[s_][jj]);
@@ -1118,8 +1157,9 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8 ? 1 : 3)) void attn_fwd_i
         // (one accumulator chain per 32-key half; the first MFMA of a half starts from zero)
         if constexpr (j == 0) nxt[s_] = f32x16_t{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         nxt[s_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ka[s_][j]), __builtin_bit_cast(bf16x8_t, qh[j]), nxt[s_], 0, 0, 0);
+        if constexpr (SINGLE && s_ == 0) ka[1][j] = lds_read_b128_off<32 * ROWB + j * 32>(kt + krow);
       }
-      constexpr int lo = i == 0 ? 0 : cend(i - 1), hi_ = cend(i);
+      constexpr int lo = i == 0 ? PRE : (cend(i - 1) > PRE ? cend(i - 1) : PRE), hi_ = cend(i) > lo ? cend(i) : lo;
       static_for<lo, hi_>([&](auto Cc) { chunk(Cc); });
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -1156,18 +1196,19 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8 ? 1 : 3)) void attn_fwd_i
     qk_tile(std::integral_constant<int, 0>{}, ka, sa[0]);
     qk_tile(std::integral_constant<int, 1>{}, ka, sa[1]);
   }
-  // nt >= 2 (launcher): first iteration without P.V, last without S, roles of sa / sb alternate
-  body(std::false_type{}, std::true_type{}, sa, sb, 0);
+  // nt >= 2 (launcher): first iteration without P.V, last without S, roles of sa / sb alternate (SINGLE: sb IS sa)
+  f32x16_t (&sbr)[2] = SINGLE ? sa : sb;
+  body(std::false_type{}, std::true_type{}, sa, sbr, 0);
   int u = 1;
   for (; u + 2 < nt; u += 2) {
-    body(std::true_type{}, std::true_type{}, sb, sa, u);
-    body(std::true_type{}, std::true_type{}, sa, sb, u + 1);
+    body(std::true_type{}, std::true_type{}, sbr, sa, u);
+    body(std::true_type{}, std::true_type{}, sa, sbr, u + 1);
   }
   if (u + 1 < nt) {        // two iterations left: u (full) and u + 1 (last)
-    body(std::true_type{}, std::true_type{}, sb, sa, u);
-    body(std::true_type{}, std::false_type{}, sa, sb, u + 1);
+    body(std::true_type{}, std::true_type{}, sbr, sa, u);
+    body(std::true_type{}, std::false_type{}, sa, sbr, u + 1);
   } else {                 // one left
-    body(std::true_type{}, std::false_type{}, sb, sa, u);
+    body(std::true_type{}, std::false_type{}, sbr, sa, u);
   }
   {   // P.V of the last tile
     const uint32_t vt = lds0 + ((nt - 1) & (RING - 1)) * STAGE + TILE;
@@ -1999,18 +2040,18 @@ static int launch_fwd_hyb_t(const AttnFwdArgs& a, const void* V, long ldv, hipSt
   return CL_OK;
 }
 
-template <int DH, int NWAVES, int AHEAD, int RING>
+template <int DH, int NWAVES, int AHEAD, int RING, bool SINGLE = false>
 static int launch_fwd_il_t(const AttnFwdArgs& a, const void* V, long ldv, hipStream_t st) {
   constexpr int LDS = RING * 2 * Geo<DH>::TILE + 16 * Geo<DH>::ROWB + 64;
   static bool done = false;
   if (!done) {
-    if (set_lds(&attn_fwd_il_kernel<DH, NWAVES, AHEAD, RING>, LDS)) return CL_ELAUNCH;
+    if (set_lds(&attn_fwd_il_kernel<DH, NWAVES, AHEAD, RING, SINGLE>, LDS)) return CL_ELAUNCH;
     done = true;
   }
   const int nqb = a.N / (32 * NWAVES);
   const long grid = (long)nqb * a.H * a.B;
   const int remap = ((a.B * a.H) % 8 == 0) ? 1 : 0;
-  hipLaunchKernelGGL((attn_fwd_il_kernel<DH, NWAVES, AHEAD, RING>), dim3((unsigned)grid), dim3(64 * NWAVES), LDS, st, a, V, ldv, nqb, remap);
+  hipLaunchKernelGGL((attn_fwd_il_kernel<DH, NWAVES, AHEAD, RING, SINGLE>), dim3((unsigned)grid), dim3(64 * NWAVES), LDS, st, a, V, ldv, nqb, remap);
   CL_CHECK_LAUNCH();
   return CL_OK;
 }
@@ -2026,10 +2067,12 @@ static bool launch_fwd_pp(const AttnFwdArgs& a, const void* V, long ldv, hipStre
       // end of round 3 (profiles/r03_attention/fwd_wave_pipeline_v*.json): results bit-identical to the hybrid kernel; 8 waves per
       // workgroup, one workgroup per CU: 265 us (tile requests 1 ahead, variant 15) / 271 us (3 ahead, 17) against 244-247 us.
       // 16 = four waves per workgroup, three workgroups per CU (3 waves per SIMD): built, NOT yet run on a GPU.
-      case 15: case 16: case 17:
+      // 18 = S single-buffered and overwritten in place (4 waves per SIMD again): built, NOT yet run on a GPU.
+      case 15: case 16: case 17: case 18:
         if constexpr (DH == 40) {
           if (g_attn_variant == 15) *rc = launch_fwd_il_t<DH, 8, 2, 4>(a, V, ldv, st);
           else if (g_attn_variant == 16) *rc = launch_fwd_il_t<DH, 4, 2, 4>(a, V, ldv, st);
+          else if (g_attn_variant == 18) *rc = launch_fwd_il_t<DH, 8, 2, 4, true>(a, V, ldv, st);
           else *rc = launch_fwd_il_t<DH, 8, 4, 8>(a, V, ldv, st);
         } else *rc = launch_fwd_hyb_t<DH, 2>(a, V, ldv, st);
         break;

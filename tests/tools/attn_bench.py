@@ -123,7 +123,7 @@ def case(dh, N, Nkv, B, variants, bwd, check=True, rounds=1):
     return out
 
 
-NAMES = {0: "default(fwd pingpong, bwd sync)", 1: "sync", 2: "fwd_pp_lookahead2", 3: "fwd+bwd pingpong", 5: "fwd_pp_1wg_per_cu", 6: "fwd_pp_setprio", 7: "fwd_pp_static_prio", 8: "fwd_pp_scalar_fma", 9: "fwd_pp_prio+static+scalar", 10: "fwd_pp_setprio+static", 11: "bwd_setprio", 12: "fwd_pp_r02(no prio)", 13: "fwd_hybrid32_la3", 14: "fwd_hybrid32_la2", 15: "fwd_wave_pipeline_8w", 16: "fwd_wave_pipeline_4w_3wg", 17: "fwd_wave_pipeline_8w_ahead4"}
+NAMES = {0: "default(fwd pingpong, bwd sync)", 1: "sync", 2: "fwd_pp_lookahead2", 3: "fwd+bwd pingpong", 5: "fwd_pp_1wg_per_cu", 6: "fwd_pp_setprio", 7: "fwd_pp_static_prio", 8: "fwd_pp_scalar_fma", 9: "fwd_pp_prio+static+scalar", 10: "fwd_pp_setprio+static", 11: "bwd_setprio", 12: "fwd_pp_r02(no prio)", 13: "fwd_hybrid32_la3", 14: "fwd_hybrid32_la2", 15: "fwd_wave_pipeline_8w", 16: "fwd_wave_pipeline_4w_3wg", 17: "fwd_wave_pipeline_8w_ahead4", 18: "fwd_wave_pipeline_inplace_4wps"}
 
 
 def main():
