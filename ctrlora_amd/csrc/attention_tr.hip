@@ -893,7 +893,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hyb_kernel(AttnFwdArgs p, con
 // fragments of an iteration are requested up front (V^T at the top, K after the first MFMAs: never more than 15 LDS reads in
 // flight) so that their latency is covered by the wave's own work.  Same arithmetic, layouts and epilogue as
 // attn_fwd_hyb_kernel; S is double-buffered in registers, hence 8 waves per CU (256 VGPRs) instead of 16.
-template <int DH, int NWAVES = 8, int AHEAD = 2, int RING = 4, bool SINGLE = false>
+template <int DH, int NWAVES = 8, int AHEAD = 2, int RING = 4, bool SINGLE = false, bool FOLD = false>
 __global__ __launch_bounds__(64 * NWAVES, (SINGLE ? 4 : NWAVES == 8 ? 1 : 3)) void attn_fwd_il_kernel(AttnFwdArgs p, const void* __restrict__ V, long ldv, int nqb, int remap) {
   using G = Geo<DH>;
   constexpr int CPR = G::CPR, DN = G::DN, ROWB = G::ROWB, TILE = G::TILE;
@@ -913,6 +913,12 @@ __global__ __launch_bounds__(64 * NWAVES, (SINGLE ? 4 : NWAVES == 8 ? 1 : 3)) vo
   // three MFMAs run beside the exp2 pass of the second half, the second half's beside the last swap chunk only.
   static_assert(AHEAD >= 2 && AHEAD + 2 <= RING && (RING & (RING - 1)) == 0, "ring depth");
   static_assert(!SINGLE || DH == 40, "the in-place schedule is laid out for NK = 3");
+  // FOLD: the caller hands over Q ALREADY multiplied by scale * log2(e) (in production that factor belongs in the to_q weights:
+  // rounding q again costs accuracy), and -m_run travels in the first spare k slot of the 48-deep walk (Q column 40 = -m_run
+  // as bf16, K pad column 40 = 1.0): the matrix product delivers s - m_run and the softmax starts at v_exp_f32 -- 16 packed
+  // fma per step less (probe: 712 -> 630 cycles).  m_run is kept bf16-representable; when it moves (rare branch) the scores in
+  // hand are corrected by the difference and the Q slot is rewritten for the S tiles still to come.
+  static_assert(!FOLD || (DH == 40 && PADONES), "the fold uses the spare k slots of d_head 40");
   constexpr int NTHR = 64 * NWAVES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -930,7 +936,14 @@ __global__ __launch_bounds__(64 * NWAVES, (SINGLE ? 4 : NWAVES == 8 ? 1 : 3)) vo
   const float sl2 = p.scale * 1.4426950408889634f;
 
   for (int i = tid; i < (16 * ROWB + 64) / 4; i += NTHR) reinterpret_cast<uint32_t*>(smem + RING * STAGE)[i] = 0u;
-  init_pads<DH>(smem, 2 * RING, 0u, 0x3F803F80u, tid, NTHR);   // K pad = 0 (meets Q zeros); V pad = 1.0: rows DH.. of V^T
+  if constexpr (FOLD) {   // K pad chunk = (1.0, 0, 0, ...): column DH meets -m_run in Q; V pad = 1.0 as below
+    for (int i = tid; i < 2 * RING * 64; i += NTHR) {
+      const bool vtile = (i >> 6) & 1;
+      const uint4 w = vtile ? make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u) : make_uint4(0x00003F80u, 0u, 0u, 0u);
+      *reinterpret_cast<uint4*>(smem + (long)i * ROWB + CPR * 16) = w;
+    }
+  } else
+    init_pads<DH>(smem, 2 * RING, 0u, 0x3F803F80u, tid, NTHR);   // K pad = 0 (meets Q zeros); V pad = 1.0: rows DH.. of V^T
 
   u32x4_t qh[NK];
   {
@@ -949,7 +962,7 @@ __global__ __launch_bounds__(64 * NWAVES, (SINGLE ? 4 : NWAVES == 8 ? 1 : 3)) vo
   for (int i = 0; i < DN; ++i)
 #pragma unroll
     for (int f = 0; f < QW; ++f) ot[i][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float m_run = -1e30f, l_run = 0.f;
+  float m_run = FOLD ? 0.f : -1e30f, l_run = 0.f;      // FOLD: S(0) is formed against m = 0 and corrected in the first iteration
   f32x16_t sa[2], sb[2];                       // S^T of the tile being soft-maxed / of the next one (roles alternate)
   u32x4_t pb[2][QW];                           // P^T operands of the tile whose P.V is pending
 
@@ -1070,13 +1083,34 @@ __global__ __launch_bounds__(64 * NWAVES, (SINGLE ? 4 : NWAVES == 8 ? 1 : 3)) vo
     }
     // ---- lazy rescale decision (wave-uniform branch, rare after the first tiles); O is rescaled at the END of the iteration
     float alpha = 1.0f;
-    const bool resc = __any(mx * sl2 > m_run + RESCALE_THR);
-    if (resc) {
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx * sl2);
-      alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
-      l_run *= alpha;
+    bool resc;
+    if constexpr (FOLD) {
+      constexpr bool FIRST = !HAS_PV;                       // S(0) was formed against m = 0
+      resc = FIRST ? true : __any(mx > RESCALE_THR);       // cur holds s - m_run
+      if (resc) {
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = FIRST ? m_run + mx : fmaxf(m_run, m_run + mx);
+        const uint32_t mb = pack2bf(m_new, 0.f) & 0xffffu;              // bf16 (round to nearest even)
+        const float m_b = __uint_as_float(mb << 16);
+        const float d = m_b - m_run;
+        alpha = FIRST ? 1.0f : __builtin_amdgcn_exp2f(-d);              // (nothing to rescale in the first iteration)
+        m_run = m_b;
+        l_run *= alpha;
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) cur[s_][r] -= d;                // the tile in hand was formed against the old maximum
+        if (hi) qh[NK - 1][0] = (qh[NK - 1][0] & 0xffff0000u) | (mb ^ 0x8000u);   // Q column DH = -m_run for the S tiles to come
+      }
+    } else {
+      resc = __any(mx * sl2 > m_run + RESCALE_THR);
+      if (resc) {
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx * sl2);
+        alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        l_run *= alpha;
+      }
     }
     // ---- part B: exp2 / pack / swap in 18 chunks of 4 instructions, beside the remaining P.V groups and the S MFMAs
     float ls = 0.f;
@@ -1085,7 +1119,8 @@ __global__ __launch_bounds__(64 * NWAVES, (SINGLE ? 4 : NWAVES == 8 ? 1 : 3)) vo
       constexpr int c = decltype(Cc)::value;
       constexpr int s_ = c / 9, k = c % 9;
       if constexpr (k < 8) {
-        const f32x2_t x = f32x2_t{cur[s_][2 * k], cur[s_][2 * k + 1]} * sl2 - m_run;
+        f32x2_t x = f32x2_t{cur[s_][2 * k], cur[s_][2 * k + 1]};
+        if constexpr (!FOLD) x = x * sl2 - m_run;
         const float e0 = __builtin_amdgcn_exp2f(x.x), e1 = __builtin_amdgcn_exp2f(x.y);
         if constexpr (!ONES) ls += e0 + e1;
         pk[s_][k] = pack2bf(e0, e1);
@@ -2040,18 +2075,18 @@ static int launch_fwd_hyb_t(const AttnFwdArgs& a, const void* V, long ldv, hipSt
   return CL_OK;
 }
 
-template <int DH, int NWAVES, int AHEAD, int RING, bool SINGLE = false>
+template <int DH, int NWAVES, int AHEAD, int RING, bool SINGLE = false, bool FOLD = false>
 static int launch_fwd_il_t(const AttnFwdArgs& a, const void* V, long ldv, hipStream_t st) {
   constexpr int LDS = RING * 2 * Geo<DH>::TILE + 16 * Geo<DH>::ROWB + 64;
   static bool done = false;
   if (!done) {
-    if (set_lds(&attn_fwd_il_kernel<DH, NWAVES, AHEAD, RING, SINGLE>, LDS)) return CL_ELAUNCH;
+    if (set_lds(&attn_fwd_il_kernel<DH, NWAVES, AHEAD, RING, SINGLE, FOLD>, LDS)) return CL_ELAUNCH;
     done = true;
   }
   const int nqb = a.N / (32 * NWAVES);
   const long grid = (long)nqb * a.H * a.B;
   const int remap = ((a.B * a.H) % 8 == 0) ? 1 : 0;
-  hipLaunchKernelGGL((attn_fwd_il_kernel<DH, NWAVES, AHEAD, RING, SINGLE>), dim3((unsigned)grid), dim3(64 * NWAVES), LDS, st, a, V, ldv, nqb, remap);
+  hipLaunchKernelGGL((attn_fwd_il_kernel<DH, NWAVES, AHEAD, RING, SINGLE, FOLD>), dim3((unsigned)grid), dim3(64 * NWAVES), LDS, st, a, V, ldv, nqb, remap);
   CL_CHECK_LAUNCH();
   return CL_OK;
 }
@@ -2068,9 +2103,13 @@ static bool launch_fwd_pp(const AttnFwdArgs& a, const void* V, long ldv, hipStre
       // workgroup, one workgroup per CU: 265 us (tile requests 1 ahead, variant 15) / 271 us (3 ahead, 17) against 244-247 us.
       // 16 = four waves per workgroup, three workgroups per CU (3 waves per SIMD): built, NOT yet run on a GPU.
       // 18 = S single-buffered and overwritten in place (4 waves per SIMD again): built, NOT yet run on a GPU.
-      case 15: case 16: case 17: case 18:
+      // 19 / 20 = 15 / 18 with the scale and -max folded into the matrix product: they expect Q PRE-MULTIPLIED by scale * log2(e)
+      // and ignore `scale` (probe / A-B use only: tests/tools/attn_bench.py pre-scales Q for them): built, NOT yet run on a GPU.
+      case 15: case 16: case 17: case 18: case 19: case 20:
         if constexpr (DH == 40) {
-          if (g_attn_variant == 15) *rc = launch_fwd_il_t<DH, 8, 2, 4>(a, V, ldv, st);
+          if (g_attn_variant == 19) *rc = launch_fwd_il_t<DH, 8, 2, 4, false, true>(a, V, ldv, st);
+          else if (g_attn_variant == 20) *rc = launch_fwd_il_t<DH, 8, 2, 4, true, true>(a, V, ldv, st);
+          else if (g_attn_variant == 15) *rc = launch_fwd_il_t<DH, 8, 2, 4>(a, V, ldv, st);
           else if (g_attn_variant == 16) *rc = launch_fwd_il_t<DH, 4, 2, 4>(a, V, ldv, st);
           else if (g_attn_variant == 18) *rc = launch_fwd_il_t<DH, 8, 2, 4, true>(a, V, ldv, st);
           else *rc = launch_fwd_il_t<DH, 8, 4, 8>(a, V, ldv, st);
