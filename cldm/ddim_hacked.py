@@ -56,6 +56,11 @@ class DDIMSampler(object):
         self.reuse_graph = False
         self._graph_state = None
         self.graph_hits = 0
+        # True (default): a condition IMAGE is VAE-encoded once per sample() call and only its posterior is re-sampled at
+        # every apply_model (ControlLDM.hint_cache).  False: the reference's own schedule -- the encoder runs inside every
+        # apply_model call (cldm_ctrlora_inference.py:165-172: 2 x 1.1 TFLOP per image and denoise step), for measurements
+        # of the reference-faithful form.
+        self.hoist_hint_encode = True
 
     def register_buffer(self, name, attr):
         if isinstance(attr, torch.Tensor) and attr.device != self.model.device:
@@ -97,7 +102,7 @@ class DDIMSampler(object):
         if verbose:
             print(f"Data shape for DDIM sampling is {size}, eta {eta}")
         # condition images do not change during a run: their VAE encode is done once (ControlLDM.hint_cache)
-        scope = getattr(self.model, "hint_cache", None)
+        scope = getattr(self.model, "hint_cache", None) if self.hoist_hint_encode else None
         with (scope() if callable(scope) else contextlib.nullcontext()):
             return self.ddim_sampling(conditioning, size, callback=callback, img_callback=img_callback,
                                       quantize_denoised=quantize_x0, mask=mask, x0=x0, ddim_use_original_steps=False,
@@ -178,8 +183,23 @@ class DDIMSampler(object):
             return tuple((k, tuple((id(t), t._version, tuple(t.shape)) for t in (v if isinstance(v, (list, tuple)) else [v])
                                    if torch.is_tensor(t))) for k, v in sorted(c.items()) if v is not None)
 
+        def _plain(c):     # non-tensor entries of a conditioning dict (cond['task'], ...) are baked into the capture too
+            if c is None:
+                return None
+            return tuple((k, repr(v)) for k, v in sorted(c.items())
+                         if v is not None and not torch.is_tensor(v)
+                         and not (isinstance(v, (list, tuple)) and any(torch.is_tensor(t) for t in v)))
+
+        from ctrlora_amd.engine.nets import WEIGHTS_GENERATION
+        # everything the captured step bakes in by VALUE: the residual scales (the UI's strength slider), the multi-LoRA
+        # weights, only_mid_control, the CFG batching mode, and the generation of the packed weights (a re-pack, a reloaded
+        # checkpoint, a bank switch or a replayed optimizer step makes the cached context K/V and folded LoRA copies stale)
         key = (id(model.engine()), S, tuple(img.shape), float(cfg_scale), float(temperature), _sig(cond), _sig(uncond),
-               np.ascontiguousarray(timesteps).tobytes())
+               np.ascontiguousarray(timesteps).tobytes(),
+               tuple(float(v) for v in getattr(model, "control_scales", ()) or ()),
+               tuple(float(v) for v in (getattr(model, "lora_weights", None) or ())),
+               bool(getattr(model, "only_mid_control", False)), bool(self.batch_cfg), bool(self.hoist_hint_encode), _plain(cond),
+               _plain(uncond), WEIGHTS_GENERATION[0])
         st = self._graph_state if self.reuse_graph else None
         # sample() rebuilds the coefficient table on every call: the kept graph reads ITS table by address (held in st), so a
         # hit needs equal contents, not the same tensor

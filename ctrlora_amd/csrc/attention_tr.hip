@@ -2177,7 +2177,7 @@ int attn_fwd_tr(const AttnFwdArgs& a, const void* V, long ldv, hipStream_t st) {
   }
 }
 
-int g_attn_fuse_delta = 1;   // A/B hook (cl_attention_force_variant(16) clears it)
+int g_attn_fuse_delta = 1;   // A/B hook (cl_debug_attention_fuse_delta(0) clears it)
 
 template <int DH, bool TQ, bool TK>
 static int launch_bwd_tr_sync(const AttnBwdArgs& a, hipStream_t st, bool skip_dq, bool fused_delta = false);

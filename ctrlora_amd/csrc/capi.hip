@@ -2,6 +2,7 @@
 #define CTRLORA_HIP_INTERNAL
 #include "../../include/ctrlora_hip.h"
 #include "attention.h"
+#include "debug_hooks.h"
 #include "elementwise.h"
 #include "gemm.h"
 #include "norm.h"
@@ -41,11 +42,18 @@ int cl_gemm_tune_set(int dtype, int mode, int M, int N, int K1, int K2, int gegl
 }
 int cl_gemm_tune_clear(void) { gemm_tune_clear(); return CL_OK; }
 int cl_gemm_tune_size(void) { return gemm_tune_size(); }
-int cl_attention_force_variant(int v) {
-  if (v == 16 || v == 17) { g_attn_fuse_delta = v == 17; return CL_OK; }   // 16 / 17: separate / fused delta (A/B hook)
-  if (v == 32 || v == 33) { g_gn_three_pass = v == 32; return CL_OK; }      // 32 / 33: three- / two-launch GroupNorm (A/B hook)
-  if (v == 34 || v == 35) { g_gn_one_pass = v == 35; return CL_OK; }        // 34 / 35: without / with the one-launch GroupNorm (A/B hook)
-  g_attn_variant = v; return CL_OK;
+// ---- probe hooks (csrc/debug_hooks.h; NOT part of include/ctrlora_hip.h: results are identical whatever they select)
+int cl_debug_attention_variant(int v) {
+  switch (v) {
+    case 0: case 1: case 2: case 3: case 5: case 6: case 7: case 8: case 9: case 10: case 11: case 12: case 13: case 14:
+    case 15: case 16: case 17: case 18: case 19: case 20:
+      g_attn_variant = v; return CL_OK;
+    default: return CL_EINVAL;
+  }
+}
+int cl_debug_attention_fuse_delta(int on) { g_attn_fuse_delta = on ? 1 : 0; return CL_OK; }
+int cl_debug_groupnorm_form(int three_pass, int one_pass) {
+  g_gn_three_pass = three_pass ? 1 : 0; g_gn_one_pass = one_pass ? 1 : 0; return CL_OK;
 }
 
 int cl_gemm(const cl_gemm_params* p, int dtype, void* stream) {

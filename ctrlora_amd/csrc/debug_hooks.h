@@ -1,0 +1,20 @@
+// Probe hooks of libctrlora_hip.so: A/B switches between schedules / launch forms that compute the SAME result.
+// They are exported for tests/tools/attn_bench.py, the A/B environment switches of ctrlora_amd/hip.py and the GPU
+// tests that cover every form that ships; they are deliberately NOT declared in include/ctrlora_hip.h (the drop-in
+// boundary): nothing a caller of the library needs, no effect on the input contract of any entry point.
+#pragma once
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* attention schedule: 0 = default; 1 = tile-synchronous kernels only; 11 = backward with s_setprio; 12 = round-2 ping-pong
+ * forward; 13 / 14 = hybrid forward (fragment lookahead 3 / 2; 14 = the default where it applies); 21-24 = round-4
+ * candidates (see attention_tr.hip).  Unknown codes: CL_EINVAL, nothing changes. */
+int cl_debug_attention_variant(int variant);
+/* 1 (default) = the dQ kernel forms delta itself; 0 = separate attn_delta launch */
+int cl_debug_attention_fuse_delta(int on);
+/* GroupNorm launch forms: three_pass = 1 forces partial -> finalize -> apply; one_pass = 0 disables the one-launch
+ * register-resident form (defaults 0, 1) */
+int cl_debug_groupnorm_form(int three_pass, int one_pass);
+#ifdef __cplusplus
+}
+#endif

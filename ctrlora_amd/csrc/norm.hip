@@ -301,7 +301,7 @@ int g_gn_three_pass = 0;   // A/B hook: 1 = always the partial -> finalize -> ap
 // pixels) stays on the two-launch form.  The backward handles trainable norms too (dgamma / dbeta: one float atomic per
 // channel and sample, as the three-launch form did).
 static constexpr int GN1_MIN_WG = 96;
-int g_gn_one_pass = 1;        // A/B hook (cl_attention_force_variant(34 / 35)): 0 = never take the one-launch form
+int g_gn_one_pass = 1;        // A/B hook (cl_debug_groupnorm_form): 0 = never take the one-launch form
 
 template <typename T> struct Pack8;
 template <> struct Pack8<bf16_t> {
@@ -337,6 +337,11 @@ static Gn1Geom gn1_geom(int B, int HW, int C, int G, int esize, bool bwd) {
   // ~80 registers of per-channel coefficients)
   const int maxw = bwd ? 8 : 16;
   int nw = (HW + ppw - 1) / ppw; if (nw > maxw) nw = maxw;
+  // the per-channel reduction (gn1_block_channel_sums) and the dgamma / dbeta atomics need one THREAD per channel of the
+  // block: at least ceil(CB / 64) waves even when HW is tiny (C = 2560 at 2x2: CB = 80, HW = 4).  Padding waves own pixels
+  // p >= HW and contribute zeros.
+  const int minw = (cb + 63) / 64;
+  if (nw < minw) nw = minw;
   g.NW = nw;
   const int per_iter = nw * ppw;
   const int nv = (HW + per_iter - 1) / per_iter;

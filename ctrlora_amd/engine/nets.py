@@ -30,6 +30,11 @@ from .blocks import (AttnE, Ctx, ResBlockE, SpatialTransformerE, base_bwd_weight
 from .packing import Conv3W, LinearW, LoraGroup, NormW, TrainableSet, rup
 
 
+# Bumped whenever packed weights change (re-pack, frozen reload, bank switch, a replayed optimizer graph): captured graphs /
+# caches that baked the old copies in (DDIMSampler.reuse_graph) compare it.
+WEIGHTS_GENERATION = [0]
+
+
 @dataclass(frozen=True)
 class NetCfg:
     """The architecture knobs of configs/*.yaml (control_stage_config / unet_config params)."""
@@ -84,6 +89,7 @@ class _Builder:
         self.sd = sd
         for fn in self.frozen:
             fn()
+        WEIGHTS_GENERATION[0] += 1
 
     def _g(self, name):
         return self.sd[self.prefix + name]
@@ -171,7 +177,10 @@ class _Builder:
             fq = self.fused([f"{tb}.attn1.to_q", f"{tb}.attn1.to_k", f"{tb}.attn1.to_v"])
             fkv = self.fused([f"{tb}.attn2.to_k", f"{tb}.attn2.to_v"])
         g1 = g2 = None
-        if lora and GROUP_LORA and self.dtype != torch.float32 and all(L.r for L in a1[:3] + a2[1:3]):
+        # (the grouped product's tile width -- 64, 128 or 160 -- has to divide the group width = the inner dimension;
+        # any other width keeps one launch per linear, as emb_groups does)
+        if (lora and GROUP_LORA and self.dtype != torch.float32 and all(L.r for L in a1[:3] + a2[1:3])
+                and a1[0].N % 64 == 0):
             # q | k | v (and the context's k | v) share their input: grouped launches (packing.LoraGroup)
             g1, g2 = LoraGroup(a1[:3]), LoraGroup(a2[1:3])
             if self.fold_lora:
@@ -442,6 +451,7 @@ class ControlNetE:
             if L.tA is not None:
                 L.tA, L.tB = lora_set.by_name[L.tA.name], lora_set.by_name[L.tB.name]
         self.tr_lora = lora_set
+        WEIGHTS_GENERATION[0] += 1
         if repack:
             self.repack(only=lora_set)
 
@@ -480,6 +490,7 @@ class ControlNetE:
     def repack(self, only: Optional[TrainableSet] = None):
         """Refresh the packed (storage dtype, both orientations) copies of every trainable matrix from the flat fp32
         masters: ONE kernel per flat buffer over a device-resident descriptor table (built on first use)."""
+        WEIGHTS_GENERATION[0] += 1
         for L in self._b.linears:
             if L.tW is not None and L.tb is not None:
                 L.bias = L.tb.master

@@ -65,7 +65,6 @@ _SIGS = {
     "cl_gemm_tune_set": [_I] * 9,
     "cl_gemm_tune_clear": [],
     "cl_gemm_tune_size": [],
-    "cl_attention_force_variant": [_I],
     "cl_gemm": [C.POINTER(GemmParams), _I, _P],
     "cl_lora_down": [_I, _P, _L, _P, _I, _P, _L, _I, _I, _P],
     "cl_lora_linear_fwd": [_I, _P, _L, _P, _P, _P, _L, _P, _I, _P, _L, _I, _P, _L, _I, _I, _I, _P],
@@ -114,6 +113,12 @@ _SIGS = {
     "cl_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
 }
 EXPORTED = tuple(_SIGS.keys())
+# probe hooks (ctrlora_amd/csrc/debug_hooks.h): exported by the library, not part of include/ctrlora_hip.h
+_DEBUG_SIGS = {
+    "cl_debug_attention_variant": [_I],
+    "cl_debug_attention_fuse_delta": [_I],
+    "cl_debug_groupnorm_form": [_I, _I],
+}
 
 
 def lib():
@@ -124,17 +129,17 @@ def lib():
             raise HipError(f"{LIB_PATH} not found -- run `python -m ctrlora_amd.build` "
                            "(the CtrLoRA engine has no non-HIP fallback)")
         L = C.CDLL(LIB_PATH)
-        for name, args in _SIGS.items():
+        for name, args in {**_SIGS, **_DEBUG_SIGS}.items():
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = C.c_long if name == "cl_groupnorm_ws_floats" else C.c_int
         _lib = L
         if os.environ.get("CTRLORA_ATTN_FUSE_DELTA", "1") == "0":      # A/B switch: separate attn_delta launch
-            L.cl_attention_force_variant(16)
-        if os.environ.get("CTRLORA_GN_THREE_PASS", "0") == "1":       # A/B switch: GroupNorm with the finalize launch
-            L.cl_attention_force_variant(32)
-        if os.environ.get("CTRLORA_GN_ONE_PASS", "1") == "0":        # A/B switch: no one-launch (register-resident) GroupNorm
-            L.cl_attention_force_variant(34)
+            L.cl_debug_attention_fuse_delta(0)
+        gn3 = os.environ.get("CTRLORA_GN_THREE_PASS", "0") == "1"      # A/B switch: GroupNorm with the finalize launch
+        gn1 = os.environ.get("CTRLORA_GN_ONE_PASS", "1") != "0"        # A/B switch: one-launch (register-resident) GroupNorm
+        if gn3 or not gn1:
+            L.cl_debug_groupnorm_form(int(gn3), int(gn1))
         if os.environ.get("CTRLORA_GEMM_TUNED", "1") != "0":
             load_gemm_table(os.environ.get("CTRLORA_GEMM_TABLE", GEMM_TABLE_PATH))
     return _lib

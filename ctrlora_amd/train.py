@@ -439,6 +439,8 @@ def replay_with_exchange(segments, g_opt, execs, reduce_fn):
     (`reduce_fn(slice)` -> handle with .wait() or None) -- it runs while the NEXT segment executes; all handles are waited for
     before the optimizer piece.  segments: [(graph, tag, lo, hi)], tag None = nothing to exchange, "all" = every executor's
     whole buffer, "tails" = lo is [(executor index, start, stop)], an int = that executor's [lo, hi) slice."""
+    from .engine.nets import WEIGHTS_GENERATION
+    WEIGHTS_GENERATION[0] += 1         # the optimizer piece re-packs the trainables: caches of the old copies are stale
     works = []
     for g, tag, lo, hi in segments:
         g.replay()
@@ -518,6 +520,8 @@ class GraphedPretrainStep:
             self.graphs[task] = (g, loss3)
             return done[2]
         opt.sync_hyper()
+        from .engine.nets import WEIGHTS_GENERATION
+        WEIGHTS_GENERATION[0] += 1
         ent[0].replay()
         cm._task = task
         for lin, lora in zip(cm._lora_linears, cm.loras_dict[task]):

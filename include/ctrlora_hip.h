@@ -60,12 +60,8 @@ int cl_gemm_force_splitk(int splitk);
 int cl_gemm_tune_set(int dtype, int mode, int M, int N, int K1, int K2, int geglu, int cfg, int splitk);
 int cl_gemm_tune_clear(void);
 int cl_gemm_tune_size(void);
-/* A/B probe hook for the attention schedules: 0 = default (hybrid ping-pong forward where it applies, tile-synchronous
- * backward), 1 = tile-synchronous kernels only, 3 = ping-pong forward and backward, 12 = the round-2 ping-pong forward,
- * 13 / 14 = hybrid forward (lookahead 3 / 2), 15-18 = per-wave software-pipelined forwards (candidates), 19 / 20 = the same
- * with the scale and -max folded into the matrix product: these two expect Q PRE-MULTIPLIED by scale * log2(e) and ignore
- * `scale` (probe use only).  32-35 select GroupNorm forms.  Not a product knob: results are identical across 0-18. */
-int cl_attention_force_variant(int variant);
+/* (Schedule / launch-form A-B switches that do not change results live in ctrlora_amd/csrc/debug_hooks.h, outside this
+ * boundary.) */
 
 /* ---- dense contractions -------------------------------------------------------------
  * One MFMA kernel family (csrc/gemm.hip) behind all of them:

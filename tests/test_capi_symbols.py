@@ -10,8 +10,9 @@ import pytest
 from tests.util import ROOT
 
 
-def _header_decls():
-    src = open(os.path.join(ROOT, "include", "ctrlora_hip.h")).read()
+def _header_decls(path=("include", "ctrlora_hip.h")):
+    src = open(os.path.join(ROOT, *path)).read()
+    src = re.sub(r"//[^\n]*", "", src)
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     decls = {}
     for m in re.finditer(r"\b(int|long)\s+(cl_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
@@ -60,6 +61,19 @@ def test_ctypes_signatures_match_header(built_lib):
             want = _cls(a)
             got = cmap.get(s, "ptr")
             assert want == got, (name, a, s)
+
+
+def test_probe_hooks_live_outside_the_boundary_header(built_lib):
+    """The A/B switches (csrc/debug_hooks.h) are exported and bound, are NOT declared in include/ctrlora_hip.h, and an
+    unknown attention schedule code is refused instead of silently selecting something."""
+    from ctrlora_amd import hip
+    dbg = _header_decls(("ctrlora_amd", "csrc", "debug_hooks.h"))
+    assert set(dbg) == set(hip._DEBUG_SIGS) and not (set(dbg) & set(_header_decls()))
+    L = ctypes.CDLL(built_lib)
+    for name, (ret, args) in dbg.items():
+        assert hasattr(L, name) and len(args) == len(hip._DEBUG_SIGS[name])
+    assert L.cl_debug_attention_variant(9999) != 0 and L.cl_debug_attention_variant(0) == 0
+    assert not hasattr(L, "cl_attention_force_variant")
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

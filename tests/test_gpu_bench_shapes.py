@@ -327,7 +327,7 @@ def test_attention_schedules_agree_pingpong_vs_tile_synchronous():
         q, k, v, do = mk(), mk(), mk(), mk()
         res = []
         for variant in (1, 3):       # 1: tile-synchronous everywhere, 3: ping-pong forward AND backward
-            hip.lib().cl_attention_force_variant(variant)
+            hip.lib().cl_debug_attention_variant(variant)
             o = torch.empty_like(q)
             lse = torch.empty(B, Hh, N, dtype=torch.float32, device="cuda")
             delta = torch.empty_like(lse)
@@ -336,7 +336,7 @@ def test_attention_schedules_agree_pingpong_vs_tile_synchronous():
             hip.attention_bwd_v2(q, k, v, o, do, lse, delta, dq, dk, dv, B, Hh, N, N, dh, dh ** -0.5)
             torch.cuda.synchronize()
             res.append((o, lse, dq, dk, dv))
-        hip.lib().cl_attention_force_variant(0)
+        hip.lib().cl_debug_attention_variant(0)
         errs = [rel_l2(a, b) for a, b in zip(res[1], res[0])]
         _record("attention_pp_vs_sync", dh=dh, N=N, o=errs[0], lse=errs[1], dq=errs[2], dk=errs[3], dv=errs[4])
         assert errs[1] < 1e-4 and max(errs[0], errs[2], errs[3], errs[4]) < 6e-3, errs

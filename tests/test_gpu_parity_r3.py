@@ -348,12 +348,14 @@ def test_grouped_lora_products_vs_fp64(M, K, N, r, G):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("C,HW,silu,train", [(640, 1024, True, False), (1280, 1024, False, True), (1920, 256, True, False),
                                              (960, 1024, True, False), (1280, 256, False, True), (2560, 64, True, False),
-                                             (2560, 256, True, False), (640, 256, True, True), (1280, 60, True, True)])
+                                             (2560, 256, True, False), (640, 256, True, True), (1280, 60, True, True),
+                                             (2560, 4, True, True), (3840, 4, True, True), (2560, 1, True, False)])
 def test_groupnorm_one_launch_production_shapes(dtype, C, HW, silu, train):
     """GroupNorm32 (+SiLU) forward / backward at the 32x32, 16x16 and 8x8 levels of SD1.5 (B = 8), where the one-launch
     kernels (csrc/norm.hip gn1_*: the (sample, channel-block) slab stays in registers between statistics and apply) take
-    over from the two-launch form: vs torch in fp64, and the two forms against each other (A/B hook 34 / 35); a ragged
-    pixel count too.  ldm/modules/diffusionmodules/util.py:217-219, openaimodel.py:201-202, attention.py:88-89."""
+    over from the two-launch form: vs torch in fp64, and the two forms against each other (cl_debug_groupnorm_form); a ragged
+    pixel count too, and 128-px images (2x2 / 1x1 levels: fewer pixels than channels in the block -- ADVICE r3: the
+    workgroup needs one thread per channel).  ldm/modules/diffusionmodules/util.py:217-219, openaimodel.py:201-202, attention.py:88-89."""
     _need_gpu()
     from ctrlora_amd import hip
     B, eps = 8, (1e-5 if silu else 1e-6)
@@ -374,7 +376,7 @@ def test_groupnorm_one_launch_production_shapes(dtype, C, HW, silu, train):
     xd, dyd, accd, gd, bd = x.to(dev), dy.to(dev), acc.to(dev), gamma.to(dev), beta.to(dev)
     out = {}
     for form in (35, 34):                    # one-launch on / off
-        hip.lib().cl_attention_force_variant(form)
+        hip.lib().cl_debug_groupnorm_form(0, int(form == 35))
         try:
             y = torch.empty_like(xd); dx = torch.empty_like(xd)
             stats = torch.empty(B, 32, 2, device=dev); ws = torch.zeros(hip.groupnorm_ws(B, HW, C), device=dev)
@@ -384,7 +386,7 @@ def test_groupnorm_one_launch_production_shapes(dtype, C, HW, silu, train):
             torch.cuda.synchronize()
             out[form] = (y, dx, stats, dgam, dbet)
         finally:
-            hip.lib().cl_attention_force_variant(35)
+            hip.lib().cl_debug_groupnorm_form(0, 1)
     y, dx, stats, dgam, dbet = out[35]
     tol = 1e-5 if dtype == torch.float32 else 6e-3
     e_y, e_dx = rel_l2(y, y_ref), rel_l2(dx, dx_ref)

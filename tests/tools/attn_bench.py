@@ -76,7 +76,7 @@ def case(dh, N, Nkv, B, variants, bwd, check=True, rounds=1):
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         runs = {}
         for name, var in variants:
-            hip.lib().cl_attention_force_variant(var)
+            hip.lib().cl_debug_attention_variant(var)
             fold = var in FOLD_VARIANTS
             hip.attention_fwd_v2(q_fold if fold else q, k, v, o, lse, B, H, N, Nkv, dh, scale)
             r = {}
@@ -90,11 +90,11 @@ def case(dh, N, Nkv, B, variants, bwd, check=True, rounds=1):
                     torch.cuda.synchronize()
                     r.update(dq_err=rel(dq, ref["dq"]), dk_err=rel(dk, ref["dk"]), dv_err=rel(dv, ref["dv"]))
             runs[name] = dict(r, f=[], b=[])
-        hip.lib().cl_attention_force_variant(variants[0][1])
+        hip.lib().cl_debug_attention_variant(variants[0][1])
         timeit(lambda: hip.attention_fwd_v2(q, k, v, o, lse, B, H, N, Nkv, dh, scale), iters=60, warm=10)   # clocks up
         for _ in range(rounds):
             for name, var in variants:
-                hip.lib().cl_attention_force_variant(var)
+                hip.lib().cl_debug_attention_variant(var)
                 qq = q_fold if var in FOLD_VARIANTS else q
                 runs[name]["f"].append(timeit(lambda: hip.attention_fwd_v2(qq, k, v, o, lse, B, H, N, Nkv, dh, scale), iters=10, warm=2))
                 if bwd:
@@ -107,10 +107,10 @@ def case(dh, N, Nkv, B, variants, bwd, check=True, rounds=1):
                 r["bwd_us_median"] = round(bb[len(bb) // 2] * 1e3, 1); r["bwd_us_min"] = round(bb[0] * 1e3, 1)
                 r["bwd_tflops"] = round(2.5 * flops_f / bb[len(bb) // 2] * 1e-9, 1)
             out[name] = r
-        hip.lib().cl_attention_force_variant(0)
+        hip.lib().cl_debug_attention_variant(0)
         return out
     for name, var in variants:
-        hip.lib().cl_attention_force_variant(var)
+        hip.lib().cl_debug_attention_variant(var)
         o = torch.empty_like(q)
         lse = torch.empty(B, H, rp, dtype=torch.float32, device="cuda")
         fwd = lambda: hip.attention_fwd_v2(q, k, v, o, lse, B, H, N, Nkv, dh, scale)
@@ -135,7 +135,7 @@ def case(dh, N, Nkv, B, variants, bwd, check=True, rounds=1):
             r["bwd_us"] = round(ms * 1e3, 1)
             r["bwd_tflops"] = round(2.5 * flops_f / ms * 1e-9, 1)
         out[name] = r
-    hip.lib().cl_attention_force_variant(0)
+    hip.lib().cl_debug_attention_variant(0)
     return out
 
 
@@ -146,7 +146,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--bwd", action="store_true")
     ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--variants", default="1,0", help="comma list of cl_attention_force_variant values")
+    ap.add_argument("--variants", default="1,0", help="comma list of cl_debug_attention_variant values")
     ap.add_argument("--shapes", default="40,4096,4096,8;80,1024,1024,8;40,4096,4096,32;80,1024,1024,32;40,1024,1024,2;40,256,128,8")
     ap.add_argument("--rounds", type=int, default=1, help="> 1: interleaved A/B, median / min over the rounds")
     ap.add_argument("--out", default=None)
