@@ -20,6 +20,9 @@ struct AttnFwdArgs {
   float* LSE; int lse_stride;
   int B, H, N, Nkv, DH;
   float scale;   // d_head^-0.5 (ldm/modules/attention.py:151)
+  // 1: Q holds q * scale * log2(e) (the producing projection applied the factor in ITS fp32 epilogue: one rounding, like any
+  // stored q) -- the kernels then take scores straight from the matrix product (log2 domain).  bf16 kernels only.
+  int q_prescaled;
 };
 
 struct AttnBwdArgs {
@@ -31,6 +34,7 @@ struct AttnBwdArgs {
   void* dQ; long lddq; void* dK; long lddk; void* dV; long lddv;  // dK/dV may be null (frozen context)
   int B, H, N, Nkv, DH;
   float scale;
+  int q_prescaled;   // as in AttnFwdArgs; dQ / dK / dV are the gradients of the TRUE q, k, v either way
 };
 
 int attn_fwd(const AttnFwdArgs& a, int dtype, hipStream_t st);
@@ -40,6 +44,10 @@ int attn_fwd_tr(const AttnFwdArgs& a, const void* V, long ldv, hipStream_t st);
 int attn_bwd_tr(const AttnBwdArgs& a, hipStream_t st);
 extern int g_attn_fuse_delta;   // 1 = the dQ kernel forms delta (default), 0 = separate attn_delta launch
 extern int g_attn_variant;   // probe hook: 0 = heuristic, 1 = tile-synchronous kernels only (no ping-pong schedule)
+// pre-scaled-Q forward for d_head 40 (attention_fwd40.hip)
+bool attn_fwd40_applies(const AttnFwdArgs& a);
+int attn_fwd40(const AttnFwdArgs& a, const void* V, long ldv, hipStream_t st);
+extern int g_attn_fwd40_waves;
 int attn_delta(const AttnBwdArgs& a, hipStream_t st);   // delta[q] = sum_d dO[q,d] O[q,d]  (bf16)
 
 }  // namespace cl

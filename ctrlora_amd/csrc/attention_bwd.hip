@@ -336,6 +336,7 @@ int attn_delta(const AttnBwdArgs& a, hipStream_t st) {
 }
 
 int attn_bwd(const AttnBwdArgs& a, int dtype, hipStream_t st) {
+  if (a.q_prescaled) return CL_EINVAL;   // the pre-scaled-Q contract is the transpose-free bf16 kernels' (attention_tr.hip)
   const int eb = dtype == CL_BF16 ? 2 : 4;
   if ((a.ldq * eb) % 16 || (a.ldk * eb) % 16 || (a.ldv * eb) % 16 || (a.lddo * eb) % 16 || (a.ldo * eb) % 16)
     return CL_EINVAL;

@@ -240,6 +240,7 @@ static int dispatch_dh(const AttnFwdArgs& a, hipStream_t st) {
 }
 
 int attn_fwd(const AttnFwdArgs& a, int dtype, hipStream_t st) {
+  if (a.q_prescaled) return CL_EINVAL;   // the pre-scaled-Q contract is the transpose-free bf16 kernels' (attention_tr.hip)
   const int eb = dtype == CL_BF16 ? 2 : 4;
   if ((a.ldq * eb) % 16 || (a.ldk * eb) % 16 || a.nkv_pad % 64 || a.nkv_pad < a.Nkv || a.Nkv < 1 || a.N < 1)
     return CL_EINVAL;

@@ -22,7 +22,7 @@ static GemmParams base_params() {
 
 extern "C" {
 
-int cl_abi_version(void) { return 5; }
+int cl_abi_version(void) { return 6; }
 int cl_last_hip_error(void) { return g_last_hip_error; }
 const char* cl_last_hip_error_string(void) { return hipGetErrorString((hipError_t)g_last_hip_error); }
 
@@ -45,9 +45,10 @@ int cl_gemm_tune_size(void) { return gemm_tune_size(); }
 // ---- probe hooks (csrc/debug_hooks.h; NOT part of include/ctrlora_hip.h: results are identical whatever they select)
 int cl_debug_attention_variant(int v) {
   switch (v) {
-    case 0: case 1: case 2: case 3: case 5: case 6: case 7: case 8: case 9: case 10: case 11: case 12: case 13: case 14:
-    case 15: case 16: case 17: case 18: case 19: case 20:
-      g_attn_variant = v; return CL_OK;
+    case 0: case 1: case 11: case 13: case 14:
+      g_attn_variant = v; g_attn_fwd40_waves = 8; return CL_OK;
+    case 21:            // pre-scaled-Q forward with 4-wave workgroups (three per CU) instead of 8-wave ones
+      g_attn_variant = 0; g_attn_fwd40_waves = 4; return CL_OK;
     default: return CL_EINVAL;
   }
 }
@@ -67,7 +68,7 @@ int cl_gemm(const cl_gemm_params* p, int dtype, void* stream) {
   g.rowbias = p->rowbias; g.ldrb = p->ldrb; g.rows_per_batch = p->rows_per_batch;
   g.residual = p->residual; g.ldr = p->ldr; g.alpha = p->alpha; g.beta = p->beta; g.act = p->act;
   g.C = p->C; g.ldc = p->ldc; g.out_f32 = p->out_f32; g.atomic = p->atomic; g.splitk = p->splitk < 1 ? 1 : p->splitk;
-  g.a1_group_n = p->a1_group_n; g.a2_group_n = p->a2_group_n;
+  g.a1_group_n = p->a1_group_n; g.a2_group_n = p->a2_group_n; g.alpha_n = p->alpha_n;
   return launch_gemm(g, dtype, S(stream));
 }
 
@@ -230,21 +231,23 @@ int cl_attention_bwd(int dtype, const void* Q, long ldq, const void* K, long ldk
 
 int cl_attention_fwd_v2(int dtype, const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, void* O,
                         long ldo, float* LSE, int lse_stride, int B, int H, int N, int Nkv, int dh, float scale,
-                        void* stream) {
-  if (dtype != CL_BF16) return CL_EINVAL;
+                        int flags, void* stream) {
+  if (dtype != CL_BF16 || (flags & ~CL_ATTN_Q_PRESCALED)) return CL_EINVAL;
   AttnFwdArgs a{}; a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.O = O; a.ldo = ldo;
   a.LSE = LSE; a.lse_stride = lse_stride; a.B = B; a.H = H; a.N = N; a.Nkv = Nkv; a.DH = dh; a.scale = scale;
+  a.q_prescaled = (flags & CL_ATTN_Q_PRESCALED) ? 1 : 0;
   return attn_fwd_tr(a, V, ldv, S(stream));
 }
 
 int cl_attention_bwd_v2(int dtype, const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv,
                         const void* O, long ldo, const void* dO, long lddo, const float* LSE, float* Delta,
                         int lse_stride, void* dQ, long lddq, void* dK, long lddk, void* dV, long lddv, int B, int H,
-                        int N, int Nkv, int dh, float scale, void* stream) {
-  if (dtype != CL_BF16) return CL_EINVAL;
+                        int N, int Nkv, int dh, float scale, int flags, void* stream) {
+  if (dtype != CL_BF16 || (flags & ~CL_ATTN_Q_PRESCALED)) return CL_EINVAL;
   AttnBwdArgs a{}; a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo;
   a.dO = dO; a.lddo = lddo; a.LSE = LSE; a.Delta = Delta; a.lse_stride = lse_stride; a.dQ = dQ; a.lddq = lddq;
   a.dK = dK; a.lddk = lddk; a.dV = dV; a.lddv = lddv; a.B = B; a.H = H; a.N = N; a.Nkv = Nkv; a.DH = dh; a.scale = scale;
+  a.q_prescaled = (flags & CL_ATTN_Q_PRESCALED) ? 1 : 0;
   return attn_bwd_tr(a, S(stream));
 }
 

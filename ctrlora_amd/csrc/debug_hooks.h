@@ -6,9 +6,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-/* attention schedule: 0 = default; 1 = tile-synchronous kernels only; 11 = backward with s_setprio; 12 = round-2 ping-pong
- * forward; 13 / 14 = hybrid forward (fragment lookahead 3 / 2; 14 = the default where it applies); 21-24 = round-4
- * candidates (see attention_tr.hip).  Unknown codes: CL_EINVAL, nothing changes. */
+/* attention schedule: 0 = default; 1 = tile-synchronous kernels only; 11 = backward with s_setprio;
+ * 13 / 14 = hybrid forward (fragment lookahead 3 / 2) also where the pre-scaled-Q forward (attention_fwd40.hip) would
+ * apply; 21 = that forward with 4-wave workgroups.  Unknown codes: CL_EINVAL, nothing changes. */
 int cl_debug_attention_variant(int variant);
 /* 1 (default) = the dQ kernel forms delta itself; 0 = separate attn_delta launch */
 int cl_debug_attention_fuse_delta(int on);

@@ -47,6 +47,9 @@ struct GemmParams {
   // columns [g * K1, (g+1) * K1) of A1 (u_g = dy_g B_g for all g in one launch).  0 = ungrouped.  A tile never straddles
   // groups: the launcher only takes configurations whose BN divides the group width.
   int a1_group_n, a2_group_n;
+  // alpha applies to output columns [0, alpha_n) only (0 = all columns): the producer of a fused q | k | v writes
+  // q * (d_head^-0.5 * log2 e) -- the attention kernels' pre-scaled-Q contract -- and leaves k, v alone.  Multiple of 8.
+  int alpha_n;
 };
 
 int launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);

@@ -71,7 +71,7 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 struct EpiArgs {
   const float* bias; const void* rowbias; long ldrb; int rows_per_batch;
   const void* residual; long ldr; float alpha, beta; int act;
-  void* C; long ldc; int out_f32; int atomic; int M, N;
+  void* C; long ldc; int out_f32; int atomic; int M, N; int alpha_n;
 };
 
 // apply the epilogue to 8 consecutive columns of one row and store
@@ -93,8 +93,9 @@ __device__ __forceinline__ void epilogue8(const EpiArgs& e, float v[8], int grow
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = silu_f(v[i]);
   }
+  const float al = (e.alpha_n > 0 && gcol >= e.alpha_n) ? 1.0f : e.alpha;     // (8 columns never straddle alpha_n)
 #pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] *= e.alpha;
+  for (int i = 0; i < 8; ++i) v[i] *= al;
   if (e.residual) {
     float rs[8];
     load8(reinterpret_cast<const T*>(e.residual) + (long)grow * e.ldr + gcol, rs);
@@ -116,7 +117,7 @@ __device__ __forceinline__ EpiArgs epi_of(const GemmParams& p) {
   EpiArgs e;
   e.bias = p.bias; e.rowbias = p.rowbias; e.ldrb = p.ldrb; e.rows_per_batch = p.rows_per_batch;
   e.residual = p.residual; e.ldr = p.ldr; e.alpha = p.alpha; e.beta = p.beta; e.act = p.act;
-  e.C = p.C; e.ldc = p.ldc; e.out_f32 = p.out_f32; e.atomic = p.atomic; e.M = p.M; e.N = p.N;
+  e.C = p.C; e.ldc = p.ldc; e.out_f32 = p.out_f32; e.atomic = p.atomic; e.M = p.M; e.N = p.N; e.alpha_n = p.alpha_n;
   return e;
 }
 
@@ -1303,6 +1304,7 @@ int launch_gemm(const GemmParams& p, int dtype, hipStream_t stream) {
   if (p.rowbias && p.rows_per_batch <= 0) return CL_EINVAL;
   if (p.act == ACT_GEGLU && (p.N % 160 || p.rowbias || p.residual || p.atomic || p.alpha != 1.0f)) return CL_EINVAL;
   if (p.a1_group_n < 0 || p.a2_group_n < 0) return CL_EINVAL;
+  if (p.alpha_n < 0 || p.alpha_n % 8 || p.alpha_n > p.N || (p.alpha_n && p.act == ACT_GEGLU)) return CL_EINVAL;
   if ((p.a1_group_n || p.a2_group_n) && p.mode != GEMM_LINEAR) return CL_EINVAL;
   if (p.a1_group_n && p.N % p.a1_group_n) return CL_EINVAL;
   if (p.a2_group_n && (p.N % p.a2_group_n || !p.K2)) return CL_EINVAL;

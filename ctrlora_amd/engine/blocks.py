@@ -22,8 +22,13 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 
+import os
+
 from .. import hip
 from .packing import Conv3W, LinearW, NormW, rup
+
+# A/B switch: 0 = the attention kernels get a plain q and scale the scores themselves (round-3 behaviour)
+PRESCALE_Q = os.environ.get("CTRLORA_PRESCALE_Q", "1") != "0"
 
 
 class Ctx:
@@ -126,8 +131,9 @@ class Ctx:
 # --------------------------------------------------------------------------- linear
 
 def linear_fwd(ctx: Ctx, L: LinearW, x, out=None, residual=None, act=hip.ACT_NONE, alpha=1.0, beta=1.0,
-               out_f32=False):
-    """y = (x W^T + b [+ (x A^T) B^T]) * alpha + beta * residual.  Returns (y, t = x A^T or None)."""
+               out_f32=False, alpha_n=0):
+    """y = (x W^T + b [+ (x A^T) B^T]) * alpha + beta * residual.  Returns (y, t = x A^T or None).
+    alpha_n > 0: alpha multiplies output columns [0, alpha_n) only (the q part of a fused q | k | v)."""
     M = x.shape[0]
     t = None
     merged = L.Wm is not None and not ctx.record      # inference executor: W + B A already folded
@@ -137,20 +143,21 @@ def linear_fwd(ctx: Ctx, L: LinearW, x, out=None, residual=None, act=hip.ACT_NON
     if out is None:
         out = ctx.new(M, L.N, torch.float32 if out_f32 else None)
     hip.gemm(x, L.Wm if merged else L.W, out, a2=t, w2=L.B if t is not None else None, bias=L.bias, residual=residual,
-             alpha=alpha, beta=beta if residual is not None else 0.0, act=act, out_f32=out_f32)
+             alpha=alpha, beta=beta if residual is not None else 0.0, act=act, out_f32=out_f32, alpha_n=alpha_n)
     return out, t
 
 
-def group_fwd(ctx: Ctx, grp, x):
-    """Every member of a packing.LoraGroup applied to x in two launches: (y [M, G N] (+ bias), t [M, G r] or None)."""
+def group_fwd(ctx: Ctx, grp, x, alpha=1.0, alpha_n=0):
+    """Every member of a packing.LoraGroup applied to x in two launches: (y [M, G N] (+ bias), t [M, G r] or None).
+    alpha / alpha_n: as linear_fwd (the first member's output scaled in the product's epilogue)."""
     M = x.shape[0]
     y = ctx.new(M, grp.G * grp.N)
     if grp.Wm is not None and not ctx.record:              # inference executor: W + B A folded, one plain product
-        hip.gemm(x, grp.Wm, y, bias=grp.bias)
+        hip.gemm(x, grp.Wm, y, bias=grp.bias, alpha=alpha, alpha_n=alpha_n)
         return y, None
     t = ctx.new(M, grp.G * grp.r)
     hip.gemm(x, grp.A, t)
-    hip.gemm(x, grp.W, y, a2=t, w2=grp.B, bias=grp.bias, a2_group_n=grp.N)
+    hip.gemm(x, grp.W, y, a2=t, w2=grp.B, bias=grp.bias, a2_group_n=grp.N, alpha=alpha, alpha_n=alpha_n)
     return y, t
 
 
@@ -379,9 +386,17 @@ class AttnE:
         self.inner = to_q.N
         self.dh = self.inner // heads
         self.scale = float(self.dh) ** -0.5
+        # Pre-scaled-Q contract of the bf16 attention kernels (CL_ATTN_Q_PRESCALED): the to_q projection's epilogue writes
+        # q * d_head^-0.5 * log2(e) -- one rounding from its fp32 accumulators, like any stored q -- so the kernels take
+        # log2-domain scores straight off the matrix product; dQ / dK / dV stay the gradients of the TRUE q, k, v, so the
+        # projections' backward is unchanged.  q is internal to the block (attention.py:163-171: only the attention reads it).
+        self.q_alpha = self.scale * 1.4426950408889634
 
-    def _group_fwd(self, ctx: Ctx, x):
-        return group_fwd(ctx, self.group, x)
+    def _prescaled(self, ctx: Ctx) -> bool:
+        return PRESCALE_Q and ctx.dtype == torch.bfloat16
+
+    def _group_fwd(self, ctx: Ctx, x, alpha=1.0, alpha_n=0):
+        return group_fwd(ctx, self.group, x, alpha=alpha, alpha_n=alpha_n)
 
     def _group_bwd(self, ctx: Ctx, dy, need_dx: bool, accum=None):
         """dy [M, G N] -> (dx [M, K] (+ accum) or None, u [M, G r])."""
@@ -415,22 +430,24 @@ class AttnE:
     def fwd(self, ctx: Ctx, xn, c, B, N, Nkv, residual, kv_cache=None):
         inner, H = self.inner, self.heads
         tq = tk = tv = None
+        pre = self._prescaled(ctx)
+        qa = self.q_alpha if pre else 1.0
         if self.is_self:
             if self.fused_qkv is not None:
-                qkv, _ = linear_fwd(ctx, self.fused_qkv, xn)
+                qkv, _ = linear_fwd(ctx, self.fused_qkv, xn, alpha=qa, alpha_n=inner if pre else 0)
                 q, k, v = qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:]
             elif self.group is not None:
-                qkv, t = self._group_fwd(ctx, xn)
+                qkv, t = self._group_fwd(ctx, xn, alpha=qa, alpha_n=inner if pre else 0)
                 q, k, v = qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:]
                 if t is not None:
                     r = self.group.r
                     tq, tk, tv = t[:, :r], t[:, r:2 * r], t[:, 2 * r:]
             else:
-                q, tq = linear_fwd(ctx, self.q, xn)
+                q, tq = linear_fwd(ctx, self.q, xn, alpha=qa)
                 k, tk = linear_fwd(ctx, self.k, xn)
                 v, tv = linear_fwd(ctx, self.v, xn)
         else:
-            q, tq = linear_fwd(ctx, self.q, xn)
+            q, tq = linear_fwd(ctx, self.q, xn, alpha=qa)
             if kv_cache is not None:
                 k, v, tk, tv = kv_cache
             else:
@@ -438,7 +455,7 @@ class AttnE:
         a = ctx.new(B * N, inner)
         lse = torch.empty((B, H, rup(N, 64)), dtype=torch.float32, device=ctx.device) if ctx.record else None
         if ctx.dtype == torch.bfloat16:       # transpose-free kernels (LDS transpose reads)
-            hip.attention_fwd_v2(q, k, v, a, lse, B, H, N, Nkv, self.dh, self.scale)
+            hip.attention_fwd_v2(q, k, v, a, lse, B, H, N, Nkv, self.dh, self.scale, q_prescaled=pre)
         else:
             kpad = rup(Nkv, 64)
             vt = torch.empty((B, inner, kpad), dtype=ctx.dtype, device=ctx.device)
@@ -473,7 +490,8 @@ class AttnE:
                 dk = ctx.new(B * Nkv, inner) if want_kv else None
                 dv = ctx.new(B * Nkv, inner) if want_kv else None
         if ctx.dtype == torch.bfloat16:
-            hip.attention_bwd_v2(q, k, v, a, da, lse, delta, dq, dk, dv, B, H, N, Nkv, self.dh, self.scale)
+            hip.attention_bwd_v2(q, k, v, a, da, lse, delta, dq, dk, dv, B, H, N, Nkv, self.dh, self.scale,
+                                 q_prescaled=self._prescaled(ctx))
         else:
             npad, kpad = rup(N, 64), rup(Nkv, 64)
             qt = torch.empty((B, inner, npad), dtype=ctx.dtype, device=ctx.device)

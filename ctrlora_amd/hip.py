@@ -47,7 +47,7 @@ class GemmParams(C.Structure):
         ("alpha", C.c_float), ("beta", C.c_float), ("act", C.c_int),
         ("C", C.c_void_p), ("ldc", C.c_long),
         ("out_f32", C.c_int), ("atomic", C.c_int), ("splitk", C.c_int),
-        ("a1_group_n", C.c_int), ("a2_group_n", C.c_int),
+        ("a1_group_n", C.c_int), ("a2_group_n", C.c_int), ("alpha_n", C.c_int),
     ]
 
 
@@ -83,9 +83,9 @@ _SIGS = {
     "cl_attention_fwd": [_I, _P, _L, _P, _L, _P, _I, _P, _L, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "cl_attention_bwd": [_I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _I, _P, _I, _P, _P, _I, _P, _L, _P, _L,
                          _P, _L, _I, _I, _I, _I, _I, _F, _P],
-    "cl_attention_fwd_v2": [_I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+    "cl_attention_fwd_v2": [_I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "cl_attention_bwd_v2": [_I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _I, _P, _L, _P, _L, _P, _L,
-                            _I, _I, _I, _I, _I, _F, _P],
+                            _I, _I, _I, _I, _I, _F, _I, _P],
     "cl_geglu_fwd": [_I, _P, _L, _P, _L, _L, _I, _P],
     "cl_geglu_bwd": [_I, _P, _L, _P, _L, _P, _L, _L, _I, _P],
     "cl_silu_fwd": [_I, _P, _P, _L, _P],
@@ -255,7 +255,7 @@ def zero_page(device) -> torch.Tensor:
 
 def gemm(a1, w1, out, *, a2=None, w2=None, bias=None, rowbias=None, rows_per_batch=0, residual=None,
          alpha=1.0, beta=0.0, act=ACT_NONE, mode=LINEAR, conv=None, k1=None, out_f32=False, atomic=False,
-         splitk=1, M=None, N=None, dtype=None, a1_group_n=0, a2_group_n=0):
+         splitk=1, M=None, N=None, dtype=None, a1_group_n=0, a2_group_n=0, alpha_n=0):
     """out[M,N] = act(a1.w1^T + a2.w2^T + bias + rowbias[m // rows_per_batch]) * alpha + beta * residual.
 
     a1: [M,K1] (LINEAR) or the NHWC activation [B*Hin*Win, C] (conv modes, conv=(B,Hin,Win,Hout,Wout)).
@@ -283,7 +283,7 @@ def gemm(a1, w1, out, *, a2=None, w2=None, bias=None, rowbias=None, rows_per_bat
     p.alpha = alpha; p.beta = beta; p.act = act
     p.C = out.data_ptr(); p.ldc = ld(out)
     p.out_f32 = int(out_f32); p.atomic = int(atomic); p.splitk = splitk
-    p.a1_group_n = a1_group_n; p.a2_group_n = a2_group_n
+    p.a1_group_n = a1_group_n; p.a2_group_n = a2_group_n; p.alpha_n = alpha_n
     _chk(lib().cl_gemm(C.byref(p), dty, stream()), "cl_gemm")
     return out
 
@@ -381,19 +381,23 @@ def attention_bwd(q, k, v, o, do, qt, dot, kt, lse, delta, dq, dk, dv, B, H, N, 
                                 stream()), "cl_attention_bwd")
 
 
-def attention_fwd_v2(q, k, v, o, lse, B, H, N, Nkv, dh, scale):
-    """bf16, transpose-free: v is [B*Nkv, >=H*dh] like k."""
+ATTN_Q_PRESCALED = 1
+
+
+def attention_fwd_v2(q, k, v, o, lse, B, H, N, Nkv, dh, scale, q_prescaled=False):
+    """bf16, transpose-free: v is [B*Nkv, >=H*dh] like k.  q_prescaled: q holds q * scale * log2(e)
+    (CL_ATTN_Q_PRESCALED: the to_q projection applied the factor in its epilogue)."""
     _chk(lib().cl_attention_fwd_v2(dt(q), q.data_ptr(), ld(q), k.data_ptr(), ld(k), v.data_ptr(), ld(v), o.data_ptr(),
                                    ld(o), ptr(lse), 0 if lse is None else lse.shape[-1], B, H, N, Nkv, dh, scale,
-                                   stream()), "cl_attention_fwd_v2")
+                                   ATTN_Q_PRESCALED if q_prescaled else 0, stream()), "cl_attention_fwd_v2")
     return o
 
 
-def attention_bwd_v2(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, N, Nkv, dh, scale):
+def attention_bwd_v2(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, N, Nkv, dh, scale, q_prescaled=False):
     _chk(lib().cl_attention_bwd_v2(dt(q), q.data_ptr(), ld(q), k.data_ptr(), ld(k), v.data_ptr(), ld(v), o.data_ptr(),
                                    ld(o), do.data_ptr(), ld(do), lse.data_ptr(), delta.data_ptr(), lse.shape[-1],
                                    dq.data_ptr(), ld(dq), ptr(dk), ld(dk), ptr(dv), ld(dv), B, H, N, Nkv, dh, scale,
-                                   stream()), "cl_attention_bwd_v2")
+                                   ATTN_Q_PRESCALED if q_prescaled else 0, stream()), "cl_attention_bwd_v2")
 
 
 # ------------------------------------------------------------------ elementwise / layout

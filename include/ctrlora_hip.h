@@ -103,6 +103,10 @@ typedef struct cl_gemm_params {
    * of A2 (A2 = [x Aq^T | x Ak^T | x Av^T], W2 = [Bq; Bk; Bv]).  a1_group_n: the same for the FIRST segment
    * (u = [dq Bq | dk Bk | dv Bv] from dy = [dq | dk | dv]: A1 columns [g*K1, (g+1)*K1)).  0 = ungrouped. */
   int a1_group_n, a2_group_n;
+  /* ABI 6: alpha multiplies output columns [0, alpha_n) only (0 = every column; a multiple of 8).  The q | k | v
+   * projection of a CrossAttention writes q * (d_head^-0.5 * log2 e) and plain k, v in ONE launch: the pre-scaled-Q
+   * contract of cl_attention_*_v2 (CL_ATTN_Q_PRESCALED). */
+  int alpha_n;
 } cl_gemm_params;
 
 /* Generic entry; the named operators below are thin fillers of cl_gemm_params. */
@@ -203,14 +207,20 @@ int cl_attention_bwd(int dtype, const void* Q, long ldq, const void* K, long ldk
 
 /* bf16 variants without any materialised transposes (csrc/attention_tr.hip): every tile is staged
  * row-major as the projections wrote it and the P.V-type operands are built with the gfx950 LDS
- * transpose read.  V is [B*Nkv, ldv] like K.  fp32 parity mode keeps the entry points above. */
+ * transpose read.  V is [B*Nkv, ldv] like K.  fp32 parity mode keeps the entry points above.
+ * flags (ABI 6): CL_ATTN_Q_PRESCALED -- Q holds q * scale * log2(e): the to_q projection applied the factor in its own
+ * fp32 epilogue (cl_gemm_params.alpha / alpha_n), so the kernels read log2-domain scores straight off the matrix
+ * product (for d_head 40 the forward also carries -max through a spare contraction slot: no per-score multiply-add
+ * at all).  `scale` is still d_head^-0.5; O, LSE, dQ, dK, dV mean the same with or without the flag (gradients are
+ * those of the TRUE q, k, v).  An explicit argument of every call -- no process-global state selects it. */
+enum { CL_ATTN_Q_PRESCALED = 1 };
 int cl_attention_fwd_v2(int dtype, const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv,
                         void* O, long ldo, float* LSE, int lse_stride, int B, int H, int N, int Nkv, int dh,
-                        float scale, void* stream);
+                        float scale, int flags, void* stream);
 int cl_attention_bwd_v2(int dtype, const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv,
                         const void* O, long ldo, const void* dO, long lddo, const float* LSE, float* Delta,
                         int lse_stride, void* dQ, long lddq, void* dK, long lddk, void* dV, long lddv,
-                        int B, int H, int N, int Nkv, int dh, float scale, void* stream);
+                        int B, int H, int N, int Nkv, int dh, float scale, int flags, void* stream);
 
 /* ---- elementwise / layout ------------------------------------------------------------ */
 int cl_geglu_fwd(int dtype, const void* h, long ldh, void* out, long ldo, long M, int F, void* stream); /* attention.py:55-56 */

@@ -349,7 +349,7 @@ def test_grouped_lora_products_vs_fp64(M, K, N, r, G):
 @pytest.mark.parametrize("C,HW,silu,train", [(640, 1024, True, False), (1280, 1024, False, True), (1920, 256, True, False),
                                              (960, 1024, True, False), (1280, 256, False, True), (2560, 64, True, False),
                                              (2560, 256, True, False), (640, 256, True, True), (1280, 60, True, True),
-                                             (2560, 4, True, True), (3840, 4, True, True), (2560, 1, True, False)])
+                                             (2560, 4, True, True), (1920, 4, True, True), (2560, 1, True, False)])
 def test_groupnorm_one_launch_production_shapes(dtype, C, HW, silu, train):
     """GroupNorm32 (+SiLU) forward / backward at the 32x32, 16x16 and 8x8 levels of SD1.5 (B = 8), where the one-launch
     kernels (csrc/norm.hip gn1_*: the (sample, channel-block) slab stays in registers between statistics and apply) take

@@ -1,7 +1,12 @@
-"""Attention kernels A/B on the GPU: correctness vs fp64 torch + HIP-event timing, for the tile-synchronous
-kernels (variant 1) and the ping-pong schedule (variant 0 = heuristic), through the C ABI.
+"""Attention kernels A/B on the GPU: correctness vs fp64 torch + HIP-event timing through the C ABI.
 
-    python tests/tools/attn_bench.py [--bwd] [--out gpurun_out/attn_bench.json]
+    python tests/tools/attn_bench.py [--bwd] [--variants 14,0p,21p] [--rounds 7] [--out gpurun_out/attn_bench.json]
+
+A variant token is a `cl_debug_attention_variant` code (csrc/debug_hooks.h), optionally followed by `p`: the call then uses
+the pre-scaled-Q contract (CL_ATTN_Q_PRESCALED): q' = bf16(q32 * d^-0.5 * log2 e) where the plain variants get q = bf16(q32)
+-- the same fp32 values rounded ONCE either way, as the to_q projection's epilogue does -- and every variant is checked
+against the fp64 reference evaluated on ITS OWN q.  `--spike` adds a case whose scores grow by ~80 nats in a late key tile:
+the optimistic pre-scaled-Q forward has to notice and repeat the block with the running maximum.
 """
 import argparse
 import json
@@ -12,6 +17,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ctrlora_amd import hip   # noqa: E402
+
+LOG2E = 1.4426950408889634
+NAMES = {0: "default", 1: "tile_sync", 11: "bwd_setprio", 13: "fwd_hybrid32_la3", 14: "fwd_hybrid32_la2", 21: "fwd40_4wave_wg"}
 
 
 def rel(a, b):
@@ -31,131 +39,122 @@ def timeit(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) / iters
 
 
-def case(dh, N, Nkv, B, variants, bwd, check=True, rounds=1):
-    H = 8
-    inner = H * dh
-    g = torch.Generator().manual_seed(dh + N)
-    mk = lambda n, s=1.0: (torch.randn(B * n, inner, generator=g) * s).to(torch.bfloat16).cuda()
-    q, k, v, do = mk(N, 1.5), mk(Nkv, 1.5), mk(Nkv), mk(N)
-    scale = dh ** -0.5
-    rp = (N + 63) // 64 * 64
-    out = dict(shape=dict(dh=dh, N=N, Nkv=Nkv, B=B, H=H))
-    ref = None
-    if check:
-        split = lambda x, n: x.double().reshape(B, n, H, dh).permute(0, 2, 1, 3).requires_grad_(bwd)
-        qr, kr, vr = split(q, N), split(k, Nkv), split(v, Nkv)
-        s = torch.einsum("bhid,bhjd->bhij", qr, kr) * scale
-        orf = torch.einsum("bhij,bhjd->bhid", s.softmax(-1), vr)
-        back = lambda x, n: x.permute(0, 2, 1, 3).reshape(B * n, inner)
-        ref = dict(o=back(orf, N).detach(), lse=torch.logsumexp(s, -1).detach())
-        if bwd:
-            orf.backward(do.double().reshape(B, N, H, dh).permute(0, 2, 1, 3))
-            ref.update(dq=back(qr.grad, N), dk=back(kr.grad, Nkv), dv=back(vr.grad, Nkv))
-        del s, orf
-    flops_f = 4.0 * B * H * N * Nkv * dh
-    # variants 19 / 20 take Q pre-multiplied by scale * log2(e) (the factor belongs in the to_q weights) and fold -max into the
-    # matrix product: they get q' = bf16(q * scale * log2 e) and are checked against the reference evaluated on THAT q'
-    FOLD_VARIANTS = (19, 20)
-    q_fold, ref_fold = None, None
-    if any(v in FOLD_VARIANTS for _, v in variants):
-        q_fold = (q.float() * (scale * 1.4426950408889634)).to(torch.bfloat16)
-        if check:
-            with torch.no_grad():
-                split = lambda x, n: x.double().reshape(B, n, H, dh).permute(0, 2, 1, 3)
-                sf = torch.einsum("bhid,bhjd->bhij", split(q_fold, N), split(k, Nkv)) * 0.6931471805599453
-                of = torch.einsum("bhij,bhjd->bhid", sf.softmax(-1), split(v, Nkv))
-                ref_fold = dict(o=of.permute(0, 2, 1, 3).reshape(B * N, inner), lse=torch.logsumexp(sf, -1))
-                del sf, of
-    if rounds > 1:
-        # interleaved A/B (guide rule 24): the FIRST variant timed in a process measures 15-20 % slow (clock ramp after the
-        # fp64 reference), so single-pass numbers are order-dependent.  Here every variant is timed once per round,
-        # round-robin, after a warm-up, and the median / min over the rounds is reported; correctness once per variant.
-        o = torch.empty_like(q)
-        lse = torch.empty(B, H, rp, dtype=torch.float32, device="cuda")
-        delta = torch.empty_like(lse)
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        runs = {}
-        for name, var in variants:
-            hip.lib().cl_debug_attention_variant(var)
-            fold = var in FOLD_VARIANTS
-            hip.attention_fwd_v2(q_fold if fold else q, k, v, o, lse, B, H, N, Nkv, dh, scale)
-            r = {}
-            rf = ref_fold if fold else ref
-            if rf is not None:
-                torch.cuda.synchronize()
-                r["o_err"] = rel(o, rf["o"]); r["lse_err"] = rel(lse[:, :, :N] * 0.6931471805599453, rf["lse"])
-            if bwd:
-                hip.attention_bwd_v2(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, N, Nkv, dh, scale)
-                if ref is not None:
-                    torch.cuda.synchronize()
-                    r.update(dq_err=rel(dq, ref["dq"]), dk_err=rel(dk, ref["dk"]), dv_err=rel(dv, ref["dv"]))
-            runs[name] = dict(r, f=[], b=[])
-        hip.lib().cl_debug_attention_variant(variants[0][1])
-        timeit(lambda: hip.attention_fwd_v2(q, k, v, o, lse, B, H, N, Nkv, dh, scale), iters=60, warm=10)   # clocks up
-        for _ in range(rounds):
-            for name, var in variants:
-                hip.lib().cl_debug_attention_variant(var)
-                qq = q_fold if var in FOLD_VARIANTS else q
-                runs[name]["f"].append(timeit(lambda: hip.attention_fwd_v2(qq, k, v, o, lse, B, H, N, Nkv, dh, scale), iters=10, warm=2))
-                if bwd:
-                    runs[name]["b"].append(timeit(lambda: hip.attention_bwd_v2(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, N, Nkv, dh, scale), iters=10, warm=2))
-        for name, r in runs.items():
-            f = sorted(r.pop("f")); bb = sorted(r.pop("b"))
-            r["fwd_us_median"] = round(f[len(f) // 2] * 1e3, 1); r["fwd_us_min"] = round(f[0] * 1e3, 1)
-            r["fwd_tflops"] = round(flops_f / f[len(f) // 2] * 1e-9, 1)
-            if bb:
-                r["bwd_us_median"] = round(bb[len(bb) // 2] * 1e3, 1); r["bwd_us_min"] = round(bb[0] * 1e3, 1)
-                r["bwd_tflops"] = round(2.5 * flops_f / bb[len(bb) // 2] * 1e-9, 1)
-            out[name] = r
-        hip.lib().cl_debug_attention_variant(0)
-        return out
-    for name, var in variants:
-        hip.lib().cl_debug_attention_variant(var)
-        o = torch.empty_like(q)
-        lse = torch.empty(B, H, rp, dtype=torch.float32, device="cuda")
-        fwd = lambda: hip.attention_fwd_v2(q, k, v, o, lse, B, H, N, Nkv, dh, scale)
-        fwd()
-        torch.cuda.synchronize()
-        r = {}
-        if ref is not None:
-            r["o_err"] = rel(o, ref["o"])
-            r["lse_err"] = rel(lse[:, :, :N] * 0.6931471805599453, ref["lse"])
-        ms = timeit(fwd)
-        r["fwd_us"] = round(ms * 1e3, 1)
-        r["fwd_tflops"] = round(flops_f / ms * 1e-9, 1)
-        if bwd:
-            delta = torch.empty_like(lse)
-            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-            bw = lambda: hip.attention_bwd_v2(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, N, Nkv, dh, scale)
-            bw()
-            torch.cuda.synchronize()
-            if ref is not None:
-                r.update(dq_err=rel(dq, ref["dq"]), dk_err=rel(dk, ref["dk"]), dv_err=rel(dv, ref["dv"]))
-            ms = timeit(bw)
-            r["bwd_us"] = round(ms * 1e3, 1)
-            r["bwd_tflops"] = round(2.5 * flops_f / ms * 1e-9, 1)
-        out[name] = r
-    hip.lib().cl_debug_attention_variant(0)
+def parse_variants(spec):
+    out = []
+    for tok in spec.split(","):
+        tok = tok.strip()
+        pre = tok.endswith("p")
+        v = int(tok[:-1] if pre else tok)
+        out.append((NAMES.get(v, f"v{v}") + ("+q_prescaled" if pre else ""), v, pre))
     return out
 
 
-NAMES = {0: "default(fwd pingpong, bwd sync)", 1: "sync", 2: "fwd_pp_lookahead2", 3: "fwd+bwd pingpong", 5: "fwd_pp_1wg_per_cu", 6: "fwd_pp_setprio", 7: "fwd_pp_static_prio", 8: "fwd_pp_scalar_fma", 9: "fwd_pp_prio+static+scalar", 10: "fwd_pp_setprio+static", 11: "bwd_setprio", 12: "fwd_pp_r02(no prio)", 13: "fwd_hybrid32_la3", 14: "fwd_hybrid32_la2", 15: "fwd_wave_pipeline_8w", 16: "fwd_wave_pipeline_4w_3wg", 17: "fwd_wave_pipeline_8w_ahead4", 18: "fwd_wave_pipeline_inplace_4wps", 19: "fwd_wave_pipeline_8w_fold(q prescaled)", 20: "fwd_wave_pipeline_inplace_fold(q prescaled)"}
+def reference(q, k, v, do, B, H, N, Nkv, dh, scale, bwd):
+    inner = H * dh
+    split = lambda x, n: x.double().reshape(B, n, H, dh).permute(0, 2, 1, 3).requires_grad_(bwd)
+    qr, kr, vr = split(q, N), split(k, Nkv), split(v, Nkv)
+    s = torch.einsum("bhid,bhjd->bhij", qr, kr) * scale
+    orf = torch.einsum("bhij,bhjd->bhid", s.softmax(-1), vr)
+    back = lambda x, n: x.permute(0, 2, 1, 3).reshape(B * n, inner)
+    ref = dict(o=back(orf, N).detach(), lse=torch.logsumexp(s, -1).detach())
+    if bwd:
+        orf.backward(do.double().reshape(B, N, H, dh).permute(0, 2, 1, 3))
+        ref.update(dq=back(qr.grad, N), dk=back(kr.grad, Nkv), dv=back(vr.grad, Nkv))
+    return ref
+
+
+def case(dh, N, Nkv, B, variants, bwd, check=True, rounds=1, spike=False):
+    H = 8
+    inner = H * dh
+    g = torch.Generator().manual_seed(dh + N + (7 if spike else 0))
+    mk32 = lambda n, s=1.0: (torch.randn(B * n, inner, generator=g) * s).cuda()
+    q32, k, v, do = mk32(N, 1.5), mk32(Nkv, 1.5).to(torch.bfloat16), mk32(Nkv).to(torch.bfloat16), mk32(N).to(torch.bfloat16)
+    if spike:       # keys of the LAST tile of every (batch, head) line up with the queries: scores jump by tens of nats there
+        kk = k.float().reshape(B, Nkv, inner)
+        qq = q32.reshape(B, N, inner)
+        kk[:, -16:, :] = qq[:, :16, :] * 6.0
+        k = kk.reshape(B * Nkv, inner).to(torch.bfloat16)
+    scale = dh ** -0.5
+    q_plain = q32.to(torch.bfloat16)
+    q_pre = (q32 * (scale * LOG2E)).to(torch.bfloat16)
+    rp = (N + 63) // 64 * 64
+    out = dict(shape=dict(dh=dh, N=N, Nkv=Nkv, B=B, H=H, spike=spike))
+    refs = {}
+    if check:
+        with torch.enable_grad():
+            if any(not p for _, _, p in variants):
+                refs[False] = reference(q_plain, k, v, do, B, H, N, Nkv, dh, scale, bwd)
+            if any(p for _, _, p in variants):
+                # the reference's q is what the kernel's q' MEANS: q' / (scale log2 e); gradients are those of that q
+                refs[True] = reference(q_pre.double() / (scale * LOG2E), k, v, do, B, H, N, Nkv, dh, scale, bwd)
+    flops_f = 4.0 * B * H * N * Nkv * dh
+    o = torch.empty_like(q_plain)
+    lse = torch.empty(B, H, rp, dtype=torch.float32, device="cuda")
+    delta = torch.empty_like(lse)
+    dq, dk, dv = torch.empty_like(q_plain), torch.empty_like(k), torch.empty_like(v)
+    L = hip.lib()
+
+    def select(var):
+        assert L.cl_debug_attention_variant(var) == 0, f"unknown attention variant {var}"
+
+    fwd = lambda pre: hip.attention_fwd_v2(q_pre if pre else q_plain, k, v, o, lse, B, H, N, Nkv, dh, scale, q_prescaled=pre)
+    bw = lambda pre: hip.attention_bwd_v2(q_pre if pre else q_plain, k, v, o, do, lse, delta, dq, dk, dv, B, H, N, Nkv, dh, scale,
+                                          q_prescaled=pre)
+    runs = {}
+    for name, var, pre in variants:
+        select(var)
+        o.fill_(float("nan")); lse.fill_(float("nan"))
+        fwd(pre)
+        r = {}
+        rf = refs.get(pre)
+        if rf is not None:
+            torch.cuda.synchronize()
+            r["o_err"] = rel(o, rf["o"]); r["lse_err"] = rel(lse[:, :, :N] * 0.6931471805599453, rf["lse"])
+        if bwd:
+            bw(pre)
+            if rf is not None:
+                torch.cuda.synchronize()
+                r.update(dq_err=rel(dq, rf["dq"]), dk_err=rel(dk, rf["dk"]), dv_err=rel(dv, rf["dv"]))
+        runs[name] = dict(r, f=[], b=[])
+    # interleaved A/B (guide rule 24): the FIRST variant timed in a process measures 15-20 % slow (clock ramp after the fp64
+    # reference), so every variant is timed once per round, round-robin, after a warm-up; median / min over the rounds
+    select(variants[0][1])
+    timeit(lambda: fwd(variants[0][2]), iters=60, warm=10)
+    for _ in range(max(rounds, 1)):
+        for name, var, pre in variants:
+            select(var)
+            runs[name]["f"].append(timeit(lambda: fwd(pre), iters=10, warm=2))
+            if bwd:
+                runs[name]["b"].append(timeit(lambda: bw(pre), iters=10, warm=2))
+    for name, r in runs.items():
+        f = sorted(r.pop("f")); bb = sorted(r.pop("b"))
+        r["fwd_us_median"] = round(f[len(f) // 2] * 1e3, 1); r["fwd_us_min"] = round(f[0] * 1e3, 1)
+        r["fwd_tflops"] = round(flops_f / f[len(f) // 2] * 1e-9, 1)
+        if bb:
+            r["bwd_us_median"] = round(bb[len(bb) // 2] * 1e3, 1); r["bwd_us_min"] = round(bb[0] * 1e3, 1)
+            r["bwd_tflops"] = round(2.5 * flops_f / bb[len(bb) // 2] * 1e-9, 1)
+        out[name] = r
+    select(0)
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--bwd", action="store_true")
     ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--variants", default="1,0", help="comma list of cl_debug_attention_variant values")
-    ap.add_argument("--shapes", default="40,4096,4096,8;80,1024,1024,8;40,4096,4096,32;80,1024,1024,32;40,1024,1024,2;40,256,128,8")
-    ap.add_argument("--rounds", type=int, default=1, help="> 1: interleaved A/B, median / min over the rounds")
+    ap.add_argument("--spike", action="store_true", help="add the case that forces the optimistic forward's second pass")
+    ap.add_argument("--variants", default="14,0p", help="comma list of cl_debug_attention_variant codes, `p` suffix = pre-scaled Q")
+    ap.add_argument("--shapes", default="40,4096,4096,8;80,1024,1024,8;40,4096,4096,32;40,1024,1024,2;40,256,128,8")
+    ap.add_argument("--rounds", type=int, default=5, help="interleaved A/B: median / min over the rounds")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
-    variants = [(NAMES.get(int(v), f"v{v}"), int(v)) for v in args.variants.split(",")]
+    variants = parse_variants(args.variants)
     res = []
-    for sh in args.shapes.split(";"):
-        dh, N, Nkv, B = (int(x) for x in sh.split(","))
-        r = case(dh, N, Nkv, B, variants, args.bwd, check=(B <= 8 and not args.no_check), rounds=args.rounds)
+    cases = [tuple(int(x) for x in sh.split(",")) + (False,) for sh in args.shapes.split(";")]
+    if args.spike:
+        cases.append((40, 4096, 4096, 2, True))
+    for dh, N, Nkv, B, spike in cases:
+        r = case(dh, N, Nkv, B, variants, args.bwd, check=(B <= 8 and not args.no_check), rounds=args.rounds, spike=spike)
         print(json.dumps(r), flush=True)
         res.append(r)
     if args.out:
