@@ -168,19 +168,19 @@ def family_census(model, opt, data, reps=10):
             e[0] += 1
         return o_gemm(a1, w1, out, **kw)
 
-    def rec_af(q, k, v, o, lse, B, H, N, Nkv, dh, scale):
+    def rec_af(q, k, v, o, lse, B, H, N, Nkv, dh, scale, **kw):
         e = calls["attention"].setdefault(("fwd", B, H, N, Nkv, dh), [0, 4.0 * B * H * N * Nkv * dh,
-                                                                   lambda: o_af(q, k, v, o, lse, B, H, N, Nkv, dh, scale)])
+                                                                   lambda: o_af(q, k, v, o, lse, B, H, N, Nkv, dh, scale, **kw)])
         e[0] += 1
-        return o_af(q, k, v, o, lse, B, H, N, Nkv, dh, scale)
+        return o_af(q, k, v, o, lse, B, H, N, Nkv, dh, scale, **kw)
 
-    def rec_ab(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, N, Nkv, dh, scale):
+    def rec_ab(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, N, Nkv, dh, scale, **kw):
         nmm = 5 if dk is not None else 3          # S, dP, dQ (+ dK, dV): algorithmic, the two kernels recompute S / dP
         e = calls["attention"].setdefault(("bwd", B, H, N, Nkv, dh, dk is not None), [
             0, 2.0 * nmm * B * H * N * Nkv * dh,
-            lambda: o_ab(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, N, Nkv, dh, scale)])
+            lambda: o_ab(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, N, Nkv, dh, scale, **kw)])
         e[0] += 1
-        return o_ab(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, N, Nkv, dh, scale)
+        return o_ab(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, N, Nkv, dh, scale, **kw)
 
     hip.gemm, hip.attention_fwd_v2, hip.attention_bwd_v2 = rec_gemm, rec_af, rec_ab
     for n, fn in hbm_orig.items():
