@@ -431,6 +431,7 @@ static int launch_fwd40(const AttnFwdArgs& a, const void* V, long ldv, hipStream
 }
 
 int attn_fwd40(const AttnFwdArgs& a, const void* V, long ldv, hipStream_t st) {
+  if (g_attn_fwd40_waves == 1) return attn_fwd40x(a, V, ldv, st);
   return g_attn_fwd40_waves == 4 ? launch_fwd40<4>(a, V, ldv, st) : launch_fwd40<8>(a, V, ldv, st);
 }
 
