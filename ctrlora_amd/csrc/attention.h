@@ -47,8 +47,6 @@ extern int g_attn_variant;   // probe hook: 0 = heuristic, 1 = tile-synchronous 
 // pre-scaled-Q forward for d_head 40 (attention_fwd40.hip)
 bool attn_fwd40_applies(const AttnFwdArgs& a);
 int attn_fwd40(const AttnFwdArgs& a, const void* V, long ldv, hipStream_t st);
-extern int g_attn_fwd40_waves;   // probe hook: 8 / 4 = attention_fwd40.hip with that many waves per workgroup, 1 = attention_fwd40x.hip
-int attn_fwd40x(const AttnFwdArgs& a, const void* V, long ldv, hipStream_t st);
 int attn_delta(const AttnBwdArgs& a, hipStream_t st);   // delta[q] = sum_d dO[q,d] O[q,d]  (bf16)
 
 }  // namespace cl

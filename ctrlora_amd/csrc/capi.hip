@@ -46,11 +46,7 @@ int cl_gemm_tune_size(void) { return gemm_tune_size(); }
 int cl_debug_attention_variant(int v) {
   switch (v) {
     case 0: case 1: case 11: case 13: case 14:
-      g_attn_variant = v; g_attn_fwd40_waves = 8; return CL_OK;
-    case 21:            // pre-scaled-Q forward with 4-wave workgroups (three per CU) instead of 8-wave ones
-      g_attn_variant = 0; g_attn_fwd40_waves = 4; return CL_OK;
-    case 22:            // ... as the one-wave-per-SIMD, two-query-blocks-per-wave kernel (attention_fwd40x.hip)
-      g_attn_variant = 0; g_attn_fwd40_waves = 1; return CL_OK;
+      g_attn_variant = v; return CL_OK;
     default: return CL_EINVAL;
   }
 }

@@ -8,7 +8,7 @@ extern "C" {
 #endif
 /* attention schedule: 0 = default; 1 = tile-synchronous kernels only; 11 = backward with s_setprio;
  * 13 / 14 = hybrid forward (fragment lookahead 3 / 2) also where the pre-scaled-Q forward (attention_fwd40.hip) would
- * apply; 21 = that forward with 4-wave workgroups; 22 = its one-wave-per-SIMD form (attention_fwd40x.hip).  Unknown codes: CL_EINVAL, nothing changes. */
+ * apply.  Unknown codes: CL_EINVAL, nothing changes. */
 int cl_debug_attention_variant(int variant);
 /* 1 (default) = the dQ kernel forms delta itself; 0 = separate attn_delta launch */
 int cl_debug_attention_fuse_delta(int on);

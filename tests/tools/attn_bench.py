@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from ctrlora_amd import hip   # noqa: E402
 
 LOG2E = 1.4426950408889634
-NAMES = {0: "default", 1: "tile_sync", 11: "bwd_setprio", 13: "fwd_hybrid32_la3", 14: "fwd_hybrid32_la2", 21: "fwd40_4wave_wg", 22: "fwd40x_1wave_per_simd"}
+NAMES = {0: "default", 1: "tile_sync", 11: "bwd_setprio", 13: "fwd_hybrid32_la3", 14: "fwd_hybrid32_la2"}
 
 
 def rel(a, b):
