@@ -69,10 +69,6 @@ int launch_wgrad_tn(const void* dy, long lddy, const void* x, long ldx, float* d
 struct WgradDesc {
   const void* dy; long lddy; const void* x; long ldx; float* dW; long lddw; int M, N, K; float alpha;
   int tap, Hin, Win, Hout, Wout, stride, pad, reserved;
-  // fold mode (fold != null): dW is a READ-ONLY fp32 base; the kernel stores storage-dtype(dW + alpha dy^T x) to fold [N, K]
-  // (row stride ldf) and, if foldT != null, its transpose to foldT [K, N] (row stride ldft) -- the training-time LoRA fold
-  // W' = bf16(W + B A): dy = B^T [r, N], x = A [r, K].  M must fit one split (M <= 32 * min steps: r <= 256).
-  void* fold; long ldf; void* foldT; long ldft;
 };
 int launch_wgrad_tn_group(const WgradDesc* probs, int n, const void* zero_page, hipStream_t stream);
 extern int g_wgrad_blocks, g_wgrad_min_steps, g_wgrad_ring;

@@ -47,7 +47,6 @@ struct WgradProb {
   int tap;                           // >= 0: 3x3-conv tap mode (x rows gathered through the conv geometry)
   short Hin, Win, Hout, Wout;        // conv geometry (<= 32767)
   short stride, pad;
-  bf16_t* fold; bf16_t* foldT; long ldf, ldft;   // fold mode (see WgradDesc): outputs instead of the accumulation into dW
 };
 constexpr int WGRAD_MAX_PROBS = 24;
 struct WgradGroup { int n; int pad; WgradProb p[WGRAD_MAX_PROBS]; };
@@ -194,33 +193,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const WgradGroup grp, 
         const float4 v = *reinterpret_cast<const float4*>(&stg[rr * EST + cg]);
         if (slab) {   // one fp32 partial slab per m-split; summed by wgrad_reduce_kernel
           *reinterpret_cast<float4*>(slab + ((long)split * N + grow) * K + gcol) = v;
-        } else if (P.fold) {   // fold mode: W' = storage(base + alpha acc); the sum goes back to the staging tile for the transpose
-          const float4 bs = *reinterpret_cast<const float4*>(dW + (long)grow * lddw + gcol);
-          float o[4] = {bs.x + v.x * alpha, bs.y + v.y * alpha, bs.z + v.z * alpha, bs.w + v.w * alpha};
-          *reinterpret_cast<float4*>(&stg[rr * EST + cg]) = make_float4(o[0], o[1], o[2], o[3]);
-          store4(P.fold + (long)grow * P.ldf + gcol, o);
         } else {      // single split: this workgroup is the only writer of its tile
           float4* dst = reinterpret_cast<float4*>(dW + (long)grow * lddw + gcol);
           float4 o = *dst;
           o.x += v.x * alpha; o.y += v.y * alpha; o.z += v.z * alpha; o.w += v.w * alpha;
           *dst = o;
-        }
-      }
-    }
-    if (P.foldT) {   // transposed copy: lane = k column of the wave's 32 (n) x 64 (k) sub-tile, 8 consecutive n per store
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const int gk = k0 + wk * 64 + lane;
-      if (gk < K) {
-#pragma unroll
-        for (int n8 = 0; n8 < 4; ++n8) {
-          const int gn = n0 + wn * 64 + ps * 32 + n8 * 8;
-          if (gn < N) {
-            float f[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = stg[(n8 * 8 + j) * EST + lane];
-            store8(P.foldT + (long)gk * P.ldft + gn, f);
-          }
         }
       }
     }
@@ -290,8 +267,6 @@ int launch_wgrad_tn_group(const WgradDesc* probs, int n, const void* zero_page, 
     if (d.N % 8 || d.K % 8 || d.lddy % 8 || d.ldx % 8 || d.lddw % 4 || d.N < 8 || d.K < 8 ||
         (reinterpret_cast<uintptr_t>(d.dW) & 15))
       return CL_EINVAL;
-    if (d.fold && (d.tap >= 0 || d.ldf % 4 || (reinterpret_cast<uintptr_t>(d.fold) & 7) || d.M > 32 * g_wgrad_min_steps)) return CL_EINVAL;
-    if (d.foldT && (!d.fold || d.ldft % 8 || (reinterpret_cast<uintptr_t>(d.foldT) & 15))) return CL_EINVAL;
     if (d.tap > 8 || (d.tap >= 0 && (d.Hin <= 0 || d.Win <= 0 || d.Hout <= 0 || d.Wout <= 0 || d.Hin > 32767 || d.Win > 32767 ||
                                      d.stride < 1 || d.stride > 2 || d.M % (d.Hout * d.Wout))))
       return CL_EINVAL;
@@ -311,7 +286,7 @@ int launch_wgrad_tn_group(const WgradDesc* probs, int n, const void* zero_page, 
     const WgradDesc& d = probs[i];
     if (d.M <= 0 || d.N <= 0 || d.K <= 0) continue;
     const int tn = (d.N + 127) / 128, tk = (d.K + 127) / 128, steps = (d.M + 31) / 32;
-    int splits = d.fold ? 1 : (int)((steps + per - 1) / per);      // (fold mode: one split, no slab: the epilogue is the output)
+    int splits = (int)((steps + per - 1) / per);
     int pp = (steps + splits - 1) / splits;
     splits = (steps + pp - 1) / pp;
     long need = splits > 1 ? (long)splits * d.N * d.K * 4 : 0;
@@ -334,7 +309,6 @@ int launch_wgrad_tn_group(const WgradDesc* probs, int n, const void* zero_page, 
     P.blk0 = nblocks; P.red0 = nred;
     P.tap = d.tap; P.Hin = (short)d.Hin; P.Win = (short)d.Win; P.Hout = (short)d.Hout; P.Wout = (short)d.Wout;
     P.stride = (short)d.stride; P.pad = (short)d.pad;
-    P.fold = (bf16_t*)d.fold; P.foldT = (bf16_t*)d.foldT; P.ldf = d.ldf; P.ldft = d.ldft;
     nblocks += tn * tk * splits;
     if (splits > 1) nred += (int)(((long)d.N * (d.K / 4) + 255) / 256);
     ws_used += (need + 255) & ~255L;
@@ -346,7 +320,7 @@ int launch_wgrad_tn_group(const WgradDesc* probs, int n, const void* zero_page, 
 int launch_wgrad_tn(const void* dy, long lddy, const void* x, long ldx, float* dW, long lddw, int M, int N, int K,
                     float alpha, const void* zero_page, hipStream_t stream) {
   WgradDesc d{}; d.dy = dy; d.lddy = lddy; d.x = x; d.ldx = ldx; d.dW = dW; d.lddw = lddw; d.M = M; d.N = N; d.K = K;
-  d.alpha = alpha; d.tap = -1;     // (fold fields zero: plain accumulation)
+  d.alpha = alpha; d.tap = -1;
   return launch_wgrad_tn_group(&d, 1, zero_page, stream);
 }
 

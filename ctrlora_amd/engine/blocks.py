@@ -137,16 +137,13 @@ def linear_fwd(ctx: Ctx, L: LinearW, x, out=None, residual=None, act=hip.ACT_NON
     M = x.shape[0]
     t = None
     merged = L.Wm is not None and not ctx.record      # inference executor: W + B A already folded
-    folded = L.Wf is not None and not merged          # training executor: Wf = bf16(W + B A), refreshed at every repack
-    if L.r and not merged and (ctx.record or not folded):
-        t = ctx.new(M, L.r)                           # (folded: t = x A^T only feeds dB)
+    if L.r and not merged:
+        t = ctx.new(M, L.r)
         hip.gemm(x, L.A, t)
     if out is None:
         out = ctx.new(M, L.N, torch.float32 if out_f32 else None)
-    seg = t is not None and not folded
-    hip.gemm(x, L.Wm if merged else (L.Wf if folded else L.W), out, a2=t if seg else None, w2=L.B if seg else None,
-             bias=L.bias, residual=residual, alpha=alpha, beta=beta if residual is not None else 0.0, act=act,
-             out_f32=out_f32, alpha_n=alpha_n)
+    hip.gemm(x, L.Wm if merged else L.W, out, a2=t, w2=L.B if t is not None else None, bias=L.bias, residual=residual,
+             alpha=alpha, beta=beta if residual is not None else 0.0, act=act, out_f32=out_f32, alpha_n=alpha_n)
     return out, t
 
 
@@ -158,14 +155,9 @@ def group_fwd(ctx: Ctx, grp, x, alpha=1.0, alpha_n=0):
     if grp.Wm is not None and not ctx.record:              # inference executor: W + B A folded, one plain product
         hip.gemm(x, grp.Wm, y, bias=grp.bias, alpha=alpha, alpha_n=alpha_n)
         return y, None
-    t = None
-    if ctx.record or grp.Wf is None:
-        t = ctx.new(M, grp.G * grp.r)
-        hip.gemm(x, grp.A, t)
-    if grp.Wf is not None:                                 # training fold: one plain product, t only feeds dB
-        hip.gemm(x, grp.Wf, y, bias=grp.bias, alpha=alpha, alpha_n=alpha_n)
-    else:
-        hip.gemm(x, grp.W, y, a2=t, w2=grp.B, bias=grp.bias, a2_group_n=grp.N, alpha=alpha, alpha_n=alpha_n)
+    t = ctx.new(M, grp.G * grp.r)
+    hip.gemm(x, grp.A, t)
+    hip.gemm(x, grp.W, y, a2=t, w2=grp.B, bias=grp.bias, a2_group_n=grp.N, alpha=alpha, alpha_n=alpha_n)
     return y, t
 
 
@@ -178,10 +170,7 @@ def linear_bwd_data(ctx: Ctx, L: LinearW, dy, out=None, accum=None):
         hip.gemm(dy, L.Bt, u)
     if out is None:
         out = ctx.new(M, L.K)
-    if L.Wft is not None:                                  # training fold: dx = dy (W + B A); u only feeds dA
-        hip.gemm(dy, L.Wft, out, residual=accum, beta=1.0 if accum is not None else 0.0)
-    else:
-        hip.gemm(dy, L.Wt, out, a2=u, w2=L.At if L.r else None, residual=accum, beta=1.0 if accum is not None else 0.0)
+    hip.gemm(dy, L.Wt, out, a2=u, w2=L.At if L.r else None, residual=accum, beta=1.0 if accum is not None else 0.0)
     return out, u
 
 
@@ -422,10 +411,7 @@ class AttnE:
         dx = None
         if need_dx:
             dx = ctx.new(M, grp.K)
-            if grp.Wft is not None:
-                hip.gemm(dy, grp.Wft, dx, residual=accum, beta=1.0 if accum is not None else 0.0)
-            else:
-                hip.gemm(dy, grp.Wt, dx, a2=u, w2=grp.At, residual=accum, beta=1.0 if accum is not None else 0.0)
+            hip.gemm(dy, grp.Wt, dx, a2=u, w2=grp.At, residual=accum, beta=1.0 if accum is not None else 0.0)
         return dx, u
 
     def project_context(self, ctx: Ctx, c):

@@ -61,8 +61,6 @@ class NetCfg:
 
 # A/B switch: CTRLORA_GROUP_LORA=0 keeps one launch per LoRA linear
 GROUP_LORA = os.environ.get("CTRLORA_GROUP_LORA", "1") != "0"
-# A/B switch: 0 = training executors keep the LoRA up-projection as a second K segment of every product (rounds 1-3)
-TRAIN_FOLD = os.environ.get("CTRLORA_TRAIN_FOLD", "1") != "0"
 
 
 def is_trainable_name(n: str) -> bool:
@@ -80,8 +78,6 @@ class _Builder:
         self.tr_lora = lora_set if lora_set is not None else trainables
         self.train_all = train_all
         self.fold_lora = False       # set by ControlNetE before building: LoRA linears keep their fp32 base weight
-        # training executors: fold W + B A into one packed weight after every optimizer step (packing.LinearW.Wf)
-        self.train_fold = bool(TRAIN_FOLD and need_bwd and not train_all and dtype == torch.bfloat16)
         self.groups: List[LoraGroup] = []
         self.linears: List[LinearW] = []
         self.norms: List[NormW] = []
@@ -105,7 +101,7 @@ class _Builder:
         dn = name + ".lora_layer.down.weight"
         L = LinearW(self._g(name + ".weight"), self._g(name + ".bias") if self._has(name + ".bias") else None,
                     self.dtype, self.device, self.need_bwd,
-                    keep_f32=(self.fold_lora or self.train_fold) and self._has(dn) and self.dtype != torch.float32)
+                    keep_f32=self.fold_lora and self._has(dn) and self.dtype != torch.float32)
         if self.train_all:
             tW = self.tr.declare(self.prefix + name + ".weight", (L.N, L.K))
             tb = self.tr.declare(self.prefix + name + ".bias", (L.N,)) if self._has(name + ".bias") else None
@@ -115,8 +111,6 @@ class _Builder:
             un = name + ".lora_layer.up.weight"
             tB = self.tr_lora.declare(self.prefix + un, self._g(un).shape)
             L.attach_lora(tA, tB, self.device)
-            if self.train_fold and L.W32 is not None:
-                L.enable_train_fold()
         self.linears.append(L)
         if not self.train_all:
             self.frozen.append(lambda: L.load(self._g(name + ".weight"),
@@ -509,9 +503,6 @@ class ControlNetE:
             desc, prefix, n, tiles = self._repack_table(ts)
             if n:
                 hip.repack(self.dtype, ts.flat, desc, prefix, n, tiles)
-        probs = [L.fold_problem() for L in self._b.linears if L.Wf is not None]
-        if probs:
-            hip.lora_fold_group(probs)         # Wf = bf16(W + B A), Wft: ceil(n / 24) launches (inside the captured optimizer piece)
         for L in self._b.linears:
             if self.merge_lora:
                 L.merge_lora()

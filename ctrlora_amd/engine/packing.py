@@ -110,11 +110,6 @@ class LinearW:
         # inference executors: W + B A folded into one packed weight (cldm/lora.py:_fuse_lora does the same on the
         # module; the reference sanctions it for inference) -- no down-projection launch, no second K segment
         self.Wm: Optional[torch.Tensor] = None
-        # TRAINING executors (bf16): Wf = bf16(W_fp32 + B A) and Wft = Wf^T, refreshed from the masters after every optimizer
-        # step (ControlNetE.repack -> cl_weight_grad_tn_group fold mode): the forward and the data gradient are plain products
-        # -- no second K segment of r columns (+40 % K at 320) -- while t = x A^T and u = dy B are still formed for dB / dA.
-        self.Wf: Optional[torch.Tensor] = None
-        self.Wft: Optional[torch.Tensor] = None
         # trainable dense weight (zero convs)
         self.tW: Optional[Trainable] = None
         self.tb: Optional[Trainable] = None
@@ -163,16 +158,6 @@ class LinearW:
         self.At = torch.empty(self.K, self.r, dtype=self.dtype, device=device)
         self.B = torch.empty(self.N, self.r, dtype=self.dtype, device=device)
         self.Bt = torch.empty(self.r, self.N, dtype=self.dtype, device=device)
-
-    def enable_train_fold(self):
-        assert self.tA is not None and self.W32 is not None and self.Wt is not None
-        if self.Wf is None:
-            self.Wf = torch.empty_like(self.W)
-            self.Wft = torch.empty_like(self.Wt)
-
-    def fold_problem(self):
-        """(B^T [r, N], A [r, K], W_fp32 [N, K], Wf, Wft) for hip.lora_fold_group."""
-        return (self.Bt, self.A, self.W32, self.Wf, self.Wft)
 
     def merge_lora(self):
         """Wm = storage-dtype(W + B A) from the packed base weight and the fp32 LoRA masters (weight-load time only)."""
@@ -240,12 +225,6 @@ class LoraGroup:
         self.B = torch.empty(G * N, r, dtype=dt_, device=dev)
         self.Bt = torch.empty(G * r, N, dtype=dt_, device=dev)
         self.Wm = None
-        self.Wf = self.Wft = None
-        if all(L.Wf is not None for L in members):                   # training fold: the members' folded weights side by side
-            self.Wf = torch.empty(G * N, K, dtype=dt_, device=dev)
-            self.Wft = torch.empty(K, G * N, dtype=dt_, device=dev)
-            for g, L in enumerate(members):
-                L.Wf, L.Wft = self.Wf[g * N:(g + 1) * N], self.Wft[:, g * N:(g + 1) * N]
         for g, L in enumerate(members):
             L.W = self.W[g * N:(g + 1) * N]
             if need_bwd:

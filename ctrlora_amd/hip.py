@@ -30,8 +30,7 @@ class WgradDesc(C.Structure):
     _fields_ = [("dy", C.c_void_p), ("lddy", C.c_long), ("x", C.c_void_p), ("ldx", C.c_long),
                 ("dW", C.c_void_p), ("lddw", C.c_long), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
                 ("scale", C.c_float), ("tap", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("Hout", C.c_int),
-                ("Wout", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("reserved", C.c_int),
-                ("fold", C.c_void_p), ("ldf", C.c_long), ("foldT", C.c_void_p), ("ldft", C.c_long)]
+                ("Wout", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("reserved", C.c_int)]
 
 
 class GemmParams(C.Structure):
@@ -314,27 +313,6 @@ def weight_grad_tn_group(problems):
             d.tap, d.Hin, d.Win, d.Hout, d.Wout, d.stride, d.pad = prob[4]
     _chk(lib().cl_weight_grad_tn_group(BF16, n, C.cast(arr, C.c_void_p), zero_page(problems[0][0].device).data_ptr(),
                                        stream()), "cl_weight_grad_tn_group")
-
-
-def lora_fold_group(problems):
-    """problems: list of (Bt [r, N] bf16, A [r, K] bf16, W32 [N, K] fp32 (read only), Wf [N, K] bf16, WfT [K, N] bf16 or None):
-    Wf = bf16(W32 + B A) and its transpose, 24 problems per launch (cl_wgrad_desc fold mode)."""
-    n = len(problems)
-    if n == 0:
-        return
-    if _workspace is None:
-        ensure_workspace(problems[0][0].device)
-    arr = (WgradDesc * n)()
-    for d, (Bt, A, W32, Wf, WfT) in zip(arr, problems):
-        d.dy = Bt.data_ptr(); d.lddy = ld(Bt); d.x = A.data_ptr(); d.ldx = ld(A)
-        d.dW = W32.data_ptr(); d.lddw = ld(W32); d.M = Bt.shape[0]; d.N = Bt.shape[1]; d.K = A.shape[1]
-        d.scale = 1.0
-        d.tap = -1
-        d.fold = Wf.data_ptr(); d.ldf = ld(Wf)
-        if WfT is not None:
-            d.foldT = WfT.data_ptr(); d.ldft = ld(WfT)
-    _chk(lib().cl_weight_grad_tn_group(BF16, n, C.cast(arr, C.c_void_p), zero_page(problems[0][0].device).data_ptr(),
-                                       stream()), "cl_weight_grad_tn_group(fold)")
 
 
 def repack(dtype, flat, desc, tile_prefix, ndesc, total_tiles):

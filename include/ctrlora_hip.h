@@ -152,11 +152,6 @@ typedef struct cl_wgrad_desc {
    * with input pixel (oy*stride + tap/3 - pad, ox*stride + tap%3 - pad), zero outside the image; dW points at the tap's
    * [N, K] slice of a [N][3][3][K] gradient (lddw = 9 K).  tap = -1: plain dy^T x (the other fields are ignored). */
   int tap, Hin, Win, Hout, Wout, stride, pad, reserved;
-  /* ABI 6, fold mode (fold != NULL): dW is a READ-ONLY fp32 base W; the launch stores dtype(W + scale dy^T x) to fold [N, K]
-   * (row stride ldf) and, if foldT != NULL, its transpose to foldT [K, N] (row stride ldft).  With dy = B^T [r, N] and
-   * x = A [r, K] that is the LoRA fold W' = W + B A of LoRACompatibleLinear._fuse_lora (cldm/lora.py:237-260) in ONE rounding,
-   * refreshed after every optimizer step so that the training forward and its data gradient are plain products.  M <= 256. */
-  void* fold; long ldf; void* foldT; long ldft;
 } cl_wgrad_desc;
 int cl_weight_grad_tn_group(int dtype, int n, const cl_wgrad_desc* descs, const void* zero_page, void* stream);
 
