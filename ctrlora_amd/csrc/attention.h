@@ -35,6 +35,10 @@ struct AttnBwdArgs {
   int B, H, N, Nkv, DH;
   float scale;
   int q_prescaled;   // as in AttnFwdArgs; dQ / dK / dV are the gradients of the TRUE q, k, v either way
+  // Optional scratch of B * H * lse_stride * 32 bytes (16-byte aligned): with a pre-scaled Q and d_head 40 the dQ kernel
+  // leaves (-lse, -delta) of every query row there, split into three bf16 pieces each, and the dK/dV kernel stages them as
+  // the pad columns of its Q / dO tiles: the matrix products then deliver s - lse and dP - delta (see attention_tr.hip).
+  void* row_ws;
 };
 
 int attn_fwd(const AttnFwdArgs& a, int dtype, hipStream_t st);

@@ -54,6 +54,19 @@ template <int DH> struct TileDma {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) off[j] = r[j] * (int)ld_bytes + cc16[j];
   }
+  // Whole 64-row tile whose pad chunk (16 bytes per row) comes from a second array `pad` with `pad_stride` bytes per row:
+  // ONE instruction per 1 KiB piece, the source address selected per lane
+  __device__ __forceinline__ void issue_with_pad(const char* base, long ld_bytes, const int (&off)[NJ], int row0, char* dst,
+                                                 int wave, const char* pad, int pad_stride) const {
+    const char* tb = base + (long)row0 * ld_bytes;      // wave-uniform
+    const char* pb = pad + (long)row0 * pad_stride;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      if (wave + 4 * j < TI) {
+        const char* src = real[j] ? tb + off[j] : pb + r[j] * pad_stride;
+        glds16(src, dst + (wave + 4 * j) * 1024);
+      }
+  }
   __device__ __forceinline__ void issue(const char* base, long ld_bytes, const int (&off)[NJ], int row0, int nrows,
                                         char* dst, int wave) const {
     const char* tb = base + (long)row0 * ld_bytes;      // wave-uniform
@@ -71,6 +84,23 @@ template <int DH> struct TileDma {
     }
   }
 };
+
+// x as three bf16 pieces (hi + mid + lo = x to ~2^-24 relative): words {hi | mid << 16, lo}
+__device__ __forceinline__ void split3_bf16(float x, uint32_t& w0, uint32_t& w1) {
+  const uint32_t hi = pack2bf(x, 0.f) & 0xffffu;
+  const float r1 = x - __uint_as_float(hi << 16);
+  const uint32_t mid = pack2bf(r1, 0.f) & 0xffffu;
+  const float r2 = r1 - __uint_as_float(mid << 16);
+  const uint32_t lo = pack2bf(r2, 0.f) & 0xffffu;
+  w0 = hi | (mid << 16); w1 = lo;
+}
+// pad chunk (1, 1, 1, 0, 0, 0, 0, 0): meets the three pieces above in the contraction
+__device__ __forceinline__ u32x4_t ones3_chunk() { return u32x4_t{0x3F803F80u, 0x00003F80u, 0u, 0u}; }
+template <int DH> __device__ __forceinline__ void init_pads_ones3(char* tiles, int ntile, int tid, int nthreads) {
+  using G = Geo<DH>;
+  for (int i = tid; i < ntile * 64; i += nthreads)
+    *reinterpret_cast<uint4*>(tiles + (long)i * G::ROWB + G::CPR * 16) = make_uint4(0x3F803F80u, 0x00003F80u, 0u, 0u);
+}
 
 }  // namespace
 
@@ -519,10 +549,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hyb_kernel(AttnFwdArgs p, con
 
 // =============================================================================== dK / dV
 // TAIL: N is not a multiple of 64 (query masking)
-template <int DH, int KF, bool TAIL, bool PRIO = false>
+// FOLD (d_head 40, pre-scaled Q, row_ws given): -lse and -delta ride through the matrix products.  The 64-deep walk of
+// d_head 40 has 24 spare contraction slots; columns 40..42 of every Q row hold -lse as three bf16 pieces (hi + mid + lo),
+// columns 40..42 of K hold 1.0 -- so S arrives as s - lse (log2 domain: Q is pre-scaled) and P = exp2(S); likewise dO / V
+// carry -delta / 1.0 and dP arrives as dP - delta.  Per score pair that leaves exp2, exp2, one packed multiply (5 -> 3 VALU).
+// The pieces come from row_ws (written by the dQ kernel, which runs first) as the pad chunk of the Q / dO tiles.
+template <int DH, int KF, bool TAIL, bool PRIO = false, bool FOLD = false>
 __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_tr_kernel(AttnBwdArgs p) {
   using G = Geo<DH>;
   constexpr int CPR = G::CPR, KSTEPS = G::KSTEPS, DN = G::DN, ROWB = G::ROWB, TILE = G::TILE, TI = G::TI;
+  static_assert(!FOLD || (DH == 40 && !TAIL), "the fold uses the pad chunk of the 96-byte pitch, whole tiles only");
+  constexpr int CIN = FOLD ? G::CPRP : CPR;    // chunks of a row that enter the S / dP contraction
   constexpr int STAGE = 2 * TILE + 512;     // Q tile, dO tile, lse[64], delta[64]
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -546,6 +583,9 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_tr_kerne
       const int c = 4 * ks + g;
       kb[kf][ks] = (c < CPR) ? *reinterpret_cast<const u32x4_t*>(kp + c * 16) : u32x4_t{0u, 0u, 0u, 0u};
       vb[kf][ks] = (c < CPR) ? *reinterpret_cast<const u32x4_t*>(vp + c * 16) : u32x4_t{0u, 0u, 0u, 0u};
+      if constexpr (FOLD) {
+        if (c == CPR) { kb[kf][ks] = ones3_chunk(); vb[kf][ks] = ones3_chunk(); }    // columns 40..42 = 1.0
+      }
     }
   }
   const char* qbase = (const char*)p.Q + ((long)b * p.N * p.ldq + (long)h * DH) * 2;
@@ -562,8 +602,14 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_tr_kerne
   TileDma<DH> dma; dma.init(wave, lane);
   int qoff[TileDma<DH>::NJ], dooff[TileDma<DH>::NJ];
   dma.offsets(p.ldq * 2, qoff); dma.offsets(p.lddo * 2, dooff);
+  const char* rowpad = FOLD ? (const char*)p.row_ws + ((long)b * p.H + h) * p.lse_stride * 32 : nullptr;
   auto issue = [&](int t, int buf) {
     char* base = smem + buf * STAGE;
+    if constexpr (FOLD) {                    // pad chunks = (-lse pieces) / (-delta pieces) of the rows: no lse / delta block
+      dma.issue_with_pad(qbase, p.ldq * 2, qoff, t * 64, base, wave, rowpad, 32);
+      dma.issue_with_pad(dobase, p.lddo * 2, dooff, t * 64, base + TILE, wave, rowpad + 16, 32);
+      return;
+    }
     dma.issue(qbase, p.ldq * 2, qoff, t * 64, p.N, base, wave);
     dma.issue(dobase, p.lddo * 2, dooff, t * 64, p.N, base + TILE, wave);
     if (wave == (TI & 3) && lane < 32) {   // lse (lanes 0-15) and delta (16-31), 64 floats each; lse_stride % 64 == 0
@@ -576,8 +622,10 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_tr_kerne
   const uint32_t rrow = lq * ROWB + g * 16;
   const uint32_t troff = (4 * g + ((lane >> 2) & 3)) * ROWB + (lane & 3) * 8;
   const int ntiles = (p.N + 63) / 64;
-  init_pads<DH>(smem, 2, 0u, 0u, tid, 256);
-  init_pads<DH>(smem + STAGE, 2, 0u, 0u, tid, 256);
+  if constexpr (!FOLD) {                    // (FOLD: the pad chunks arrive with the tile DMA)
+    init_pads<DH>(smem, 2, 0u, 0u, tid, 256);
+    init_pads<DH>(smem + STAGE, 2, 0u, 0u, tid, 256);
+  }
   issue(0, 0);
   for (int t = 0; t < ntiles; ++t) {
     const int buf = t & 1;
@@ -595,12 +643,15 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_tr_kerne
         u32x4_t qa[KSTEPS], da[KSTEPS];
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-          const bool in = 4 * ks + g < CPR;
+          const bool in = 4 * ks + g < CIN;
           qa[ks] = in ? lds_read_b128(aQ + rrow + qf * 16 * ROWB + ks * 64) : u32x4_t{0u, 0u, 0u, 0u};
           da[ks] = in ? lds_read_b128(adO + rrow + qf * 16 * ROWB + ks * 64) : u32x4_t{0u, 0u, 0u, 0u};
         }
-        const u32x4_t l4 = lds_read_b128(aL + (qf * 16 + 4 * g) * 4);
-        const u32x4_t d4 = lds_read_b128(aL + 256 + (qf * 16 + 4 * g) * 4);
+        u32x4_t l4 = {0u, 0u, 0u, 0u}, d4 = {0u, 0u, 0u, 0u};
+        if constexpr (!FOLD) {
+          l4 = lds_read_b128(aL + (qf * 16 + 4 * g) * 4);
+          d4 = lds_read_b128(aL + 256 + (qf * 16 + 4 * g) * 4);
+        }
         lds_wait();
         const float lv[4] = {__uint_as_float(l4.x), __uint_as_float(l4.y), __uint_as_float(l4.z), __uint_as_float(l4.w)};
         const float dv[4] = {__uint_as_float(d4.x), __uint_as_float(d4.y), __uint_as_float(d4.z), __uint_as_float(d4.w)};
@@ -616,11 +667,17 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_tr_kerne
           // epilogue (linear).  Two rows per packed instruction.
 #pragma unroll
           for (int h2 = 0; h2 < 2; ++h2) {
-            const f32x2_t s2 = {sc[2 * h2], sc[2 * h2 + 1]}, l2 = {lv[2 * h2], lv[2 * h2 + 1]};
-            const f32x2_t x = s2 * sl2 - l2;
-            f32x2_t pr = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
-            const f32x2_t dd = f32x2_t{dp[2 * h2], dp[2 * h2 + 1]} - f32x2_t{dv[2 * h2], dv[2 * h2 + 1]};
-            f32x2_t dsv = pr * dd;
+            f32x2_t pr, dsv;
+            if constexpr (FOLD) {            // sc = s - lse, dp = dP - delta already
+              pr = f32x2_t{__builtin_amdgcn_exp2f(sc[2 * h2]), __builtin_amdgcn_exp2f(sc[2 * h2 + 1])};
+              dsv = pr * f32x2_t{dp[2 * h2], dp[2 * h2 + 1]};
+            } else {
+              const f32x2_t s2 = {sc[2 * h2], sc[2 * h2 + 1]}, l2 = {lv[2 * h2], lv[2 * h2 + 1]};
+              const f32x2_t x = s2 * sl2 - l2;
+              pr = f32x2_t{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+              const f32x2_t dd = f32x2_t{dp[2 * h2], dp[2 * h2 + 1]} - f32x2_t{dv[2 * h2], dv[2 * h2 + 1]};
+              dsv = pr * dd;
+            }
             if constexpr (TAIL) {   // lse / delta pads may hold NaN
               if (qrow + 2 * h2 >= p.N) { pr.x = 0.f; dsv.x = 0.f; }
               if (qrow + 2 * h2 + 1 >= p.N) { pr.y = 0.f; dsv.y = 0.f; }
@@ -677,10 +734,15 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_tr_kerne
 // DELTA: delta[q] = sum_d dO[q,d] O[q,d] is formed here from the dO fragments the kernel holds anyway (+ one read of the
 // O rows) and stored for the dK/dV kernel, which then has to be launched AFTER this one: saves the separate
 // attn_delta launch (32 per training step, ~13 us each at the 64x64 level).
-template <int DH, int QF, bool TAIL, bool DELTA = false, bool PRIO = false>
+// FOLD: as in the dK/dV kernel; here Q / dO are this wave's register fragments, so -lse / -delta go straight into their
+// columns 40..42 and K / V tiles get (1, 1, 1, 0, ...) as their pad chunk.  The kernel also leaves the pieces in row_ws for
+// the dK/dV kernel (DELTA form: it runs first).
+template <int DH, int QF, bool TAIL, bool DELTA = false, bool PRIO = false, bool FOLD = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_tr_kernel(AttnBwdArgs p) {
   using G = Geo<DH>;
   constexpr int CPR = G::CPR, KSTEPS = G::KSTEPS, DN = G::DN, ROWB = G::ROWB, TILE = G::TILE;
+  static_assert(!FOLD || (DH == 40 && !TAIL && DELTA), "fold: d_head 40, whole key tiles, fused delta");
+  constexpr int CIN = FOLD ? G::CPRP : CPR;
   constexpr int STAGE = 2 * TILE;           // K tile, V tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -729,6 +791,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_tr_kernel(AttnBwdArgs p) {
     } else {
       dlt_q[f] = p.Delta[((long)b * p.H + h) * p.lse_stride + qr];
     }
+    if constexpr (FOLD) {
+      uint32_t l0, l1, d0, d1;
+      split3_bf16(-lse_q[f], l0, l1);
+      split3_bf16(-dlt_q[f], d0, d1);
+      if (g == 1) {                          // chunk 5 = columns 40..47 of this lane's query (4 ks + g with ks = 1)
+        qb[f][1] = u32x4_t{l0, l1, 0u, 0u};
+        ob[f][1] = u32x4_t{d0, d1, 0u, 0u};
+      }
+      if (g == 0 && q_w + f * 16 + lq < p.N) {
+        uint4* rp = reinterpret_cast<uint4*>((char*)p.row_ws + (((long)b * p.H + h) * p.lse_stride + qr) * 32);
+        rp[0] = make_uint4(l0, l1, 0u, 0u);
+        rp[1] = make_uint4(d0, d1, 0u, 0u);
+      }
+    }
   }
   const char* kbase = (const char*)p.K + ((long)b * p.Nkv * p.ldk + (long)h * DH) * 2;
   const char* vbase = (const char*)p.V + ((long)b * p.Nkv * p.ldv + (long)h * DH) * 2;
@@ -746,7 +822,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_tr_kernel(AttnBwdArgs p) {
   TileDma<DH> dma; dma.init(wave, lane);
   int koff[TileDma<DH>::NJ], voff[TileDma<DH>::NJ];
   dma.offsets(p.ldk * 2, koff); dma.offsets(p.ldv * 2, voff);
-  init_pads<DH>(smem, 4, 0u, 0u, tid, 256);
+  if constexpr (FOLD) init_pads_ones3<DH>(smem, 4, tid, 256);      // K / V columns 40..42 = 1.0
+  else init_pads<DH>(smem, 4, 0u, 0u, tid, 256);
   dma.issue(kbase, p.ldk * 2, koff, 0, p.Nkv, smem, wave);
   dma.issue(vbase, p.ldv * 2, voff, 0, p.Nkv, smem + TILE, wave);
   for (int t = 0; t < ntiles; ++t) {
@@ -768,7 +845,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_tr_kernel(AttnBwdArgs p) {
         u32x4_t ka[KSTEPS], va[KSTEPS];
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-          const bool in = 4 * ks + g < CPR;
+          const bool in = 4 * ks + g < CIN;
           ka[ks] = in ? lds_read_b128(aK + rrow + kf * 16 * ROWB + ks * 64) : u32x4_t{0u, 0u, 0u, 0u};
           va[ks] = in ? lds_read_b128(aV + rrow + kf * 16 * ROWB + ks * 64) : u32x4_t{0u, 0u, 0u, 0u};
         }
@@ -783,9 +860,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_tr_kernel(AttnBwdArgs p) {
           // dS^T = P (dP - delta), two keys per packed instruction; d_head^-0.5 goes onto dQ in the epilogue
 #pragma unroll
           for (int h2 = 0; h2 < 2; ++h2) {
-            const f32x2_t x = f32x2_t{sc[2 * h2], sc[2 * h2 + 1]} * sl2 - lse_q[f];
-            const f32x2_t pr = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
-            f32x2_t dsv = pr * (f32x2_t{dp[2 * h2], dp[2 * h2 + 1]} - dlt_q[f]);
+            f32x2_t dsv;
+            if constexpr (FOLD) {            // sc = s - lse, dp = dP - delta already
+              const f32x2_t pr = {__builtin_amdgcn_exp2f(sc[2 * h2]), __builtin_amdgcn_exp2f(sc[2 * h2 + 1])};
+              dsv = pr * f32x2_t{dp[2 * h2], dp[2 * h2 + 1]};
+            } else {
+              const f32x2_t x = f32x2_t{sc[2 * h2], sc[2 * h2 + 1]} * sl2 - lse_q[f];
+              const f32x2_t pr = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+              dsv = pr * (f32x2_t{dp[2 * h2], dp[2 * h2 + 1]} - dlt_q[f]);
+            }
             if constexpr (TAIL) {
               if (kv0 + kf * 16 + 4 * g + 2 * h2 >= p.Nkv) dsv.x = 0.f;
               if (kv0 + kf * 16 + 4 * g + 2 * h2 + 1 >= p.Nkv) dsv.y = 0.f;
@@ -941,6 +1024,26 @@ static int launch_bwd_tr(const AttnBwdArgs& a, hipStream_t st) {
     if (rc) return rc;
   }
   const bool prio = g_attn_variant == 11;
+  // -lse / -delta folded into the matrix products: d_head 40, pre-scaled Q, whole tiles, row scratch given, enough
+  // workgroups for the two-fragment forms (the 64x64 self-attentions)
+  if constexpr (DH == 40 && !TQ && !TK) {
+    const long qb2 = (long)(a.N / 128) * a.H * a.B, kb2 = (long)(a.Nkv / 128) * a.H * a.B;
+    if (a.q_prescaled && a.row_ws && fused_delta && g_attn_variant == 0 && a.N % 128 == 0 && a.Nkv % 128 == 0 &&
+        qb2 >= 512 && (!a.dK || kb2 >= 512)) {
+      static bool done_f = false;
+      if (!done_f) {
+        if (set_lds(&attn_bwd_dq_tr_kernel<DH, KF, TK, true, false, true>, LDS_DQ) ||
+            set_lds(&attn_bwd_dkv_tr_kernel<DH, KF, TQ, false, true>, LDS_DKV))
+          return CL_ELAUNCH;
+        done_f = true;
+      }
+      hipLaunchKernelGGL((attn_bwd_dq_tr_kernel<DH, KF, TK, true, false, true>), dim3(a.N / 128, a.H, a.B), dim3(256), LDS_DQ, st, a);
+      if (a.dK)
+        hipLaunchKernelGGL((attn_bwd_dkv_tr_kernel<DH, KF, TQ, false, true>), dim3(a.Nkv / 128, a.H, a.B), dim3(256), LDS_DKV, st, a);
+      CL_CHECK_LAUNCH();
+      return CL_OK;
+    }
+  }
   auto launch_dq = [&]() {
     const long qb2 = (long)((a.N + 64 * KF - 1) / (64 * KF)) * a.H * a.B;
     if (KF == 2 && qb2 >= 512) {
@@ -983,6 +1086,7 @@ int attn_bwd_tr(const AttnBwdArgs& a, hipStream_t st) {
   if ((a.ldq * 2) % 16 || (a.ldk * 2) % 16 || (a.ldv * 2) % 16 || (a.lddo * 2) % 16 || (a.ldo * 2) % 16) return CL_EINVAL;
   if ((a.lddq * 2) % 16 || a.lse_stride % 64 || a.lse_stride < a.N) return CL_EINVAL;
   if ((a.dK == nullptr) != (a.dV == nullptr)) return CL_EINVAL;
+  if (a.row_ws && (reinterpret_cast<uintptr_t>(a.row_ws) & 15)) return CL_EINVAL;
   if (a.dK && ((a.lddk * 2) % 16 || (a.lddv * 2) % 16)) return CL_EINVAL;
   switch (a.DH) {
     case 8: return launch_bwd_tr_t<8>(a, st);

@@ -240,12 +240,13 @@ int cl_attention_fwd_v2(int dtype, const void* Q, long ldq, const void* K, long 
 int cl_attention_bwd_v2(int dtype, const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv,
                         const void* O, long ldo, const void* dO, long lddo, const float* LSE, float* Delta,
                         int lse_stride, void* dQ, long lddq, void* dK, long lddk, void* dV, long lddv, int B, int H,
-                        int N, int Nkv, int dh, float scale, int flags, void* stream) {
+                        int N, int Nkv, int dh, float scale, int flags, void* row_ws, void* stream) {
   if (dtype != CL_BF16 || (flags & ~CL_ATTN_Q_PRESCALED)) return CL_EINVAL;
   AttnBwdArgs a{}; a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo;
   a.dO = dO; a.lddo = lddo; a.LSE = LSE; a.Delta = Delta; a.lse_stride = lse_stride; a.dQ = dQ; a.lddq = lddq;
   a.dK = dK; a.lddk = lddk; a.dV = dV; a.lddv = lddv; a.B = B; a.H = H; a.N = N; a.Nkv = Nkv; a.DH = dh; a.scale = scale;
   a.q_prescaled = (flags & CL_ATTN_Q_PRESCALED) ? 1 : 0;
+  a.row_ws = row_ws;
   return attn_bwd_tr(a, S(stream));
 }
 

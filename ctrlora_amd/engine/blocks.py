@@ -490,8 +490,11 @@ class AttnE:
                 dk = ctx.new(B * Nkv, inner) if want_kv else None
                 dv = ctx.new(B * Nkv, inner) if want_kv else None
         if ctx.dtype == torch.bfloat16:
+            pre = self._prescaled(ctx)
+            # (-lse, -delta) of every query row as bf16 triples: lets the d_head-40 kernels fold them into their products
+            row_ws = torch.empty(lse.numel() * 8, dtype=torch.float32, device=ctx.device) if (pre and self.dh == 40) else None
             hip.attention_bwd_v2(q, k, v, a, da, lse, delta, dq, dk, dv, B, H, N, Nkv, self.dh, self.scale,
-                                 q_prescaled=self._prescaled(ctx))
+                                 q_prescaled=pre, row_ws=row_ws)
         else:
             npad, kpad = rup(N, 64), rup(Nkv, 64)
             qt = torch.empty((B, inner, npad), dtype=ctx.dtype, device=ctx.device)

@@ -85,7 +85,7 @@ _SIGS = {
                          _P, _L, _I, _I, _I, _I, _I, _F, _P],
     "cl_attention_fwd_v2": [_I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "cl_attention_bwd_v2": [_I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _I, _P, _L, _P, _L, _P, _L,
-                            _I, _I, _I, _I, _I, _F, _I, _P],
+                            _I, _I, _I, _I, _I, _F, _I, _P, _P],
     "cl_geglu_fwd": [_I, _P, _L, _P, _L, _L, _I, _P],
     "cl_geglu_bwd": [_I, _P, _L, _P, _L, _P, _L, _L, _I, _P],
     "cl_silu_fwd": [_I, _P, _P, _L, _P],
@@ -393,11 +393,13 @@ def attention_fwd_v2(q, k, v, o, lse, B, H, N, Nkv, dh, scale, q_prescaled=False
     return o
 
 
-def attention_bwd_v2(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, N, Nkv, dh, scale, q_prescaled=False):
+def attention_bwd_v2(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, N, Nkv, dh, scale, q_prescaled=False, row_ws=None):
+    """row_ws: optional uint8 / any tensor of >= B * H * lse.shape[-1] * 32 bytes (see cl_attention_bwd_v2)."""
+    assert row_ws is None or row_ws.numel() * row_ws.element_size() >= B * H * lse.shape[-1] * 32
     _chk(lib().cl_attention_bwd_v2(dt(q), q.data_ptr(), ld(q), k.data_ptr(), ld(k), v.data_ptr(), ld(v), o.data_ptr(),
                                    ld(o), do.data_ptr(), ld(do), lse.data_ptr(), delta.data_ptr(), lse.shape[-1],
                                    dq.data_ptr(), ld(dq), ptr(dk), ld(dk), ptr(dv), ld(dv), B, H, N, Nkv, dh, scale,
-                                   ATTN_Q_PRESCALED if q_prescaled else 0, stream()), "cl_attention_bwd_v2")
+                                   ATTN_Q_PRESCALED if q_prescaled else 0, ptr(row_ws), stream()), "cl_attention_bwd_v2")
 
 
 # ------------------------------------------------------------------ elementwise / layout

@@ -220,7 +220,11 @@ int cl_attention_fwd_v2(int dtype, const void* Q, long ldq, const void* K, long 
 int cl_attention_bwd_v2(int dtype, const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv,
                         const void* O, long ldo, const void* dO, long lddo, const float* LSE, float* Delta,
                         int lse_stride, void* dQ, long lddq, void* dK, long lddk, void* dV, long lddv,
-                        int B, int H, int N, int Nkv, int dh, float scale, int flags, void* stream);
+                        int B, int H, int N, int Nkv, int dh, float scale, int flags, void* row_ws, void* stream);
+/* row_ws (ABI 6; may be NULL): scratch of B * H * lse_stride * 32 bytes, 16-byte aligned.  With CL_ATTN_Q_PRESCALED and
+ * d_head 40 the backward kernels keep (-lse, -delta) of every query row there as bf16 triples and feed them through spare
+ * contraction slots of the matrix products, which then deliver s - lse and dP - delta (attention.py:171-192's backward with
+ * 3 instead of 5 vector instructions per score pair).  Results are the same with or without it. */
 
 /* ---- elementwise / layout ------------------------------------------------------------ */
 int cl_geglu_fwd(int dtype, const void* h, long ldh, void* out, long ldo, long M, int F, void* stream); /* attention.py:55-56 */

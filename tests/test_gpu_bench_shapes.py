@@ -302,7 +302,8 @@ def _attention_case(dh, N, Nkv, B, prescaled, spike=False, variant=0, q_std=1.0)
     assert hip.lib().cl_debug_attention_variant(variant) == 0
     try:
         hip.attention_fwd_v2(q, k, v, o, lse, B, Hh, N, Nkv, dh, scale, q_prescaled=prescaled)
-        hip.attention_bwd_v2(q, k, v, o, do, lse, delta, dq, dk, dv, B, Hh, N, Nkv, dh, scale, q_prescaled=prescaled)
+        row_ws = torch.empty(lse.numel() * 8, dtype=torch.float32, device="cuda") if prescaled else None   # as the engine does
+        hip.attention_bwd_v2(q, k, v, o, do, lse, delta, dq, dk, dv, B, Hh, N, Nkv, dh, scale, q_prescaled=prescaled, row_ws=row_ws)
         torch.cuda.synchronize()
     finally:
         hip.lib().cl_debug_attention_variant(0)

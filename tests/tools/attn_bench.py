@@ -98,8 +98,9 @@ def case(dh, N, Nkv, B, variants, bwd, check=True, rounds=1, spike=False):
         assert L.cl_debug_attention_variant(var) == 0, f"unknown attention variant {var}"
 
     fwd = lambda pre: hip.attention_fwd_v2(q_pre if pre else q_plain, k, v, o, lse, B, H, N, Nkv, dh, scale, q_prescaled=pre)
+    row_ws = torch.empty(lse.numel() * 8, dtype=torch.float32, device="cuda")     # (-lse, -delta) triples: the engine passes it too
     bw = lambda pre: hip.attention_bwd_v2(q_pre if pre else q_plain, k, v, o, do, lse, delta, dq, dk, dv, B, H, N, Nkv, dh, scale,
-                                          q_prescaled=pre)
+                                          q_prescaled=pre, row_ws=row_ws if pre else None)
     runs = {}
     for name, var, pre in variants:
         select(var)
