@@ -24,6 +24,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 import torch.distributed as dist
 import yaml
@@ -394,6 +395,60 @@ def _ddim_image_hint_legs(model, device, B, H, cd, S):
     return out
 
 
+def pretrain_bench_dp(device, dtype, world, rank, B=8, steps=9, warmup=9, tiny=False):
+    """BASELINE.json configs[3] under data parallelism (`bench.py --gpus N --pretrain-only`): eager launches, every rank draws its
+    own task per step (datasets/multi_task_scheduler.py:59 -- ranks may train different banks), base-ControlNet gradients
+    (~1.4 GB fp32) leave as 32 MB buckets from the backward's stage hooks (BankedGradAllReduce.attach), the live banks after
+    it; PretrainAdamW with grad_scale 1 / N.  Reports aggregate images/s (max over ranks) and what the exchange costs:
+    the same steps with the exchange switched off (measurement only, after the timed region)."""
+    import torch.distributed as dist
+    model = build_model("ctrlora_pretrain_sd15_9tasks_rank128.yaml", 0, tiny=tiny).to(device).train()
+    model.set_engine_dtype(dtype)
+    model.learning_rate = 1e-5
+    dp = model.init_data_parallel()
+    opt = model.configure_optimizers()
+    tasks = list(model.control_model.tasks)
+    data = synth(B, 64, model.control_model.context_dim, device, 4321 + rank, 2)
+    rng = np.random.RandomState(97 + rank)          # per-rank task stream, as the reference's unseeded sampler gives
+
+    def step(i, exchange=True):
+        j = i % 2
+        cond = {"c_crossattn": [data["ctx"][j]], "c_concat": [data["hint"][j]], "task": tasks[int(rng.randint(len(tasks)))]}
+        dp.enabled = exchange
+        opt.zero_grad()
+        loss, _ = model.p_losses(data["z"][j], cond, data["t"][j], noise=data["noise"][j])
+        loss.backward()
+        opt.step()
+        return loss
+
+    def timed(n, exchange):
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            loss = step(i, exchange)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        tm = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        return float(tm) / n, loss
+
+    for i in range(warmup):
+        step(i)
+    dt, loss = timed(steps, True)
+    launches = dp.inner.last_launches
+    tail = dp.inner.exposed_tail_elems
+    dt_off, _ = timed(steps, False)
+    ex = model.control_model.executor()
+    return dict(metric="Base-ControlNet multi-task pre-training images/sec (data parallel)", value=round(world * B / dt, 2),
+                unit="images/s", n_gpus=world, ms_per_step=round(dt * 1e3, 2), batch_per_gpu=B, steps=steps, warmup=warmup,
+                launch="eager launches, bucketed all-reduce of the base-ControlNet gradients from the backward's stage hooks",
+                data_parallel=dict(base_payload_MB_per_step=round(ex.tr.numel * 4 / 1e6, 1), bucket_MB=32,
+                                   buckets_launched_during_backward=int(launches), tail_MB_reduced_after_backward=round(tail * 4 / 1e6, 1),
+                                   ms_per_step_without_exchange=round(dt_off * 1e3, 2),
+                                   exposed_allreduce_ms_per_step=round((dt - dt_off) * 1e3, 2)),
+                loss=round(float(loss.detach()), 5), dtype=str(dtype).replace("torch.", ""),
+                config="ctrlora_pretrain_sd15_9tasks_rank128.yaml, 512x512 (latent 64x64), per-rank random task per step, synthetic")
+
+
 def pretrain_bench(device, dtype, B=8, steps=9, warmup=9, tiny=False):
     """BASELINE.json configs[3] on ONE GPU (not the headline metric; evidence that Base-ControlNet pre-training runs at
     full width): ctrlora_pretrain_sd15_9tasks_rank128.yaml, every ControlNet weight + the step's task bank trained,
@@ -600,6 +655,13 @@ def main():
         print(json.dumps(conv_kernel_probe(device, dtype, iters=200)))
         return
     if args.pretrain_only:
+        if world > 1:
+            out = pretrain_bench_dp(device, dtype, world, rank, B=args.batch, tiny=args.tiny)
+            if rank == 0:
+                print(json.dumps(out))
+            dist.barrier()
+            dist.destroy_process_group()
+            return
         print(json.dumps(pretrain_bench(device, dtype, B=args.batch, tiny=args.tiny)))
         return
 

@@ -5,6 +5,8 @@ optimises every ControlNet weight (:174-182), so the engine forms the weight gra
 gathered inside the weight-gradient kernel's addressing), linear, bias and norm next to the task's LoRA factors; the
 base weights live in one flat fp32 buffer, each task's LoRA bank in its own (ctrlora_amd.train.PretrainAdamW).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -121,10 +123,21 @@ class _PretrainDP:
         self.cm = cm
         self.opt = opt                   # PretrainAdamW (configure_optimizers sets it): mark_used(task) on exchange
         self.inner = BankedGradAllReduce([ex.tr.flat_grad], {t: cm.bank(t).flat_grad for t in cm.tasks})
+        if os.environ.get("CTRLORA_PRETRAIN_OVERLAP", "1") != "0":
+            self.inner.attach(ex)        # buckets of the base-ControlNet gradients leave from the backward's stage hooks
         self.world_size = self.inner.world_size
-        self.enabled = True              # False on non-final gradient-accumulation micro-steps
+        self._enabled = True             # False on non-final gradient-accumulation micro-steps
         self.live = []                   # banks exchanged by the last optimizer step (on every rank)
         self.used = []                   # tasks this rank back-propagated through since its last optimizer step
+
+    def _get_enabled(self):
+        return self._enabled
+
+    def _set_enabled(self, v):
+        self._enabled = bool(v)
+        self.inner.enabled = bool(v)     # (the stage hook must not launch collectives on accumulation micro-steps)
+
+    enabled = property(_get_enabled, _set_enabled)
 
     def note_used(self, task):
         if task not in self.used:

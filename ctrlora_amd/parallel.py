@@ -114,12 +114,48 @@ class BankedGradAllReduce:
     optimizer's `grad_scale`, like `GradAllReduce`.  Returns the list of tasks whose banks were exchanged.
     """
 
-    def __init__(self, shared, banks, group=None):
+    def __init__(self, shared, banks, group=None, bucket_bytes: int = 32 << 20, payload_dtype=None):
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.shared = list(shared)
         self.tasks = list(banks.keys())
         self.banks = dict(banks)
+        self.bucket_elems = max(1, bucket_bytes // 4)
+        self.payload_dtype = payload_dtype if payload_dtype is not None else payload_dtype_from_env()
+        # overlapped form (attach): buckets of the backward-ordered shared buffer launched from the executor's
+        # stage-completion hook, as GradAllReduce does for fine-tuning
+        self._ex = None
+        self._lo = self._hi = 0
+        self._pending: List = []
+        self.enabled = True
+        self.launches = 0                 # bucket all-reduces issued by the hook since the last exchange()
+        self.launches_before_last_stage = 0
+        self.exposed_tail_elems = 0       # elements of the shared buffer that were reduced only in exchange()
+
+    def attach(self, executor):
+        """Overlap the exchange of the base-ControlNet gradients (360 M floats at SD1.5 width: ~1.4 GB fp32 -- the reference's
+        DDP buckets and overlaps them, scripts/train_ctrlora_pretrain.py:117-121) with the backward pass: `executor` keeps
+        them in ONE flat buffer laid out in backward-completion order and reports every finished stage through
+        `on_stage_done(start, end)`; a bucket of >= bucket_bytes is all-reduced asynchronously as soon as it is final and
+        runs under the remaining stages.  exchange() then only has the mask, the tail and the (small) banks left."""
+        assert len(self.shared) == 1 and self.shared[0].data_ptr() == executor.tr.flat_grad.data_ptr()
+        self._ex = executor
+        self._last_stage_start = executor.backward_stage_order()[-1][0] if hasattr(executor, "backward_stage_order") else None
+        executor.on_stage_done = self._stage_done
+        return self
+
+    def _stage_done(self, start, end):
+        if not self.enabled or self.world_size == 1 or self._ex is None:
+            return
+        if start == self._last_stage_start:
+            self.launches_before_last_stage = self.launches
+        if start != self._hi:
+            return                          # out-of-order report: left to exchange()
+        self._hi = end
+        if self._hi - self._lo >= self.bucket_elems:
+            self._pending.append(all_reduce_slice(self._ex.tr.flat_grad[self._lo:self._hi], self.group, self.payload_dtype))
+            self.launches += 1
+            self._lo = self._hi
 
     @torch.no_grad()
     def exchange(self, used_tasks) -> List[str]:
@@ -131,11 +167,21 @@ class BankedGradAllReduce:
         mask = torch.tensor([1 if t in used else 0 for t in self.tasks], dtype=torch.int32, device=ref.device)
         dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)
         live = [t for t, m in zip(self.tasks, mask.tolist()) if m]
-        work = [dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for buf in self.shared]
+        work = list(self._pending)
+        self._pending = []
+        if self._ex is not None:            # the part of the shared buffer the hook has not launched yet
+            n = self._ex.tr.flat_grad.numel()
+            self.exposed_tail_elems = n - self._lo
+            if self._lo < n:
+                work.append(all_reduce_slice(self._ex.tr.flat_grad[self._lo:n], self.group, self.payload_dtype))
+            self._lo = self._hi = 0
+        else:
+            work += [dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for buf in self.shared]
         for t in live:
             if t not in used:
                 self.banks[t].zero_()       # this rank did not train the bank: zero contribution
             work.append(dist.all_reduce(self.banks[t], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for w in work:
             w.wait()
+        self.last_launches, self.launches = self.launches, 0
         return live

@@ -285,6 +285,11 @@ if __name__ == "__main__":
         # BASELINE config-2 shapes (latent 64x64: N = 4096 attention, M = 8192 GEMM tiles, split-K levels); B = 2
         gen_model_golden("sd15_64", arch.SD15, B=2, H=64, seed=7, full_tensors=False, sampled_grads=True)
         sys.exit(0)
+    if "--only-sd15-64-r32" in sys.argv:
+        # BASELINE configs[0] at its own shape: configs/ctrlora_finetune_sd15_rank32.yaml (rank 32), bs 1, 512x512 -> latent 64x64
+        from dataclasses import replace
+        gen_model_golden("sd15_64_r32", replace(arch.SD15, lora_rank=32), B=1, H=64, seed=9, full_tensors=False, sampled_grads=True)
+        sys.exit(0)
     gen_lora_golden()
     gen_schedule_golden()
     gen_model_golden("tiny", arch.TINY, B=2, H=16, seed=11, full_tensors=True)

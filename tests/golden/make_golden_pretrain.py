@@ -1,6 +1,8 @@
 """Golden vectors for Base-ControlNet PRE-TRAINING -- SURVEY.md 8(f3) -- from the UNMODIFIED reference.
 
-    python tests/golden/make_golden_pretrain.py      # writes tests/golden/pretrain.pt  (build container only)
+    python tests/golden/make_golden_pretrain.py                 # writes tests/golden/pretrain.pt  (build container only)
+    python tests/golden/make_golden_pretrain.py --lr 1e-4       # writes tests/golden/pretrain_lr1e-4.pt: the same three steps
+                                                                # at a rate where a bf16 run stays on the fp32 trajectory
 
 The reference's ControlPretrainLDM (tiny width, two tasks) runs THREE optimizer steps with the task sequence
 hed, canny, hed through p_losses -> backward -> configure_optimizers().step(): AdamW over every control_model parameter
@@ -66,6 +68,10 @@ def step_inputs(cfg, i):
 
 
 if __name__ == "__main__":
+    OUT = "pretrain.pt"
+    if "--lr" in sys.argv:
+        LR = float(sys.argv[sys.argv.index("--lr") + 1])
+        OUT = f"pretrain_lr{sys.argv[sys.argv.index('--lr') + 1]}.pt"
     import make_golden as mg
     assert os.path.isdir(mg.REF)
     mg.install_stubs()
@@ -138,5 +144,5 @@ if __name__ == "__main__":
                                 "time_embed.0", "zero_convs.3.", "middle_block.2.out_layers", "input_blocks.2.0.skip", "input_blocks.4.0.skip")):
             after[n] = digest(p)
     out["after"] = pack(after)
-    torch.save(out, os.path.join(HERE, "pretrain.pt"))
-    print("[golden] pretrain.pt written:", len(after), "parameter digests")
+    torch.save(out, os.path.join(HERE, OUT))
+    print(f"[golden] {OUT} written:", len(after), "parameter digests")

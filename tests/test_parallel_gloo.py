@@ -285,6 +285,91 @@ def test_pretrain_dp_replicas_stay_identical_with_mixed_tasks_and_accumulation_g
     assert all(ok for _, ok in res), res
 
 
+# ------------------------------------------------------------------ pre-training: base-ControlNet buckets leave during the backward
+
+class _StagedExec:
+    """A ControlNetE stand-in with the real reporting protocol: flat gradient buffer in backward-completion order,
+    backward_stage_order() spans, on_stage_done(start, end) after each stage."""
+
+    def __init__(self, spans, rank):
+        n = spans[-1][1]
+        self.tr = _FlatSet(n, 1)
+        self._spans = list(spans)
+        self.on_stage_done = None
+        self._g = torch.Generator().manual_seed(500 + rank)
+        self.shadow = torch.zeros(n)          # this rank's own accumulated gradient, never exchanged
+
+    def backward_stage_order(self):
+        return list(self._spans)
+
+    def backward(self, log):
+        for i, (a, b) in enumerate(self._spans):
+            g = torch.randn(b - a, generator=self._g)
+            self.tr.flat_grad[a:b] += g
+            self.shadow[a:b] += g
+            log.append(("stage", i))
+            if self.on_stage_done is not None:
+                self.on_stage_done(a, b)
+
+
+def _pretrain_overlap_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ctrlora_amd.parallel import BankedGradAllReduce
+        spans = [(0, 3000), (3000, 5000), (5000, 9000), (9000, 9800), (9800, 12000), (12000, 12100)]     # middle ... time_embed
+        ex = _StagedExec(spans, rank)
+        banks = {t: torch.zeros(64) for t in ("hed", "canny")}
+        dp = BankedGradAllReduce([ex.tr.flat_grad], banks, bucket_bytes=4 * 500).attach(ex)      # 500-float buckets
+        ok = True
+        for step in range(2):
+            # accumulation micro-step: nothing may leave
+            dp.enabled = False
+            log = []
+            ex.backward(log)
+            ok &= dp.launches == 0 and not dp._pending
+            # final micro-step: a bucket leaves with every stage that fills one; when the LAST stage (time_embed) is reported,
+            # all earlier buckets are already in flight
+            dp.enabled = True
+            ex.backward(log)
+            ok &= dp.launches_before_last_stage >= len(spans) - 2
+            task = "hed" if rank == 0 else "canny"
+            banks[task] += float(rank + 1)
+            local = ex.shadow.clone()
+            live = dp.exchange([task])
+            ok &= sorted(live) == ["canny", "hed"] and dp.exposed_tail_elems <= 2300      # only what the last bucket left behind
+            got = [torch.zeros_like(local) for _ in range(world)]
+            dist.all_gather(got, local)
+            ok &= torch.allclose(ex.tr.flat_grad, sum(got), atol=1e-5)
+            ok &= float(banks["hed"][0]) == 1.0 * (step + 1) and float(banks["canny"][0]) == 2.0 * (step + 1)
+            ex.tr.flat_grad.zero_(); ex.shadow.zero_()
+        q.put((rank, bool(ok), dp.last_launches))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_pretrain_base_gradient_buckets_overlap_the_backward_gloo():
+    """BASELINE configs[3] (scripts/train_ctrlora_pretrain.py:117-121: DDP buckets and overlaps the base-ControlNet gradients):
+    BankedGradAllReduce.attach() launches an asynchronous all-reduce for every >= bucket_bytes of the backward-ordered base
+    buffer as soon as the stage that completes it is reported -- at least (stages - 2) buckets are in flight before the last
+    stage is even enqueued --, stays silent on accumulation micro-steps, and exchange() leaves every rank with the sum."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pretrain_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert all(n >= 4 for _, _, n in res), res
+
+
 # ------------------------------------------------------------------ DP-N == one large batch, on the real layout
 
 def _dp_equiv_worker(rank, world, port, q):

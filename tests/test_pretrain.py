@@ -36,12 +36,20 @@ def _model(dtype):
     return m, cfg
 
 
-@pytest.mark.parametrize("dtype,tol_g,tol_p", [(torch.float32, 1e-3, 5e-3), (torch.bfloat16, 2.6e-1, 3e-1)])
-def test_pretraining_three_steps_two_tasks_vs_reference(dtype, tol_g, tol_p):
+# fp32 follows the reference at both learning rates.  bf16 runs FREE only at lr 1e-4: at the reference recipe's 1e-3 AdamW's first
+# updates (lr * sign(g) on 0.02-scale weights) separate a bf16 trajectory from the fp32 one within a step -- what is measured
+# from step 1 on is then parameter divergence (1.3e-1 .. 2.0e-1, chaotic), not kernel error; that case is gated where it can be:
+# test_gpu_parity_r3.py::test_pretraining_bf16_error_is_flat_on_the_fp32_parameter_trajectory pins the parameters to the fp32
+# trajectory at lr 1e-3 and requires a flat error.  At 1e-4 the trajectories stay together and every step is a kernel check.
+@pytest.mark.parametrize("dtype,fixture,tol_g,tol_p", [(torch.float32, "pretrain.pt", 1e-3, 5e-3),
+                                                         (torch.float32, "pretrain_lr1e-4.pt", 1e-3, 5e-3),
+                                                         (torch.bfloat16, "pretrain_lr1e-4.pt", 9e-2, 4e-2)])
+def test_pretraining_three_steps_two_tasks_vs_reference(dtype, fixture, tol_g, tol_p):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
-    from tests.golden.make_golden_pretrain import LR, SEQ, TASKS, digest, step_inputs, unpack
-    gold = torch.load(os.path.join(GOLDEN, "pretrain.pt"), weights_only=False)
+    from tests.golden.make_golden_pretrain import SEQ, TASKS, digest, step_inputs, unpack
+    gold = torch.load(os.path.join(GOLDEN, fixture), weights_only=False)
+    LR = gold["meta"]["lr"]
     m, cfg = _model(dtype)
     m.learning_rate = LR
     opt = m.configure_optimizers()
@@ -89,13 +97,8 @@ def test_pretraining_three_steps_two_tasks_vs_reference(dtype, tol_g, tol_p):
             worst.append((e, n))
         worst.sort(reverse=True)
         print(f"[pretrain {dtype} step {i} {task}] loss {float(loss):.6f} (ref {g['loss']:.6f}); worst grad errors {worst[:3]}")
-        # bf16: the first step measures the kernels (6e-2 at this d_head-8 width); from the second step on the two parameter
-        # trajectories have drifted apart (AdamW's first updates are lr * sign(g), lr = 1e-3 on 0.02-scale weights), which
-        # test_pretraining_bf16_error_is_flat_on_the_fp32_parameter_trajectory separates from kernel error: on the fp32
-        # trajectory the error stays at 5e-2.  Free-running it was measured at 1.3e-1 / 1.8e-1 .. 2.0e-1 (chaotic in the
-        # last digit of every bf16 rounding), hence the looser gate for steps 1, 2.
-        gate = tol_g if (dtype == torch.float32 or i > 0) else 8e-2
-        assert worst[0][0] < gate, worst[:5]
+        # (bf16 at this d_head-8 width: ~6e-2 per step, measured; the gate holds for EVERY step)
+        assert worst[0][0] < tol_g, worst[:5]
         opt.step()
     assert opt.active == ["hed", "canny"]
     ref = unpack(gold["after"])
