@@ -51,7 +51,6 @@ def test_rank32_sd15_latent64_bs1_forward_backward_vs_reference_golden(dtype):
     gs = gold["grad_sampled"]
     items = eng.controls[0].tr.items
     assert len(items) == 246 and set(t.name for t in items) == set(gs)
-    assert sum(t.master.numel() for t in items) == 17_881_600 or True          # (17.9 M optimizer parameters at rank 32)
     errs, norm_errs = [], []
     for t in items:
         g = gs[t.name]
@@ -68,8 +67,8 @@ def test_rank32_sd15_latent64_bs1_forward_backward_vs_reference_golden(dtype):
         assert errs[0][0] < 5e-4 and max(norm_errs) < 5e-4, errs[:5]
     else:
         assert e_eps < BF16_EPS and abs(loss - gold["loss"]) < 2e-2 * gold["loss"]
-        # batch 1: a gradient is a sum over 4096 tokens instead of 16384 -- the same bf16 noise per term, less averaging
-        assert errs[0][0] < 1.5 * BF16_GRAD_MAX and med < 1.3 * BF16_GRAD_MEDIAN and max(norm_errs) < 1.5 * BF16_GRAD_MAX, errs[:5]
+        # (measured: eps 9.9e-3, worst gradient 3.0e-2, median 1.2e-2: the bench-shape gates hold unchanged)
+        assert errs[0][0] < BF16_GRAD_MAX and med < BF16_GRAD_MEDIAN and max(norm_errs) < BF16_GRAD_MAX, errs[:5]
 
 
 def test_ddim_reuse_graph_is_dropped_when_scales_or_weights_change():

@@ -43,7 +43,7 @@ def _model(dtype):
 # trajectory at lr 1e-3 and requires a flat error.  At 1e-4 the trajectories stay together and every step is a kernel check.
 @pytest.mark.parametrize("dtype,fixture,tol_g,tol_p", [(torch.float32, "pretrain.pt", 1e-3, 5e-3),
                                                          (torch.float32, "pretrain_lr1e-4.pt", 1e-3, 5e-3),
-                                                         (torch.bfloat16, "pretrain_lr1e-4.pt", 9e-2, 4e-2)])
+                                                         (torch.bfloat16, "pretrain_lr1e-4.pt", 9e-2, 5e-3)])
 def test_pretraining_three_steps_two_tasks_vs_reference(dtype, fixture, tol_g, tol_p):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
@@ -97,7 +97,8 @@ def test_pretraining_three_steps_two_tasks_vs_reference(dtype, fixture, tol_g, t
             worst.append((e, n))
         worst.sort(reverse=True)
         print(f"[pretrain {dtype} step {i} {task}] loss {float(loss):.6f} (ref {g['loss']:.6f}); worst grad errors {worst[:3]}")
-        # (bf16 at this d_head-8 width: ~6e-2 per step, measured; the gate holds for EVERY step)
+        # (bf16 at this d_head-8 width, measured: 6.5e-2, 6.8e-2, 6.5e-2 -- flat; parameters after 3 steps 3.1e-3; the gate
+        # holds for EVERY step)
         assert worst[0][0] < tol_g, worst[:5]
         opt.step()
     assert opt.active == ["hed", "canny"]
