@@ -25,8 +25,9 @@ os.environ["CTRLORA_GEMM_TUNED"] = "0"
 import bench  # noqa: E402
 from ctrlora_amd import hip  # noqa: E402
 
-FL = (10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 31, 32)   # full-line (LDS-DMA, 128-byte K lines) configurations
+FL = (10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 31, 32, 33)   # full-line (LDS-DMA, 128-byte K lines) configurations
 W80 = (31, 32)                                           # 128 x 80 tiles (linear products, N % 80 == 0)
+W320 = (33,)                                             # 128 x 320 full-N tiles (linear products, N % 320 == 0)
 PERSIST = (25, 26, 27, 28, 29, 30)                      # persistent forms of 16 / 17 / 20 / 21 / 10 / 11 (linear only)
 W160 = (2, 5, 10, 12, 14, 16, 18, 20, 23, 25, 27, 29)   # 160-column tiles
 W128 = (1, 7, 11, 13, 15, 17, 19, 21, 22, 26, 28, 30)   # 128-column tiles
@@ -106,6 +107,8 @@ def candidates(key):
         if c in W160 and N % 160:
             continue
         if c in W80 and (N % 80 or mode != hip.LINEAR or M > 16384):
+            continue
+        if c in W320 and (N % 320 or mode != hip.LINEAR or M < 8192):
             continue
         if c in W128 and N % 128 and N % 160 == 0:
             continue                      # keep the tile width the heuristic would use for this N
