@@ -281,7 +281,7 @@ def vae_bench(device, dtype, B=8, iters=3):
     return dict(images=2 * B, ms=round(ms, 2), tflops=round(gf / ms, 1), mfma_frac=round(gf / ms / PEAK_BF16_TFLOPS, 4))
 
 
-def ddim_bench(device, dtype, B=16, S=50, tiny=False, loops=5, warm_loops=10):
+def ddim_bench(device, dtype, B=16, S=50, tiny=False, loops=5, warm_loops=10, extras=True):
     from cldm.ddim_hacked import DDIMSampler
     model = build_model("inference/ctrlora_sd15_rank128_1lora.yaml", 0, tiny=tiny).to(device).eval()
     model.set_engine_dtype(dtype)
@@ -313,24 +313,29 @@ def ddim_bench(device, dtype, B=16, S=50, tiny=False, loops=5, warm_loops=10):
     hits = getattr(sampler, "graph_hits", 0)
     # (a) ONE cold sample() call as rounds 1-2 timed it and as a one-shot user pays it: fresh sampler, eager first step,
     #     capture of the step graph, S - 2 replays
-    cold = DDIMSampler(model)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    cold.sample(S, B, (4, H, H), cond, verbose=False, eta=0.0, x_T=x_T, unconditional_guidance_scale=7.5,
-                unconditional_conditioning=unc)
-    torch.cuda.synchronize()
-    dt_cold = time.perf_counter() - t0
-    del cold
+    dt_cold = None
+    if extras:
+        cold = DDIMSampler(model)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cold.sample(S, B, (4, H, H), cond, verbose=False, eta=0.0, x_T=x_T, unconditional_guidance_scale=7.5,
+                    unconditional_conditioning=unc)
+        torch.cuda.synchronize()
+        dt_cold = time.perf_counter() - t0
+        del cold
     # (b) condition IMAGES instead of latents (what scripts/sample.py hands over): hoisted = the VAE encode once per call and
     #     the posterior re-sampled on the device in every apply_model; reference_faithful = the encoder inside every
     #     apply_model call as the reference runs it (4.44 TFLOP per image and step)
     image_leg = None
     try:
-        image_leg = ddim_image_hint_bench(model, device, dtype, B, H, cd, S=20 if not tiny else 4)
+        if extras:
+            image_leg = ddim_image_hint_bench(model, device, dtype, B, H, cd, S=20 if not tiny else 4)
     except Exception as e:      # the headline leg above stands on its own
         print(f"[bench] DDIM image-hint leg failed ({type(e).__name__}: {e})", file=sys.stderr)
-    return dict(cold=dict(steps_per_s=round(S / dt_cold, 3), note="one sample() call on a fresh sampler incl. the eager first step "
-                          "and the graph capture (the methodology of BENCH_r01/r02)"),
+    cold_leg = None if dt_cold is None else dict(
+        steps_per_s=round(S / dt_cold, 3), note="one sample() call on a fresh sampler incl. the eager first step and the graph "
+                                               "capture (the methodology of BENCH_r01/r02)")
+    return dict(cold=cold_leg,
                 image_hint=image_leg,
                 metric="DDIM denoise steps/s (CFG 7.5, both passes, all B images)", value=round(sps, 3), batch=B, S=S,
                 ms_per_step=round(dt / S * 1e3, 2), best=round(S / times[0], 3), loops=loops,
@@ -621,6 +626,7 @@ def main():
     ap.add_argument("--ddim-only", action="store_true", help="profiling aid: run only the DDIM leg")
     ap.add_argument("--ddim-loops", type=int, default=5, help="timed S = 50 loops of the DDIM leg")
     ap.add_argument("--ddim-warm", type=int, default=10, help="warm-up loops of the DDIM leg")
+    ap.add_argument("--ddim-core-only", action="store_true", help="profiling aid: skip the cold-call and image-hint DDIM legs")
     ap.add_argument("--force-split-graphs", action="store_true",
                     help="test aid: use the multi-rank structure (segment graphs with bucketed all-reduces in between, "
                          "then the AdamW graph) even with one rank")
@@ -649,7 +655,8 @@ def main():
         dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=900))
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     if args.ddim_only:
-        print(json.dumps(ddim_bench(device, dtype, tiny=args.tiny, loops=args.ddim_loops, warm_loops=args.ddim_warm)))
+        print(json.dumps(ddim_bench(device, dtype, tiny=args.tiny, loops=args.ddim_loops, warm_loops=args.ddim_warm,
+                                    extras=not args.ddim_core_only)))
         return
     if args.probe_only:
         print(json.dumps(conv_kernel_probe(device, dtype, iters=200)))
@@ -797,22 +804,19 @@ def main():
         if not args.tiny and args.dtype == "bf16":   # rank 0 only; no collective inside
             dk = conv_kernel_probe(device, dtype)
             fam = family_census(model, opt, data)
-            # contract fields describe the dominant kernel FAMILY (implicit-GEMM conv + linear kernels of
-            # csrc/gemm.hip), time-weighted over every shape of the step; its best single shape and the attention
-            # family stay alongside, as does the whole-step figure
+            # Contract fields = the DOMINANT KERNEL of the step (gemm_fl_kernel<256 x 160, conv-s1>: 14 % of the step's GPU time,
+            # profiles/r04_prof/train_kernel_stats_steady.txt) at its dominant shape, timed live with HIP events on the launching
+            # stream: the figure the rocprofv3 --stats row of the same launch has to agree with (profiles/r04_prof/
+            # dominant_kernel_stats.csv).  The time-weighted figure of the whole GEMM family, the attention and the HBM-bound
+            # families and the whole step stay alongside -- the whole-step fraction is the honest summary of the step.
+            roof.update(achieved=dk["achieved"], frac=dk["frac"], traffic=dk["traffic"], kernel=dk["kernel"],
+                        ms_per_launch=dk["ms"], algorithmic_bytes_per_launch=43_800_000,
+                        traffic_kind="rocprofv3 TCC passes on this launch, FETCH_SIZE (x2: gfx950 correction) + WRITE_SIZE, re-measured in "
+                                     "round 4 (profiles/dominant_kernel_traffic.json); static in this run")
             gf = fam.get("gemm")
             if gf:
-                roof.update(achieved=gf["achieved"], frac=gf["frac"], traffic=None,
-                            kernel="gemm_fl / gemm kernel family (implicit-GEMM 3x3 conv + linear + LoRA-fused linear), "
-                                   "time-weighted over all shapes of one step",
-                            family=gf)
-            # `traffic` (contract field): PMC-measured HBM bytes per launch of the family's dominant kernel (its best_shape entry)
-            roof["traffic"] = dk["traffic"]
-            roof["traffic_of"] = "best_shape launch (43.8 MB algorithmic per launch); see best_shape.traffic_kind"
-            roof["best_shape"] = dict(kernel=dk["kernel"], achieved=dk["achieved"], frac=dk["frac"], ms_per_launch=dk["ms"],
-                                      traffic=dk["traffic"],
-                                      traffic_kind="static: rocprofv3 TCC_EA passes on this launch (profiles/dominant_kernel_traffic.json), "
-                                                   "not re-measured in this run")
+                roof["family"] = dict(gf, kernel="gemm_fl / gemm kernel family (implicit-GEMM 3x3 conv + linear + LoRA-fused linear), "
+                                                 "time-weighted over all shapes of one step")
             if "attention" in fam:
                 roof["attention_family"] = fam["attention"]
             if "hbm" in fam:
