@@ -144,7 +144,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_tr_kernel(AttnFwdArgs p, cons
   for (int f = 0; f < QW; ++f) { m_run[f] = -1e30f; l_run[f] = 0.f; }   // finite: exp2(m_run - m_new) must not see inf - inf
 
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  const uint32_t krow = lq * ROWB + g * 16;                                    // b128: row lq, chunk g (+4 ks)
+  // b128: row lq, chunk 4 ks + g; a lane past the head dim re-reads the last data chunk against the zero slots of its Q
+  // fragment (+-0 added: bit-identical) instead of being masked off -- see the dK / dV kernel
+  uint32_t krow[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) krow[ks] = lq * ROWB + min(4 * ks + g, CPR - 1) * 16;
   const uint32_t troff = (4 * g + ((lane >> 2) & 3)) * ROWB + (lane & 3) * 8;  // transpose read: row 4g+j, cols 4q
   const int ntiles = (p.Nkv + 63) / 64;
   TileDma<DH> dma; dma.init(wave, lane);
@@ -167,12 +171,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_tr_kernel(AttnFwdArgs p, cons
     // (software-pipelining the LDS reads one fragment ahead was measured: no gain -- the kernel is VALU-bound
     // and the other resident waves already cover LDS latency -- and it cost an occupancy step in registers)
     f32x4_t st[4][QW];
+    uint32_t kr[KSTEPS];
 #pragma unroll
-    for (int kf = 0; kf < 4; ++kf) {
+    for (int ks = 0; ks < KSTEPS; ++ks) kr[ks] = kt + krow[ks];
+    static_for<0, 4>([&](auto KF_) {
+      constexpr int kf = decltype(KF_)::value;
       u32x4_t ka[KSTEPS];
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks)
-        ka[ks] = (4 * ks + g < CPR) ? lds_read_b128(kt + krow + kf * 16 * ROWB + ks * 64) : u32x4_t{0u, 0u, 0u, 0u};
+      for (int ks = 0; ks < KSTEPS; ++ks) ka[ks] = lds_read_b128_off<kf * 16 * ROWB>(kr[ks]);
       lds_wait();
 #pragma unroll
       for (int f = 0; f < QW; ++f) {
@@ -180,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_tr_kernel(AttnFwdArgs p, cons
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) Mma<bf16_t>::run(ka[ks], qf[f][ks], st[kf][f]);
       }
-    }
+    });
     // ---- online softmax: lane owns query lq of each q fragment; max on the raw scores, one fma + exp2 each
     const int kv0 = t * 64;
     {
@@ -222,17 +228,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_tr_kernel(AttnFwdArgs p, cons
         f32x4_t tmp[2] = {st[2 * s][f], st[2 * s + 1][f]};
         pb[s][f] = PFrag<bf16_t>::make(tmp);
       }
-#pragma unroll
-    for (int i = 0; i < DN; ++i) {
+    const uint32_t tb = vt + troff;
+    static_for<0, DN>([&](auto I_) {
+      constexpr int i = decltype(I_)::value;
       u32x4_t va[2];
-      va[0] = tr_frag<ROWB, 0>(vt + troff + i * 32);
-      va[1] = tr_frag<ROWB, 1>(vt + troff + i * 32);
+      va[0] = tr_frag_off<ROWB, 0, i * 32>(tb);
+      va[1] = tr_frag_off<ROWB, 1, i * 32>(tb);
       lds_wait();
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int f = 0; f < QW; ++f) Mma<bf16_t>::run(va[s], pb[s][f], ot[i][f]);
-    }
+    });
   }
 
   // ---- epilogue: normalise, store O rows, log-sum-exp
@@ -560,6 +567,7 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_tr_kerne
   constexpr int CPR = G::CPR, KSTEPS = G::KSTEPS, DN = G::DN, ROWB = G::ROWB, TILE = G::TILE, TI = G::TI;
   static_assert(!FOLD || (DH == 40 && !TAIL), "the fold uses the pad chunk of the 96-byte pitch, whole tiles only");
   constexpr int CIN = FOLD ? G::CPRP : CPR;    // chunks of a row that enter the S / dP contraction
+  constexpr bool PIPE = FOLD;                  // software-pipelined fragment reads (see the tile loop)
   constexpr int STAGE = 2 * TILE + 512;     // Q tile, dO tile, lse[64], delta[64]
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -619,94 +627,156 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_tr_kerne
   };
 
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  const uint32_t rrow = lq * ROWB + g * 16;
+  // Row-fragment addresses, one per 32-deep step.  A lane whose chunk 4 ks + g lies past the contraction (d_head 40: chunks 6, 7
+  // of the second step) reads the LAST contracted chunk again instead of being masked off: its B-operand slots (K / V
+  // fragments above) are exact zeros, so the duplicate contributes +-0 and the result is bit-identical -- and the reads need
+  // no exec masking, no zero-filled registers and no per-lane select (that was 36 v_mov + 10 branches per tile).
+  uint32_t rrow[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) rrow[ks] = lq * ROWB + min(4 * ks + g, CIN - 1) * 16;
   const uint32_t troff = (4 * g + ((lane >> 2) & 3)) * ROWB + (lane & 3) * 8;
   const int ntiles = (p.N + 63) / 64;
   if constexpr (!FOLD) {                    // (FOLD: the pad chunks arrive with the tile DMA)
     init_pads<DH>(smem, 2, 0u, 0u, tid, 256);
     init_pads<DH>(smem + STAGE, 2, 0u, 0u, tid, 256);
   }
+  // PIPE: tiles are requested TWO ahead into a ring of three stages, and the wait at the top of a tile counts this wave's
+  // own requests of the tile after it (loads retire in order), so a tile's DMA has two tile times to land instead of one --
+  // at ~0.9 us per tile one was not enough to cover an L2 / HBM round trip under load.  A stage is refilled at the top of
+  // tile t with tile t + 2: its last readers (tile t - 1) are behind the barrier every wave has just passed.
+  const int dma_per_tile = 2 * ((TI - wave + 3) / 4);      // this wave's DMA instructions per tile (Q + dO pieces)
   issue(0, 0);
+  if constexpr (PIPE) { if (ntiles > 1) issue(1, 1); }
+  int buf = 0;
   for (int t = 0; t < ntiles; ++t) {
-    const int buf = t & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (PIPE) {
+      if (t + 1 >= ntiles) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (dma_per_tile == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
-    if (t + 1 < ntiles) issue(t + 1, buf ^ 1);
     const uint32_t aQ = lds0 + buf * STAGE, adO = aQ + TILE, aL = adO + TILE;
     const int q0 = t * 64;
+    // PIPE (= FOLD): the row fragments of the NEXT query fragment and the column fragments of the NEXT d block are requested
+    // before the products of the current one are issued, and each wait counts only the requests that must have landed
+    // (lgkmcnt retires LDS reads in order).  The masked form below waits for lgkmcnt(0) seven times per tile with nothing
+    // of its own in flight: at two waves per SIMD that is seven exposed LDS round trips per wave and tile.
+    uint32_t rb[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) rb[ks] = aQ + rrow[ks];
+    const uint32_t tb = aQ + troff;
+    u32x4_t qa[2][KSTEPS], da[2][KSTEPS];
+    if constexpr (PIPE) {
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) { qa[0][ks] = lds_read_b128_off<0>(rb[ks]); da[0][ks] = lds_read_b128_off<TILE>(rb[ks]); }
+    }
+    if constexpr (PIPE) {
+      if (t + 2 < ntiles) issue(t + 2, buf == 0 ? 2 : buf - 1);
+    } else {
+      if (t + 1 < ntiles) issue(t + 1, buf ^ 1);
+    }
 
     // ---- S = Q K^T, dP = dO V^T  (rows = queries 16 qf + 4g + r, col = key lq)
+    // (every fragment offset below is an instruction immediate on three address registers: rb[ks], tb)
     f32x4_t ps[KF][4], ds[KF][4];
-    {
+    u32x4_t oa[2][2], qt[2][2];
+    static_for<0, 4>([&](auto QF_) {
+      constexpr int qf = decltype(QF_)::value;
+      constexpr int cur = PIPE ? (qf & 1) : 0;
+      u32x4_t l4 = {0u, 0u, 0u, 0u}, d4 = {0u, 0u, 0u, 0u};
+      if constexpr (PIPE) {
+        if constexpr (qf + 1 < 4) {
 #pragma unroll
-      for (int qf = 0; qf < 4; ++qf) {
-        u32x4_t qa[KSTEPS], da[KSTEPS];
+          for (int ks = 0; ks < KSTEPS; ++ks) {
+            qa[cur ^ 1][ks] = lds_read_b128_off<(qf + 1) * 16 * ROWB>(rb[ks]);
+            da[cur ^ 1][ks] = lds_read_b128_off<TILE + (qf + 1) * 16 * ROWB>(rb[ks]);
+          }
+          lgkm_wait<2 * KSTEPS>();
+        } else {           // last query fragment: the first d block's column fragments go out under its exp2 / pack work
+          oa[0][0] = tr_frag_off<ROWB, 0, TILE>(tb); oa[0][1] = tr_frag_off<ROWB, 1, TILE>(tb);
+          qt[0][0] = tr_frag_off<ROWB, 0, 0>(tb); qt[0][1] = tr_frag_off<ROWB, 1, 0>(tb);
+          lgkm_wait<8>();
+        }
+      } else {
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-          const bool in = 4 * ks + g < CIN;
-          qa[ks] = in ? lds_read_b128(aQ + rrow + qf * 16 * ROWB + ks * 64) : u32x4_t{0u, 0u, 0u, 0u};
-          da[ks] = in ? lds_read_b128(adO + rrow + qf * 16 * ROWB + ks * 64) : u32x4_t{0u, 0u, 0u, 0u};
+          qa[0][ks] = lds_read_b128_off<qf * 16 * ROWB>(rb[ks]);
+          da[0][ks] = lds_read_b128_off<TILE + qf * 16 * ROWB>(rb[ks]);
         }
-        u32x4_t l4 = {0u, 0u, 0u, 0u}, d4 = {0u, 0u, 0u, 0u};
         if constexpr (!FOLD) {
           l4 = lds_read_b128(aL + (qf * 16 + 4 * g) * 4);
           d4 = lds_read_b128(aL + 256 + (qf * 16 + 4 * g) * 4);
         }
         lds_wait();
-        const float lv[4] = {__uint_as_float(l4.x), __uint_as_float(l4.y), __uint_as_float(l4.z), __uint_as_float(l4.w)};
-        const float dv[4] = {__uint_as_float(d4.x), __uint_as_float(d4.y), __uint_as_float(d4.z), __uint_as_float(d4.w)};
-        const int qrow = q0 + qf * 16 + 4 * g;
+      }
+      const float lv[4] = {__uint_as_float(l4.x), __uint_as_float(l4.y), __uint_as_float(l4.z), __uint_as_float(l4.w)};
+      const float dv[4] = {__uint_as_float(d4.x), __uint_as_float(d4.y), __uint_as_float(d4.z), __uint_as_float(d4.w)};
+      const int qrow = q0 + qf * 16 + 4 * g;
 #pragma unroll
-        for (int kf = 0; kf < KF; ++kf) {
-          f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-          if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+      for (int kf = 0; kf < KF; ++kf) {
+        f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-          for (int ks = 0; ks < KSTEPS; ++ks) { Mma<bf16_t>::run(qa[ks], kb[kf][ks], sc); Mma<bf16_t>::run(da[ks], vb[kf][ks], dp); }
-          if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-          // P = exp2(s * sl2 - lse), dS = P (dP - delta); the d_head^-0.5 factor of dS is applied once to dK in the
-          // epilogue (linear).  Two rows per packed instruction.
+        for (int ks = 0; ks < KSTEPS; ++ks) { Mma<bf16_t>::run(qa[cur][ks], kb[kf][ks], sc); Mma<bf16_t>::run(da[cur][ks], vb[kf][ks], dp); }
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+        // P = exp2(s * sl2 - lse), dS = P (dP - delta); the d_head^-0.5 factor of dS is applied once to dK in the
+        // epilogue (linear).  Two rows per packed instruction.
 #pragma unroll
-          for (int h2 = 0; h2 < 2; ++h2) {
-            f32x2_t pr, dsv;
-            if constexpr (FOLD) {            // sc = s - lse, dp = dP - delta already
-              pr = f32x2_t{__builtin_amdgcn_exp2f(sc[2 * h2]), __builtin_amdgcn_exp2f(sc[2 * h2 + 1])};
-              dsv = pr * f32x2_t{dp[2 * h2], dp[2 * h2 + 1]};
-            } else {
-              const f32x2_t s2 = {sc[2 * h2], sc[2 * h2 + 1]}, l2 = {lv[2 * h2], lv[2 * h2 + 1]};
-              const f32x2_t x = s2 * sl2 - l2;
-              pr = f32x2_t{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
-              const f32x2_t dd = f32x2_t{dp[2 * h2], dp[2 * h2 + 1]} - f32x2_t{dv[2 * h2], dv[2 * h2 + 1]};
-              dsv = pr * dd;
-            }
-            if constexpr (TAIL) {   // lse / delta pads may hold NaN
-              if (qrow + 2 * h2 >= p.N) { pr.x = 0.f; dsv.x = 0.f; }
-              if (qrow + 2 * h2 + 1 >= p.N) { pr.y = 0.f; dsv.y = 0.f; }
-            }
-            ps[kf][qf][2 * h2] = pr.x; ps[kf][qf][2 * h2 + 1] = pr.y;
-            ds[kf][qf][2 * h2] = dsv.x; ds[kf][qf][2 * h2 + 1] = dsv.y;
+        for (int h2 = 0; h2 < 2; ++h2) {
+          f32x2_t pr, dsv;
+          if constexpr (FOLD) {            // sc = s - lse, dp = dP - delta already
+            pr = f32x2_t{__builtin_amdgcn_exp2f(sc[2 * h2]), __builtin_amdgcn_exp2f(sc[2 * h2 + 1])};
+            dsv = pr * f32x2_t{dp[2 * h2], dp[2 * h2 + 1]};
+          } else {
+            const f32x2_t s2 = {sc[2 * h2], sc[2 * h2 + 1]}, l2 = {lv[2 * h2], lv[2 * h2 + 1]};
+            const f32x2_t x = s2 * sl2 - l2;
+            pr = f32x2_t{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+            const f32x2_t dd = f32x2_t{dp[2 * h2], dp[2 * h2 + 1]} - f32x2_t{dv[2 * h2], dv[2 * h2 + 1]};
+            dsv = pr * dd;
           }
+          if constexpr (TAIL) {   // lse / delta pads may hold NaN
+            if (qrow + 2 * h2 >= p.N) { pr.x = 0.f; dsv.x = 0.f; }
+            if (qrow + 2 * h2 + 1 >= p.N) { pr.y = 0.f; dsv.y = 0.f; }
+          }
+          ps[kf][qf][2 * h2] = pr.x; ps[kf][qf][2 * h2 + 1] = pr.y;
+          ds[kf][qf][2 * h2] = dsv.x; ds[kf][qf][2 * h2 + 1] = dsv.y;
         }
       }
-    }
+    });
     // ---- dV^T += dO^T . P ;  dK^T += Q^T . dS   (A operands by transpose reads of the same tiles)
     u32x4_t pb[KF][2], sb[KF][2];
 #pragma unroll
     for (int kf = 0; kf < KF; ++kf)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) { pb[kf][s2] = PFrag<bf16_t>::make(&ps[kf][2 * s2]); sb[kf][s2] = PFrag<bf16_t>::make(&ds[kf][2 * s2]); }
-#pragma unroll
-    for (int i = 0; i < DN; ++i) {
-      u32x4_t oa[2], qt[2];
-      oa[0] = tr_frag<ROWB, 0>(adO + troff + i * 32); oa[1] = tr_frag<ROWB, 1>(adO + troff + i * 32);
-      qt[0] = tr_frag<ROWB, 0>(aQ + troff + i * 32); qt[1] = tr_frag<ROWB, 1>(aQ + troff + i * 32);
-      lds_wait();
+    static_for<0, DN>([&](auto I_) {
+      constexpr int i = decltype(I_)::value;
+      constexpr int cur = PIPE ? (i & 1) : 0;
+      if constexpr (PIPE) {
+        if constexpr (i + 1 < DN) {
+          // (lgkmcnt is a 4-bit counter: never more than 12 reads in flight)
+          oa[cur ^ 1][0] = tr_frag_off<ROWB, 0, TILE + (i + 1) * 32>(tb); oa[cur ^ 1][1] = tr_frag_off<ROWB, 1, TILE + (i + 1) * 32>(tb);
+          lgkm_wait<4>();
+          qt[cur ^ 1][0] = tr_frag_off<ROWB, 0, (i + 1) * 32>(tb); qt[cur ^ 1][1] = tr_frag_off<ROWB, 1, (i + 1) * 32>(tb);
+        } else {
+          lgkm_wait<0>();
+        }
+      } else {
+        oa[0][0] = tr_frag_off<ROWB, 0, TILE + i * 32>(tb); oa[0][1] = tr_frag_off<ROWB, 1, TILE + i * 32>(tb);
+        qt[0][0] = tr_frag_off<ROWB, 0, i * 32>(tb); qt[0][1] = tr_frag_off<ROWB, 1, i * 32>(tb);
+        lds_wait();
+      }
       if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kf = 0; kf < KF; ++kf)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) { Mma<bf16_t>::run(oa[s2], pb[kf][s2], dvt[kf][i]); Mma<bf16_t>::run(qt[s2], sb[kf][s2], dkt[kf][i]); }
+        for (int s2 = 0; s2 < 2; ++s2) { Mma<bf16_t>::run(oa[cur][s2], pb[kf][s2], dvt[kf][i]); Mma<bf16_t>::run(qt[cur][s2], sb[kf][s2], dkt[kf][i]); }
       if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-    }
+    });
+    if constexpr (PIPE) buf = buf == 2 ? 0 : buf + 1;
+    else buf ^= 1;
   }
   // ---- store dK / dV rows (4 consecutive d per lane)
 #pragma unroll
@@ -743,6 +813,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_tr_kernel(AttnBwdArgs p) {
   constexpr int CPR = G::CPR, KSTEPS = G::KSTEPS, DN = G::DN, ROWB = G::ROWB, TILE = G::TILE;
   static_assert(!FOLD || (DH == 40 && !TAIL && DELTA), "fold: d_head 40, whole key tiles, fused delta");
   constexpr int CIN = FOLD ? G::CPRP : CPR;
+  constexpr bool PIPE = FOLD;
   constexpr int STAGE = 2 * TILE;           // K tile, V tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -816,86 +887,135 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_tr_kernel(AttnBwdArgs p) {
     for (int i = 0; i < DN; ++i) dqt[f][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  const uint32_t rrow = lq * ROWB + g * 16;
+  uint32_t rrow[KSTEPS];     // as in the dK / dV kernel: lanes past the contraction re-read its last chunk against zero B slots
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) rrow[ks] = lq * ROWB + min(4 * ks + g, CIN - 1) * 16;
   const uint32_t troff = (4 * g + ((lane >> 2) & 3)) * ROWB + (lane & 3) * 8;
   const int ntiles = (p.Nkv + 63) / 64;
   TileDma<DH> dma; dma.init(wave, lane);
   int koff[TileDma<DH>::NJ], voff[TileDma<DH>::NJ];
   dma.offsets(p.ldk * 2, koff); dma.offsets(p.ldv * 2, voff);
-  if constexpr (FOLD) init_pads_ones3<DH>(smem, 4, tid, 256);      // K / V columns 40..42 = 1.0
+  if constexpr (FOLD) init_pads_ones3<DH>(smem, 6, tid, 256);      // K / V columns 40..42 = 1.0 (three stages, see PIPE below)
   else init_pads<DH>(smem, 4, 0u, 0u, tid, 256);
-  dma.issue(kbase, p.ldk * 2, koff, 0, p.Nkv, smem, wave);
-  dma.issue(vbase, p.ldv * 2, voff, 0, p.Nkv, smem + TILE, wave);
+  // PIPE: K / V tiles requested two ahead into three stages, counted vmcnt -- as in the dK / dV kernel.  (The row_ws / delta
+  // stores above may still be in flight at the first wait: they only make it wait longer, never shorter -- loads retire
+  // in order among themselves, and `count <= my requests of the next tile` implies the current tile's have all landed.)
+  constexpr int TI = G::TI;
+  const int dma_per_tile = 2 * ((TI - wave + 3) / 4);
+  auto issue_kv = [&](int t, int st_) {
+    dma.issue(kbase, p.ldk * 2, koff, t * 64, p.Nkv, smem + st_ * STAGE, wave);
+    dma.issue(vbase, p.ldv * 2, voff, t * 64, p.Nkv, smem + st_ * STAGE + TILE, wave);
+  };
+  issue_kv(0, 0);
+  if constexpr (PIPE) { if (ntiles > 1) issue_kv(1, 1); }
+  int buf = 0;
   for (int t = 0; t < ntiles; ++t) {
-    const int buf = t & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t + 1 < ntiles) {
-      dma.issue(kbase, p.ldk * 2, koff, (t + 1) * 64, p.Nkv, smem + (buf ^ 1) * STAGE, wave);
-      dma.issue(vbase, p.ldv * 2, voff, (t + 1) * 64, p.Nkv, smem + (buf ^ 1) * STAGE + TILE, wave);
+    if constexpr (PIPE) {
+      if (t + 1 >= ntiles) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (dma_per_tile == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    __syncthreads();
     const uint32_t aK = lds0 + buf * STAGE, aV = aK + TILE;
     const int kv0 = t * 64;
+    uint32_t rb[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) rb[ks] = aK + rrow[ks];
+    const uint32_t tb = aK + troff;
+    u32x4_t ka[2][KSTEPS], va[2][KSTEPS], kc[2][2];
+    if constexpr (PIPE) {        // software-pipelined fragment reads, as in the dK / dV kernel
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) { ka[0][ks] = lds_read_b128_off<0>(rb[ks]); va[0][ks] = lds_read_b128_off<TILE>(rb[ks]); }
+    }
+    if constexpr (PIPE) {
+      if (t + 2 < ntiles) issue_kv(t + 2, buf == 0 ? 2 : buf - 1);
+    } else {
+      if (t + 1 < ntiles) issue_kv(t + 1, buf ^ 1);
+    }
 
     // ---- S^T = K Q^T, dP^T = V dO^T  (rows = keys 16 kf + 4g + r, col = query lq)
     f32x4_t dst[QF][4];
-    {
+    static_for<0, 4>([&](auto KF_) {
+      constexpr int kf = decltype(KF_)::value;
+      constexpr int cur = PIPE ? (kf & 1) : 0;
+      if constexpr (PIPE) {
+        if constexpr (kf + 1 < 4) {
 #pragma unroll
-      for (int kf = 0; kf < 4; ++kf) {
-        u32x4_t ka[KSTEPS], va[KSTEPS];
+          for (int ks = 0; ks < KSTEPS; ++ks) {
+            ka[cur ^ 1][ks] = lds_read_b128_off<(kf + 1) * 16 * ROWB>(rb[ks]);
+            va[cur ^ 1][ks] = lds_read_b128_off<TILE + (kf + 1) * 16 * ROWB>(rb[ks]);
+          }
+          lgkm_wait<2 * KSTEPS>();
+        } else {
+          kc[0][0] = tr_frag_off<ROWB, 0, 0>(tb); kc[0][1] = tr_frag_off<ROWB, 1, 0>(tb);
+          lgkm_wait<4>();
+        }
+      } else {
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-          const bool in = 4 * ks + g < CIN;
-          ka[ks] = in ? lds_read_b128(aK + rrow + kf * 16 * ROWB + ks * 64) : u32x4_t{0u, 0u, 0u, 0u};
-          va[ks] = in ? lds_read_b128(aV + rrow + kf * 16 * ROWB + ks * 64) : u32x4_t{0u, 0u, 0u, 0u};
+          ka[0][ks] = lds_read_b128_off<kf * 16 * ROWB>(rb[ks]);
+          va[0][ks] = lds_read_b128_off<TILE + kf * 16 * ROWB>(rb[ks]);
         }
         lds_wait();
+      }
 #pragma unroll
-        for (int f = 0; f < QF; ++f) {
-          f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-          if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+      for (int f = 0; f < QF; ++f) {
+        f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-          for (int ks = 0; ks < KSTEPS; ++ks) { Mma<bf16_t>::run(ka[ks], qb[f][ks], sc); Mma<bf16_t>::run(va[ks], ob[f][ks], dp); }
-          if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-          // dS^T = P (dP - delta), two keys per packed instruction; d_head^-0.5 goes onto dQ in the epilogue
+        for (int ks = 0; ks < KSTEPS; ++ks) { Mma<bf16_t>::run(ka[cur][ks], qb[f][ks], sc); Mma<bf16_t>::run(va[cur][ks], ob[f][ks], dp); }
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+        // dS^T = P (dP - delta), two keys per packed instruction; d_head^-0.5 goes onto dQ in the epilogue
 #pragma unroll
-          for (int h2 = 0; h2 < 2; ++h2) {
-            f32x2_t dsv;
-            if constexpr (FOLD) {            // sc = s - lse, dp = dP - delta already
-              const f32x2_t pr = {__builtin_amdgcn_exp2f(sc[2 * h2]), __builtin_amdgcn_exp2f(sc[2 * h2 + 1])};
-              dsv = pr * f32x2_t{dp[2 * h2], dp[2 * h2 + 1]};
-            } else {
-              const f32x2_t x = f32x2_t{sc[2 * h2], sc[2 * h2 + 1]} * sl2 - lse_q[f];
-              const f32x2_t pr = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
-              dsv = pr * (f32x2_t{dp[2 * h2], dp[2 * h2 + 1]} - dlt_q[f]);
-            }
-            if constexpr (TAIL) {
-              if (kv0 + kf * 16 + 4 * g + 2 * h2 >= p.Nkv) dsv.x = 0.f;
-              if (kv0 + kf * 16 + 4 * g + 2 * h2 + 1 >= p.Nkv) dsv.y = 0.f;
-            }
-            dst[f][kf][2 * h2] = dsv.x; dst[f][kf][2 * h2 + 1] = dsv.y;
+        for (int h2 = 0; h2 < 2; ++h2) {
+          f32x2_t dsv;
+          if constexpr (FOLD) {            // sc = s - lse, dp = dP - delta already
+            const f32x2_t pr = {__builtin_amdgcn_exp2f(sc[2 * h2]), __builtin_amdgcn_exp2f(sc[2 * h2 + 1])};
+            dsv = pr * f32x2_t{dp[2 * h2], dp[2 * h2 + 1]};
+          } else {
+            const f32x2_t x = f32x2_t{sc[2 * h2], sc[2 * h2 + 1]} * sl2 - lse_q[f];
+            const f32x2_t pr = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+            dsv = pr * (f32x2_t{dp[2 * h2], dp[2 * h2 + 1]} - dlt_q[f]);
           }
+          if constexpr (TAIL) {
+            if (kv0 + kf * 16 + 4 * g + 2 * h2 >= p.Nkv) dsv.x = 0.f;
+            if (kv0 + kf * 16 + 4 * g + 2 * h2 + 1 >= p.Nkv) dsv.y = 0.f;
+          }
+          dst[f][kf][2 * h2] = dsv.x; dst[f][kf][2 * h2 + 1] = dsv.y;
         }
       }
-    }
+    });
     // ---- dQ^T += K^T . dS^T   (A = K^T by transpose reads of the K tile)
     u32x4_t sb[QF][2];
 #pragma unroll
     for (int f = 0; f < QF; ++f)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) sb[f][s2] = PFrag<bf16_t>::make(&dst[f][2 * s2]);
-#pragma unroll
-    for (int i = 0; i < DN; ++i) {
-      u32x4_t kc[2];
-      kc[0] = tr_frag<ROWB, 0>(aK + troff + i * 32); kc[1] = tr_frag<ROWB, 1>(aK + troff + i * 32);
-      lds_wait();
+    static_for<0, DN>([&](auto I_) {
+      constexpr int i = decltype(I_)::value;
+      constexpr int cur = PIPE ? (i & 1) : 0;
+      if constexpr (PIPE) {
+        if constexpr (i + 1 < DN) {
+          kc[cur ^ 1][0] = tr_frag_off<ROWB, 0, (i + 1) * 32>(tb); kc[cur ^ 1][1] = tr_frag_off<ROWB, 1, (i + 1) * 32>(tb);
+          lgkm_wait<4>();
+        } else {
+          lgkm_wait<0>();
+        }
+      } else {
+        kc[0][0] = tr_frag_off<ROWB, 0, i * 32>(tb); kc[0][1] = tr_frag_off<ROWB, 1, i * 32>(tb);
+        lds_wait();
+      }
       if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int f = 0; f < QF; ++f)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) Mma<bf16_t>::run(kc[s2], sb[f][s2], dqt[f][i]);
+        for (int s2 = 0; s2 < 2; ++s2) Mma<bf16_t>::run(kc[cur][s2], sb[f][s2], dqt[f][i]);
       if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-    }
+    });
+    if constexpr (PIPE) buf = buf == 2 ? 0 : buf + 1;
+    else buf ^= 1;
   }
 #pragma unroll
   for (int f = 0; f < QF; ++f) {
@@ -1009,6 +1129,8 @@ static int launch_bwd_tr(const AttnBwdArgs& a, hipStream_t st) {
   constexpr int KF = DH <= 40 ? 2 : 1;     // key / query fragments per wave (register budget: <= 256 VGPRs)
   constexpr int LDS_DKV = 2 * (2 * Geo<DH>::TILE + 512) + 64 + 16 * Geo<DH>::ROWB;
   constexpr int LDS_DQ = 2 * 2 * Geo<DH>::TILE + 64 + 16 * Geo<DH>::ROWB;
+  constexpr int LDS_DKV3 = 3 * (2 * Geo<DH>::TILE + 512) + 64 + 16 * Geo<DH>::ROWB;   // fold kernels: three-stage ring
+  constexpr int LDS_DQ3 = 3 * 2 * Geo<DH>::TILE + 64 + 16 * Geo<DH>::ROWB;
   static bool done = false;
   if (!done) {
     if (set_lds(&attn_bwd_dkv_tr_kernel<DH, KF, TQ>, LDS_DKV) || set_lds(&attn_bwd_dkv_tr_kernel<DH, 1, TQ>, LDS_DKV) ||
@@ -1032,14 +1154,14 @@ static int launch_bwd_tr(const AttnBwdArgs& a, hipStream_t st) {
         qb2 >= 512 && (!a.dK || kb2 >= 512)) {
       static bool done_f = false;
       if (!done_f) {
-        if (set_lds(&attn_bwd_dq_tr_kernel<DH, KF, TK, true, false, true>, LDS_DQ) ||
-            set_lds(&attn_bwd_dkv_tr_kernel<DH, KF, TQ, false, true>, LDS_DKV))
+        if (set_lds(&attn_bwd_dq_tr_kernel<DH, KF, TK, true, false, true>, LDS_DQ3) ||
+            set_lds(&attn_bwd_dkv_tr_kernel<DH, KF, TQ, false, true>, LDS_DKV3))
           return CL_ELAUNCH;
         done_f = true;
       }
-      hipLaunchKernelGGL((attn_bwd_dq_tr_kernel<DH, KF, TK, true, false, true>), dim3(a.N / 128, a.H, a.B), dim3(256), LDS_DQ, st, a);
+      hipLaunchKernelGGL((attn_bwd_dq_tr_kernel<DH, KF, TK, true, false, true>), dim3(a.N / 128, a.H, a.B), dim3(256), LDS_DQ3, st, a);
       if (a.dK)
-        hipLaunchKernelGGL((attn_bwd_dkv_tr_kernel<DH, KF, TQ, false, true>), dim3(a.Nkv / 128, a.H, a.B), dim3(256), LDS_DKV, st, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_tr_kernel<DH, KF, TQ, false, true>), dim3(a.Nkv / 128, a.H, a.B), dim3(256), LDS_DKV3, st, a);
       CL_CHECK_LAUNCH();
       return CL_OK;
     }
