@@ -64,8 +64,18 @@ __device__ __forceinline__ void x40_mfma_v0(f32x16_t& c, const u32x4_t& a, const
 __device__ __forceinline__ void x40_mfma_v(f32x16_t& c, const u32x4_t& a, const u32x4_t& b) {
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
-// the compiler does not know an inline-asm MFMA's latency: before VALU reads its result (>= 18 wait states for 16 passes)
-__device__ __forceinline__ void x40_mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+// The compiler does not know an inline-asm MFMA's latency: before anything but an MFMA reads its result, 11 wait states
+// (8 passes + 3) must pass.  The drain takes the accumulators it protects as in/out operands: to the compiler an asm
+// statement that does not mention them is no obstacle for their readers -- the first version of this drain ("s_nop" with a
+// memory clobber only) had the epilogue's ds_bpermute of the denominator row scheduled BEFORE it, one s_nop 0 behind the
+// last P.V MFMA; a stale denominator sent workgroups into the second pass at random (correct results, different roundings:
+// 1-ulp flips in ~2 % of the outputs from run to run; found by tests/tools/debug_determinism.py).
+__device__ __forceinline__ void x40_mfma_drain(f32x16_t& a, f32x16_t& b, f32x16_t& c, f32x16_t& d) {
+  asm volatile("s_nop 15\n\ts_nop 15" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+__device__ __forceinline__ void x40_mfma_drain(f32x16_t& a, f32x16_t& b) {
+  asm volatile("s_nop 15\n\ts_nop 15" : "+v"(a), "+v"(b));
+}
 // c += a . b (O^T accumulators).  Inline asm keeps every MFMA operand in architectural registers: with the builtin the allocator
 // parked the SCORES in accumulation registers (64 v_accvgpr_read per tile in front of the exp2s); with "v" everywhere the
 // kernel needs 224 registers, no AGPRs, and two workgroups share a CU (two waves per SIMD).
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(X40_THREADS, 2) void attn_fwd40_kernel(AttnFwdArgs 
     pin_k();
     static_for<0, 6>([&](auto Qc) { s_mfma(XA{}, Qc); });
     static_for<0, 6>([&](auto Qc) { s_mfma(XB{}, Qc); });
-    x40_mfma_drain();
+    x40_mfma_drain(sc[0][0], sc[0][1], sc[1][0], sc[1][1]);
     first_max(XA{});
     first_max(XB{});
     static_for<0, 4>([&](auto Ic) { req_v(Ic); });         // V(0) fragments for iteration 0 (16 reads: waited for at its top)
@@ -360,7 +370,7 @@ __global__ __launch_bounds__(X40_THREADS, 2) void attn_fwd40_kernel(AttnFwdArgs 
       static_for<0, 2>([&](auto Xc) {
         constexpr int x = decltype(Xc)::value;
         static_for<0, 6>([&](auto Qc) { s_mfma(Xc, Qc); });
-        x40_mfma_drain();
+        x40_mfma_drain(sc[x][0], sc[x][1]);
         float mx = sc[x][0][0];
 #pragma unroll
         for (int s_ = 0; s_ < 2; ++s_)
@@ -378,7 +388,7 @@ __global__ __launch_bounds__(X40_THREADS, 2) void attn_fwd40_kernel(AttnFwdArgs 
           for (int s_ = 0; s_ < 2; ++s_)
 #pragma unroll
             for (int r = 0; r < 16; ++r) sc[x][s_][r] -= d;
-          x40_mfma_drain();                                              // (inline-asm MFMAs wrote O^T: see pv_mfma)
+          x40_mfma_drain(oT[x][0], oT[x][1]);                            // (inline-asm MFMAs wrote O^T: see pv_mfma)
 #pragma unroll
           for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -392,7 +402,7 @@ __global__ __launch_bounds__(X40_THREADS, 2) void attn_fwd40_kernel(AttnFwdArgs 
   };
 
   run_fast();
-  x40_mfma_drain();                                        // (the last P.V MFMAs are inline asm: their results are read below)
+  x40_mfma_drain(oT[0][0], oT[0][1], oT[1][0], oT[1][1]);  // (the last P.V MFMAs are inline asm: their results are read below)
   // every row's denominator (O^T row 40: d block 1, register 4 of the lower half-wave) must be an ordinary number
   float lsum[2];
   auto denominators = [&]() {
@@ -406,7 +416,7 @@ __global__ __launch_bounds__(X40_THREADS, 2) void attn_fwd40_kernel(AttnFwdArgs 
   };
   if (__syncthreads_or(denominators() ? 1 : 0)) {
     run_safe();
-    x40_mfma_drain();
+    x40_mfma_drain(oT[0][0], oT[0][1], oT[1][0], oT[1][1]);
     denominators();
   }
 

@@ -339,7 +339,7 @@ class ResBlockE:
         saved = (x, st1, h2, st2, semb, t_e, (h1, h3) if keep else None) if ctx.record else None
         return out, saved
 
-    def bwd(self, ctx: Ctx, dout, saved, B, H, W, dsemb=None, need_emb_grads=False, out=None):
+    def bwd(self, ctx: Ctx, dout, saved, B, H, W, dsemb=None, need_emb_grads=False, out=None, de_slot=None):
         x, st1, h2, st2, semb, t_e, conv_in = saved
         HW = H * W
         if conv_in is not None:
@@ -347,7 +347,10 @@ class ResBlockE:
         dh3 = conv3_bwd_data(ctx, self.conv2, dout, B, H, W)
         dh2 = self.gn2.bwd(ctx, h2, dh3, st2, B, HW)
         del dh3
-        if need_emb_grads:
+        if need_emb_grads and de_slot is not None:
+            # d emb_out[b, c] = sum_p dh2[b, p, c] into this block's slice; the linear's backward runs grouped, after the trunk
+            hip.colsum(dh2, de_slot, B, HW)
+        elif need_emb_grads:
             # d emb_out[b, c] = sum_p dh2[b, p, c]; back through the LoRA'd emb linear into d silu(emb)
             de32 = ctx.zeros(B, self.cout, torch.float32)
             hip.colsum(dh2, de32, B, HW)

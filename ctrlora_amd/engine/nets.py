@@ -61,6 +61,8 @@ class NetCfg:
 
 # A/B switch: CTRLORA_GROUP_LORA=0 keeps one launch per LoRA linear
 GROUP_LORA = os.environ.get("CTRLORA_GROUP_LORA", "1") != "0"
+# A/B switch: CTRLORA_HOIST_EMB_BWD=0 keeps the emb_layers backward inside every ResBlock
+HOIST_EMB_BWD = os.environ.get("CTRLORA_HOIST_EMB_BWD", "1") != "0"
 
 
 def is_trainable_name(n: str) -> bool:
@@ -195,7 +197,7 @@ class _Builder:
 
 class _Env:
     """Mutable per-pass state threaded through the layers."""
-    __slots__ = ("B", "H", "W", "semb", "c", "Nkv", "dsemb", "emb_grads", "kv", "emb_all", "kv_all", "emb_pre")
+    __slots__ = ("B", "H", "W", "semb", "c", "Nkv", "dsemb", "emb_grads", "kv", "emb_all", "kv_all", "emb_pre", "de_all")
 
     def __init__(self, B, H, W, semb, c, Nkv):
         self.B, self.H, self.W, self.semb, self.c, self.Nkv = B, H, W, semb, c, Nkv
@@ -205,6 +207,7 @@ class _Env:
         self.emb_all = None      # frozen UNet: every ResBlock's emb_layers output, one product [B, sum cout]
         self.kv_all = None       # frozen UNet: every cross-attention's K / V of the context, one product
         self.emb_pre = None      # ControlNet: {id(_Res): (emb_layers output, x A^T)} formed by grouped launches up front
+        self.de_all = None       # ControlNet backward: fp32 [B, sum cout] -- every grouped ResBlock's d emb_out lands in its slice
 
 
 class _Res:
@@ -212,6 +215,7 @@ class _Res:
         self.blk = blk
         self.cout = blk.cout
         self.emb_off = None      # column offset into _Env.emb_all (frozen UNet only)
+        self.de_off = None       # column offset into _Env.de_all (ControlNet, member of an emb_layers group)
 
     def fwd(self, ctx, x, env, out=None):
         pre = None
@@ -222,8 +226,11 @@ class _Res:
         return self.blk.fwd(ctx, x, env.semb, env.B, env.H, env.W, out=out, e_pre=pre)
 
     def bwd(self, ctx, dy, saved, env, out=None):
+        slot = None
+        if env.de_all is not None and self.de_off is not None:      # hoisted emb_layers backward (ControlNetE.bwd)
+            slot = env.de_all[:, self.de_off:self.de_off + self.cout]
         return self.blk.bwd(ctx, dy, saved, env.B, env.H, env.W, dsemb=env.dsemb, need_emb_grads=env.emb_grads,
-                            out=out)
+                            out=out, de_slot=slot)
 
 
 class _ST:
@@ -410,6 +417,23 @@ class ControlNetE:
         time_items = self.tr.items[:marks[0]]
         # flat buffer in backward-completion order: middle stage first, time_embed last
         self.tr.items.reverse()
+        # The grouped emb_layers also run their BACKWARD as grouped launches, once every block's d emb_out exists -- i.e. after
+        # the last encoder stage: their LoRA gradients are final only then, so their trainables move from their blocks' stages
+        # to the tail of the flat buffer, next to time_embed (the data-parallel hook reports a span when it is final).
+        self.emb_sum = 0
+        if self.emb_groups and HOIST_EMB_BWD:
+            hoisted = set()
+            for grp, ls in self.emb_groups:
+                for l in ls:
+                    l.de_off = self.emb_sum
+                    self.emb_sum += l.cout
+                    hoisted.update(id(t) for t in (l.blk.emb.tA, l.blk.emb.tB) if t is not None)
+            emb_items = [t for t in self.tr.items if id(t) in hoisted]
+            time_ids = set(id(t) for t in time_items)
+            stage_items = [[t for t in it if id(t) not in hoisted] for it in stage_items]
+            self.tr.items = ([t for t in self.tr.items if id(t) not in hoisted and id(t) not in time_ids] + emb_items +
+                             [t for t in self.tr.items if id(t) in time_ids])
+            time_items = emb_items + time_items
         self.tr.materialize({k: v for k, v in sd.items()}, device)
         if train_all and self.tr_lora.flat is None:
             self.tr_lora.materialize({k: v for k, v in sd.items()}, device)
@@ -526,10 +550,12 @@ class ControlNetE:
         semb, tsv = self.time.fwd(ctx, t)
         env = _Env(B, H, W, semb, c, c.shape[0] // B)
         env.kv = kv
+        emb_tt = []
         if self.emb_groups:
             env.emb_pre = {}
             for grp, ls in self.emb_groups:
                 y, tt = group_fwd(ctx, grp, semb)
+                emb_tt.append(tt)
                 for i, l in enumerate(ls):
                     env.emb_pre[id(l)] = (y[:, i * grp.N:(i + 1) * grp.N],
                                           None if tt is None else tt[:, i * grp.r:(i + 1) * grp.r])
@@ -542,7 +568,7 @@ class ControlNetE:
         h, sv = _run_fwd(ctx, self.mid, h, env)
         saved.append(sv); dims.append((env.H, env.W))
         hs.append(h)
-        return ((tsv, semb, saved, hs, dims, c, hint_tok) if ctx.record else None), hs
+        return ((tsv, semb, saved, hs, dims, c, hint_tok, emb_tt) if ctx.record else None), hs
 
     def fwd_zero(self, hs, sinks, scales, weight=1.0):
         for k, h in enumerate(hs):
@@ -554,10 +580,12 @@ class ControlNetE:
         hip.gemm(h, z.W, out, bias=z.bias, alpha=alpha, residual=res, beta=1.0 if res is not None else 0.0)
 
     def bwd(self, ctx: Ctx, record, dsinks, scales, weight, B):
-        tsv, semb, saved, hs, dims, c, hint_tok = record
+        tsv, semb, saved, hs, dims, c, hint_tok, emb_tt = record
         env = _Env(B, 0, 0, semb, c, c.shape[0] // B)
         env.emb_grads = True
         env.dsemb = ctx.zeros(B, self.cfg.time_embed_dim)
+        if self.emb_sum:
+            env.de_all = ctx.zeros(B, self.emb_sum, torch.float32)
         nb = len(self.blocks)
         # middle_block_out + middle block
         env.H, env.W = dims[nb]
@@ -574,9 +602,32 @@ class ControlNetE:
             elif self.train_all:      # pre-training also trains the input conv: weight gradient only (the hint needs none)
                 conv3_bwd_weight(ctx, self.blocks[0][0].cw, hint_tok, dh, B, env.H, env.W)
             self._done(ctx, self.stage_spans[k])
+        if env.de_all is not None:
+            self._emb_bwd(ctx, env, semb, emb_tt, B)
         self.time.bwd(ctx, env.dsemb, tsv)
         self._done(ctx, self.time_span)
         ctx.retire_wgrad()      # every weight gradient of this network is ordered before what follows
+
+    def _emb_bwd(self, ctx, env, semb, emb_tt, B):
+        """Backward of every grouped emb_layers linear at once (openaimodel.py:254-274: emb_out enters h as a per-sample row
+        bias, so d emb_out[b] is the column sum of dh over the sample's pixels -- the ResBlocks left those in env.de_all):
+        per width ONE u = de B launch and ONE dsemb += [de | u] [W | A] launch instead of two (+ a clear, a pack and the
+        split-K reduces) per block; the LoRA factor gradients dB += de^T t, dA += u^T silu(emb) join the weight-gradient queue."""
+        de = ctx.new(B, self.emb_sum)
+        hip.pack2d(env.de_all, de)
+        for (grp, ls), tt in zip(self.emb_groups, emb_tt):
+            o0 = ls[0].de_off
+            de_g = de[:, o0:o0 + grp.G * grp.N]
+            u = ctx.new(B, grp.G * grp.r)
+            if grp.r % 64 == 0:
+                hip.gemm(de_g, grp.Bt, u, k1=grp.N, a1_group_n=grp.r)
+            else:                                 # rank below the narrowest tile: one small product per member (as AttnE._group_bwd)
+                for i, l in enumerate(ls):
+                    hip.gemm(de_g[:, i * grp.N:(i + 1) * grp.N], l.blk.emb.Bt, u[:, i * grp.r:(i + 1) * grp.r])
+            hip.gemm(de_g, grp.Wt, env.dsemb, a2=u, w2=grp.At, residual=env.dsemb, beta=1.0)
+            for i, l in enumerate(ls):
+                linear_bwd_lora(ctx, l.blk.emb, semb, tt[:, i * grp.r:(i + 1) * grp.r], de_g[:, i * grp.N:(i + 1) * grp.N],
+                                u[:, i * grp.r:(i + 1) * grp.r])
 
     def _done(self, ctx, span):
         """End of a backward stage: its queued weight gradients go out as one grouped launch, and once they are

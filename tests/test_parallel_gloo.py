@@ -576,3 +576,28 @@ def test_bf16_payload_halves_the_exchanged_bytes_and_keeps_the_buffer_fp32_gloo(
         assert is_f32 and launches >= 2
         assert nbytes == 4000 * 2
         assert 0 < err < 2e-2, err
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_backward_stage_spans_tile_the_flat_buffer(dtype):
+    """What the data-parallel hook relies on (parallel.py:GradAllReduce._stage_done): the spans ControlNetE.bwd reports
+    are adjacent, in increasing offset order, and cover the flat gradient buffer.  In the bf16 layout the grouped emb_layers
+    run their backward AFTER the last encoder stage (nets.py:_emb_bwd), so their LoRA factors must sit in the LAST span,
+    next to time_embed -- a stage reported final must not contain a gradient that is still to be written."""
+    from ctrlora_amd.engine import ControlNetE, NetCfg
+    from oracle import arch
+    cfg = arch.TINY
+    ncfg = NetCfg(cfg.in_channels, cfg.out_channels, cfg.model_channels, cfg.channel_mult, cfg.num_res_blocks,
+                  cfg.attention_resolutions, cfg.num_heads, cfg.context_dim)
+    ex = ControlNetE(arch.make_state(arch.controlnet_shapes(cfg), 1), ncfg, dtype, torch.device("cpu"), layout_only=True)
+    order = ex.backward_stage_order()
+    assert order[0][0] == 0 and order[-1][1] == ex.tr.numel
+    assert all(order[i][1] == order[i + 1][0] for i in range(len(order) - 1)), order
+    last = order[-1][0]
+    emb = [t for t in ex.tr.items if ".emb_layers." in t.name]
+    hoisted = {id(t) for _, ls in ex.emb_groups for l in ls for t in (l.blk.emb.tA, l.blk.emb.tB)}
+    assert len(emb) > 0 and (len(hoisted) > 0) == (dtype == torch.bfloat16)
+    for t in emb:
+        assert (t.offset >= last) == (id(t) in hoisted), t.name
+    assert all(t.offset >= last for t in ex.tr.items if t.name.startswith("time_embed."))
+    assert sorted(t.name for t in ex.tr.items) == sorted(k for k in arch.controlnet_shapes(cfg) if arch.is_trainable(k))
