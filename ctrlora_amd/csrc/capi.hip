@@ -22,7 +22,7 @@ static GemmParams base_params() {
 
 extern "C" {
 
-int cl_abi_version(void) { return 6; }
+int cl_abi_version(void) { return CL_ABI_VERSION; }
 int cl_last_hip_error(void) { return g_last_hip_error; }
 const char* cl_last_hip_error_string(void) { return hipGetErrorString((hipError_t)g_last_hip_error); }
 

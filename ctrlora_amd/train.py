@@ -141,16 +141,30 @@ class FusedAdamW(torch.optim.Optimizer):
             hip.zero_(ex.tr.flat_grad)
 
     def state_dict(self):
-        return dict(step=self._step, m=[m.clone() for m in self._m], v=[v.clone() for v in self._v],
+        """Moments BY PARAMETER NAME: the order of the flat buffers is an implementation detail of a build / dtype (the bf16
+        engine keeps the grouped emb_layers factors at the tail, nets.py), a checkpoint must not depend on it."""
+        def by_name(ex, buf):
+            return {t.name: buf[t.offset:t.offset + t.master.numel()].clone() for t in ex.tr.items}
+        return dict(step=self._step, format="by_name", m=[by_name(ex, m) for ex, m in zip(self.executors, self._m)],
+                    v=[by_name(ex, v) for ex, v in zip(self.executors, self._v)],
                     param_groups=[{k: v for k, v in g.items() if k != "params"} for g in self.param_groups])
 
     def load_state_dict(self, sd):
         self._step_dev.fill_(int(sd["step"]))
         assert len(sd["m"]) == len(self._m), "optimizer state was saved for a different number of ControlNet banks"
-        for dst, src in zip(self._m, sd["m"]):
-            dst.copy_(src)
-        for dst, src in zip(self._v, sd["v"]):
-            dst.copy_(src)
+        for key, bufs in (("m", self._m), ("v", self._v)):
+            for ex, dst, src in zip(self.executors, bufs, sd[key]):
+                if isinstance(src, dict):
+                    missing = [t.name for t in ex.tr.items if t.name not in src]
+                    if missing:
+                        raise KeyError(f"optimizer state lacks {len(missing)} tensors, e.g. {missing[:3]}")
+                    for t in ex.tr.items:
+                        dst[t.offset:t.offset + t.master.numel()].copy_(src[t.name].reshape(-1))
+                else:       # rounds 1-3: one flat tensor in the flat buffer's order of the build that wrote it
+                    if getattr(ex, "emb_sum", 0):
+                        raise RuntimeError("this optimizer state was saved in flat-buffer order by an older build; resume it "
+                                           "with CTRLORA_HOIST_EMB_BWD=0 (that build's order) and save again")
+                    dst.copy_(src)
         _restore_param_groups(self, sd)
 
 

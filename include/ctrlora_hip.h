@@ -33,6 +33,8 @@ extern "C" {
 #define CL_F32 1
 #endif
 
+/* the version this header describes; cl_abi_version() returns the one the loaded library was built from */
+#define CL_ABI_VERSION 6
 int cl_abi_version(void);
 /* the hipError_t behind the most recent CL_ELAUNCH return (diagnostics) */
 int cl_last_hip_error(void);

@@ -46,7 +46,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     L = ctypes.CDLL(built_lib)
     for name in decls:
         assert hasattr(L, name), f"{name} declared in ctrlora_hip.h but not exported"
-    assert L.cl_abi_version() == 6
+    assert L.cl_abi_version() == 6 and "#define CL_ABI_VERSION 6" in open(os.path.join(ROOT, "include", "ctrlora_hip.h")).read()
 
 
 def test_ctypes_signatures_match_header(built_lib):

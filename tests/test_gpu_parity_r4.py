@@ -169,3 +169,50 @@ def test_rccl_world_size_one_next_to_segment_graphs(tmp_path):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_optimizer_state_is_keyed_by_name_not_by_flat_offset(monkeypatch):
+    """The bf16 engine keeps the LoRA factors of the grouped emb_layers at the tail of the flat buffers (their backward runs
+    after the trunk, nets.py:_emb_bwd); CTRLORA_HOIST_EMB_BWD=0, the fp32 engine and builds before round 4 do not.
+    FusedAdamW.state_dict() therefore stores the moments per parameter NAME: a checkpoint written under one order resumes
+    under the other with every tensor's moments in place."""
+    _need_gpu()
+    import bench
+    import ctrlora_amd.engine.nets as nets
+
+    def build():
+        m = bench.build_model("ctrlora_finetune_sd15_rank128.yaml", 0, tiny=True).cuda().train()
+        m.set_engine_dtype(torch.bfloat16)
+        m.learning_rate = 1e-4
+        return m, m.configure_optimizers()
+
+    model, opt = build()
+    data = bench.synth(2, 16, model.control_model.context_dim, torch.device("cuda"), 77, 1)
+    cond = {"c_crossattn": [data["ctx"][0]], "c_concat": [data["hint"][0]]}
+    for _ in range(2):
+        opt.zero_grad()
+        loss, _ = model.p_losses(data["z"][0], cond, data["t"][0], noise=data["noise"][0])
+        loss.backward()
+        opt.step()
+    torch.cuda.synchronize()
+    sd = opt.state_dict()
+    ex = opt.executors[0]
+    assert ex.emb_sum > 0 and sd["format"] == "by_name" and set(sd["m"][0]) == {t.name for t in ex.tr.items}
+    assert all(float(v.abs().sum()) > 0 for v in sd["v"][0].values())          # every tensor has seen a gradient
+    off_a = {t.name: t.offset for t in ex.tr.items}
+    monkeypatch.setattr(nets, "HOIST_EMB_BWD", False)
+    model2, opt2 = build()
+    ex2 = opt2.executors[0]
+    off_b = {t.name: t.offset for t in ex2.tr.items}
+    assert ex2.emb_sum == 0 and any(off_a[n] != off_b[n] for n in off_a), "the two builds were meant to differ in layout"
+    opt2.load_state_dict(sd)
+    for t in ex2.tr.items:
+        n = t.master.numel()
+        assert torch.equal(opt2._m[0][t.offset:t.offset + n], sd["m"][0][t.name].reshape(-1)), t.name
+        assert torch.equal(opt2._v[0][t.offset:t.offset + n], sd["v"][0][t.name].reshape(-1)), t.name
+    # a flat (round <= 3) state is refused by a build whose order differs from the one that wrote it
+    legacy = dict(sd, m=[opt2._m[0].clone()], v=[opt2._v[0].clone()])
+    legacy.pop("format")
+    with pytest.raises(RuntimeError):
+        opt.load_state_dict(legacy)
+    opt2.load_state_dict(legacy)                                                # same order: accepted as before
