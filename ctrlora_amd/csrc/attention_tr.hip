@@ -27,7 +27,45 @@
 #include "attn_common.h"
 #include "attn_tr_util.h"
 
+// Probe builds only (tools/build_probes.sh attn_bwd_abl): -DATTN_BWD_ABL=n removes one ingredient of the two d_head-40 fold
+// backward kernels so that its share of the time can be measured (results are wrong by construction):
+//   1 no exp2   2 no MFMA (operands kept alive)   3 no LDS fragment reads   4 no DMA wait / barrier   5 no cvt_pk (P, dS not packed)
+#ifndef ATTN_BWD_ABL
+#define ATTN_BWD_ABL 0
+#endif
+#if ATTN_BWD_ABL == 2
+#define BWD_MMA(a, b, c) asm volatile("" ::"v"(a), "v"(b))
+#else
+#define BWD_MMA(a, b, c) Mma<bf16_t>::run(a, b, c)
+#endif
+#if ATTN_BWD_ABL == 3
+#define BWD_RD128 abl_rd128
+#define BWD_TRF abl_trf
+#else
+#define BWD_RD128 lds_read_b128_off
+#define BWD_TRF tr_frag_off
+#endif
+#if ATTN_BWD_ABL == 5
+#define BWD_PACK(p) abl_pack(p)
+#else
+#define BWD_PACK(p) PFrag<bf16_t>::make(p)
+#endif
+#if ATTN_BWD_ABL == 1
+#define BWD_EXP2(x) (x)
+#else
+#define BWD_EXP2(x) __builtin_amdgcn_exp2f(x)
+#endif
+
 namespace cl {
+#if ATTN_BWD_ABL == 3
+template <int OFF> __device__ __forceinline__ u32x4_t abl_rd128(uint32_t a) { u32x4_t v = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; asm volatile("" : "+v"(v) : "v"(a)); return v; }
+template <int ROWB, int STEP, int OFF> __device__ __forceinline__ u32x4_t abl_trf(uint32_t a) { u32x4_t v = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; asm volatile("" : "+v"(v) : "v"(a)); return v; }
+#endif
+#if ATTN_BWD_ABL == 5
+__device__ __forceinline__ u32x4_t abl_pack(const f32x4_t* p) {
+  return u32x4_t{__float_as_uint(p[0][0]), __float_as_uint(p[0][2]), __float_as_uint(p[1][0]), __float_as_uint(p[1][2])};
+}
+#endif
 
 namespace {
 
@@ -649,6 +687,9 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_tr_kerne
   if constexpr (PIPE) { if (ntiles > 1) issue(1, 1); }
   int buf = 0;
   for (int t = 0; t < ntiles; ++t) {
+#if ATTN_BWD_ABL == 4
+    if constexpr (!PIPE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+#else
     if constexpr (PIPE) {
       if (t + 1 >= ntiles) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (dma_per_tile == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -657,6 +698,7 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_tr_kerne
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+#endif
     const uint32_t aQ = lds0 + buf * STAGE, adO = aQ + TILE, aL = adO + TILE;
     const int q0 = t * 64;
     // PIPE (= FOLD): the row fragments of the NEXT query fragment and the column fragments of the NEXT d block are requested
@@ -670,7 +712,7 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_tr_kerne
     u32x4_t qa[2][KSTEPS], da[2][KSTEPS];
     if constexpr (PIPE) {
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) { qa[0][ks] = lds_read_b128_off<0>(rb[ks]); da[0][ks] = lds_read_b128_off<TILE>(rb[ks]); }
+      for (int ks = 0; ks < KSTEPS; ++ks) { qa[0][ks] = BWD_RD128<0>(rb[ks]); da[0][ks] = BWD_RD128<TILE>(rb[ks]); }
     }
     if constexpr (PIPE) {
       if (t + 2 < ntiles) issue(t + 2, buf == 0 ? 2 : buf - 1);
@@ -690,20 +732,20 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_tr_kerne
         if constexpr (qf + 1 < 4) {
 #pragma unroll
           for (int ks = 0; ks < KSTEPS; ++ks) {
-            qa[cur ^ 1][ks] = lds_read_b128_off<(qf + 1) * 16 * ROWB>(rb[ks]);
-            da[cur ^ 1][ks] = lds_read_b128_off<TILE + (qf + 1) * 16 * ROWB>(rb[ks]);
+            qa[cur ^ 1][ks] = BWD_RD128<(qf + 1) * 16 * ROWB>(rb[ks]);
+            da[cur ^ 1][ks] = BWD_RD128<TILE + (qf + 1) * 16 * ROWB>(rb[ks]);
           }
           lgkm_wait<2 * KSTEPS>();
         } else {           // last query fragment: the first d block's column fragments go out under its exp2 / pack work
-          oa[0][0] = tr_frag_off<ROWB, 0, TILE>(tb); oa[0][1] = tr_frag_off<ROWB, 1, TILE>(tb);
-          qt[0][0] = tr_frag_off<ROWB, 0, 0>(tb); qt[0][1] = tr_frag_off<ROWB, 1, 0>(tb);
+          oa[0][0] = BWD_TRF<ROWB, 0, TILE>(tb); oa[0][1] = BWD_TRF<ROWB, 1, TILE>(tb);
+          qt[0][0] = BWD_TRF<ROWB, 0, 0>(tb); qt[0][1] = BWD_TRF<ROWB, 1, 0>(tb);
           lgkm_wait<8>();
         }
       } else {
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-          qa[0][ks] = lds_read_b128_off<qf * 16 * ROWB>(rb[ks]);
-          da[0][ks] = lds_read_b128_off<TILE + qf * 16 * ROWB>(rb[ks]);
+          qa[0][ks] = BWD_RD128<qf * 16 * ROWB>(rb[ks]);
+          da[0][ks] = BWD_RD128<TILE + qf * 16 * ROWB>(rb[ks]);
         }
         if constexpr (!FOLD) {
           l4 = lds_read_b128(aL + (qf * 16 + 4 * g) * 4);
@@ -719,7 +761,7 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_tr_kerne
         f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) { Mma<bf16_t>::run(qa[cur][ks], kb[kf][ks], sc); Mma<bf16_t>::run(da[cur][ks], vb[kf][ks], dp); }
+        for (int ks = 0; ks < KSTEPS; ++ks) { BWD_MMA(qa[cur][ks], kb[kf][ks], sc); BWD_MMA(da[cur][ks], vb[kf][ks], dp); }
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         // P = exp2(s * sl2 - lse), dS = P (dP - delta); the d_head^-0.5 factor of dS is applied once to dK in the
         // epilogue (linear).  Two rows per packed instruction.
@@ -727,7 +769,7 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_tr_kerne
         for (int h2 = 0; h2 < 2; ++h2) {
           f32x2_t pr, dsv;
           if constexpr (FOLD) {            // sc = s - lse, dp = dP - delta already
-            pr = f32x2_t{__builtin_amdgcn_exp2f(sc[2 * h2]), __builtin_amdgcn_exp2f(sc[2 * h2 + 1])};
+            pr = f32x2_t{BWD_EXP2(sc[2 * h2]), BWD_EXP2(sc[2 * h2 + 1])};
             dsv = pr * f32x2_t{dp[2 * h2], dp[2 * h2 + 1]};
           } else {
             const f32x2_t s2 = {sc[2 * h2], sc[2 * h2 + 1]}, l2 = {lv[2 * h2], lv[2 * h2 + 1]};
@@ -750,29 +792,29 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_tr_kerne
 #pragma unroll
     for (int kf = 0; kf < KF; ++kf)
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) { pb[kf][s2] = PFrag<bf16_t>::make(&ps[kf][2 * s2]); sb[kf][s2] = PFrag<bf16_t>::make(&ds[kf][2 * s2]); }
+      for (int s2 = 0; s2 < 2; ++s2) { pb[kf][s2] = BWD_PACK(&ps[kf][2 * s2]); sb[kf][s2] = BWD_PACK(&ds[kf][2 * s2]); }
     static_for<0, DN>([&](auto I_) {
       constexpr int i = decltype(I_)::value;
       constexpr int cur = PIPE ? (i & 1) : 0;
       if constexpr (PIPE) {
         if constexpr (i + 1 < DN) {
           // (lgkmcnt is a 4-bit counter: never more than 12 reads in flight)
-          oa[cur ^ 1][0] = tr_frag_off<ROWB, 0, TILE + (i + 1) * 32>(tb); oa[cur ^ 1][1] = tr_frag_off<ROWB, 1, TILE + (i + 1) * 32>(tb);
+          oa[cur ^ 1][0] = BWD_TRF<ROWB, 0, TILE + (i + 1) * 32>(tb); oa[cur ^ 1][1] = BWD_TRF<ROWB, 1, TILE + (i + 1) * 32>(tb);
           lgkm_wait<4>();
-          qt[cur ^ 1][0] = tr_frag_off<ROWB, 0, (i + 1) * 32>(tb); qt[cur ^ 1][1] = tr_frag_off<ROWB, 1, (i + 1) * 32>(tb);
+          qt[cur ^ 1][0] = BWD_TRF<ROWB, 0, (i + 1) * 32>(tb); qt[cur ^ 1][1] = BWD_TRF<ROWB, 1, (i + 1) * 32>(tb);
         } else {
           lgkm_wait<0>();
         }
       } else {
-        oa[0][0] = tr_frag_off<ROWB, 0, TILE + i * 32>(tb); oa[0][1] = tr_frag_off<ROWB, 1, TILE + i * 32>(tb);
-        qt[0][0] = tr_frag_off<ROWB, 0, i * 32>(tb); qt[0][1] = tr_frag_off<ROWB, 1, i * 32>(tb);
+        oa[0][0] = BWD_TRF<ROWB, 0, TILE + i * 32>(tb); oa[0][1] = BWD_TRF<ROWB, 1, TILE + i * 32>(tb);
+        qt[0][0] = BWD_TRF<ROWB, 0, i * 32>(tb); qt[0][1] = BWD_TRF<ROWB, 1, i * 32>(tb);
         lds_wait();
       }
       if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kf = 0; kf < KF; ++kf)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) { Mma<bf16_t>::run(oa[cur][s2], pb[kf][s2], dvt[kf][i]); Mma<bf16_t>::run(qt[cur][s2], sb[kf][s2], dkt[kf][i]); }
+        for (int s2 = 0; s2 < 2; ++s2) { BWD_MMA(oa[cur][s2], pb[kf][s2], dvt[kf][i]); BWD_MMA(qt[cur][s2], sb[kf][s2], dkt[kf][i]); }
       if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     });
     if constexpr (PIPE) buf = buf == 2 ? 0 : buf + 1;
@@ -910,6 +952,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_tr_kernel(AttnBwdArgs p) {
   if constexpr (PIPE) { if (ntiles > 1) issue_kv(1, 1); }
   int buf = 0;
   for (int t = 0; t < ntiles; ++t) {
+#if ATTN_BWD_ABL == 4
+    if constexpr (!PIPE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+#else
     if constexpr (PIPE) {
       if (t + 1 >= ntiles) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (dma_per_tile == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -918,6 +963,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_tr_kernel(AttnBwdArgs p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+#endif
     const uint32_t aK = lds0 + buf * STAGE, aV = aK + TILE;
     const int kv0 = t * 64;
     uint32_t rb[KSTEPS];
@@ -927,7 +973,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_tr_kernel(AttnBwdArgs p) {
     u32x4_t ka[2][KSTEPS], va[2][KSTEPS], kc[2][2];
     if constexpr (PIPE) {        // software-pipelined fragment reads, as in the dK / dV kernel
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) { ka[0][ks] = lds_read_b128_off<0>(rb[ks]); va[0][ks] = lds_read_b128_off<TILE>(rb[ks]); }
+      for (int ks = 0; ks < KSTEPS; ++ks) { ka[0][ks] = BWD_RD128<0>(rb[ks]); va[0][ks] = BWD_RD128<TILE>(rb[ks]); }
     }
     if constexpr (PIPE) {
       if (t + 2 < ntiles) issue_kv(t + 2, buf == 0 ? 2 : buf - 1);
@@ -944,19 +990,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_tr_kernel(AttnBwdArgs p) {
         if constexpr (kf + 1 < 4) {
 #pragma unroll
           for (int ks = 0; ks < KSTEPS; ++ks) {
-            ka[cur ^ 1][ks] = lds_read_b128_off<(kf + 1) * 16 * ROWB>(rb[ks]);
-            va[cur ^ 1][ks] = lds_read_b128_off<TILE + (kf + 1) * 16 * ROWB>(rb[ks]);
+            ka[cur ^ 1][ks] = BWD_RD128<(kf + 1) * 16 * ROWB>(rb[ks]);
+            va[cur ^ 1][ks] = BWD_RD128<TILE + (kf + 1) * 16 * ROWB>(rb[ks]);
           }
           lgkm_wait<2 * KSTEPS>();
         } else {
-          kc[0][0] = tr_frag_off<ROWB, 0, 0>(tb); kc[0][1] = tr_frag_off<ROWB, 1, 0>(tb);
+          kc[0][0] = BWD_TRF<ROWB, 0, 0>(tb); kc[0][1] = BWD_TRF<ROWB, 1, 0>(tb);
           lgkm_wait<4>();
         }
       } else {
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-          ka[0][ks] = lds_read_b128_off<kf * 16 * ROWB>(rb[ks]);
-          va[0][ks] = lds_read_b128_off<TILE + kf * 16 * ROWB>(rb[ks]);
+          ka[0][ks] = BWD_RD128<kf * 16 * ROWB>(rb[ks]);
+          va[0][ks] = BWD_RD128<TILE + kf * 16 * ROWB>(rb[ks]);
         }
         lds_wait();
       }
@@ -965,14 +1011,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_tr_kernel(AttnBwdArgs p) {
         f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) { Mma<bf16_t>::run(ka[cur][ks], qb[f][ks], sc); Mma<bf16_t>::run(va[cur][ks], ob[f][ks], dp); }
+        for (int ks = 0; ks < KSTEPS; ++ks) { BWD_MMA(ka[cur][ks], qb[f][ks], sc); BWD_MMA(va[cur][ks], ob[f][ks], dp); }
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         // dS^T = P (dP - delta), two keys per packed instruction; d_head^-0.5 goes onto dQ in the epilogue
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
           f32x2_t dsv;
           if constexpr (FOLD) {            // sc = s - lse, dp = dP - delta already
-            const f32x2_t pr = {__builtin_amdgcn_exp2f(sc[2 * h2]), __builtin_amdgcn_exp2f(sc[2 * h2 + 1])};
+            const f32x2_t pr = {BWD_EXP2(sc[2 * h2]), BWD_EXP2(sc[2 * h2 + 1])};
             dsv = pr * f32x2_t{dp[2 * h2], dp[2 * h2 + 1]};
           } else {
             const f32x2_t x = f32x2_t{sc[2 * h2], sc[2 * h2 + 1]} * sl2 - lse_q[f];
@@ -992,26 +1038,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_tr_kernel(AttnBwdArgs p) {
 #pragma unroll
     for (int f = 0; f < QF; ++f)
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) sb[f][s2] = PFrag<bf16_t>::make(&dst[f][2 * s2]);
+      for (int s2 = 0; s2 < 2; ++s2) sb[f][s2] = BWD_PACK(&dst[f][2 * s2]);
     static_for<0, DN>([&](auto I_) {
       constexpr int i = decltype(I_)::value;
       constexpr int cur = PIPE ? (i & 1) : 0;
       if constexpr (PIPE) {
         if constexpr (i + 1 < DN) {
-          kc[cur ^ 1][0] = tr_frag_off<ROWB, 0, (i + 1) * 32>(tb); kc[cur ^ 1][1] = tr_frag_off<ROWB, 1, (i + 1) * 32>(tb);
+          kc[cur ^ 1][0] = BWD_TRF<ROWB, 0, (i + 1) * 32>(tb); kc[cur ^ 1][1] = BWD_TRF<ROWB, 1, (i + 1) * 32>(tb);
           lgkm_wait<4>();
         } else {
           lgkm_wait<0>();
         }
       } else {
-        kc[0][0] = tr_frag_off<ROWB, 0, i * 32>(tb); kc[0][1] = tr_frag_off<ROWB, 1, i * 32>(tb);
+        kc[0][0] = BWD_TRF<ROWB, 0, i * 32>(tb); kc[0][1] = BWD_TRF<ROWB, 1, i * 32>(tb);
         lds_wait();
       }
       if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int f = 0; f < QF; ++f)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) Mma<bf16_t>::run(kc[cur][s2], sb[f][s2], dqt[f][i]);
+        for (int s2 = 0; s2 < 2; ++s2) BWD_MMA(kc[cur][s2], sb[f][s2], dqt[f][i]);
       if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     });
     if constexpr (PIPE) buf = buf == 2 ? 0 : buf + 1;

@@ -148,7 +148,10 @@ def main():
     ap.add_argument("--shapes", default="40,4096,4096,8;80,1024,1024,8;40,4096,4096,32;40,1024,1024,2;40,256,128,8")
     ap.add_argument("--rounds", type=int, default=5, help="interleaved A/B: median / min over the rounds")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--lib", default=None, help="load this build of the library instead (probe builds: tools/build_probes.sh attn_bwd_abl)")
     args = ap.parse_args()
+    if args.lib:
+        hip.LIB_PATH = os.path.abspath(args.lib)
     variants = parse_variants(args.variants)
     res = []
     cases = [tuple(int(x) for x in sh.split(",")) + (False,) for sh in args.shapes.split(";")]

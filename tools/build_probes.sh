@@ -11,6 +11,13 @@ for p in "$@"; do
     gemm_t) hipcc $FLAGS -DFL_TIMING tools/probe_gemm.hip $C/gemm.hip $C/wgrad.hip -o build/probe_gemm_t ;;
     attn) hipcc $FLAGS tools/probe_attn.hip $C/gemm.hip $C/attention_fwd.hip $C/attention_bwd.hip $C/attention_tr.hip $C/elementwise.hip -o build/probe_attn ;;
     attn_bwd) hipcc $FLAGS tools/probe_attn_bwd.hip $C/gemm.hip $C/attention_fwd.hip $C/attention_bwd.hip $C/attention_tr.hip $C/elementwise.hip -o build/probe_attn_bwd ;;
+    attn_bwd_abl)   # the product library with ONE ingredient of the d_head-40 fold backward kernels removed (attention_tr.hip: ATTN_BWD_ABL)
+      python -m ctrlora_amd.build > /dev/null
+      mkdir -p build/abl
+      for a in 1 2 3 4 5; do
+        hipcc $FLAGS -fPIC -DATTN_BWD_ABL=$a -c $C/attention_tr.hip -o build/abl/attention_tr_abl$a.o
+        hipcc --offload-arch=gfx950 -shared -fPIC $(ls build/obj/*.o | grep -v attention_tr.o) build/abl/attention_tr_abl$a.o -o build/abl/libctrlora_hip_abl$a.so
+      done ;;
     *) echo "unknown probe $p"; exit 1 ;;
   esac
 done
