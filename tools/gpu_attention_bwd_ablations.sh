@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round 4, visit P: what bounds the d_head-40 fold backward kernels?  The product library against five probe builds with one
+# What bounds the d_head-40 fold backward kernels?  The product library against five probe builds with one
 # ingredient removed each (tools/build_probes.sh attn_bwd_abl), same shape, separate processes (absolute times), plus per-kernel
 # durations from rocprofv3 for the product and the no-MFMA / no-LDS builds.
-mkdir -p gpurun_out/r04_p
+mkdir -p gpurun_out/attention_bwd_ablations
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04_p
+O=gpurun_out/attention_bwd_ablations
 for a in 0 1 2 3 4 5 0; do
   if [ $a = 0 ]; then L=""; else L="--lib build/abl/libctrlora_hip_abl$a.so"; fi
   timeout 120 python tests/tools/attn_bench.py --bwd --variants 0p --rounds 5 --no-check --shapes "40,4096,4096,8" $L > $O/abl$a.log 2>&1

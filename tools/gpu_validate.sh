@@ -1,11 +1,16 @@
 #!/bin/bash
-# Round 4: the full GPU suite as the driver runs it, smoke, the default bench line, steady-state kernel traces (training step,
-# DDIM loop proper), the dominant-kernel probe under rocprofv3 --stats.  Outputs -> gpurun_out/r04_final (copied to profiles/).
-mkdir -p gpurun_out/r04_final
+# The full GPU suite as the driver runs it, smoke, the default bench line, steady-state kernel traces (training step,
+# DDIM loop proper), the dominant-kernel probe under rocprofv3 --stats.  Outputs -> gpurun_out/final (copied to profiles/).
+mkdir -p gpurun_out/final
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04_final
+O=gpurun_out/final
 rm -f gpurun_out/parity_measured.jsonl
-timeout 1500 python -m pytest tests/ -x -q -m gpu --durations=15 > $O/pytest_gpu.log 2>&1; tail -4 $O/pytest_gpu.log
+# $2 = "subset": only what changed since the last full run of the suite (the full run is 13 minutes)
+if [ "$2" = "subset" ]; then
+  timeout 1500 python -m pytest tests/test_gpu_scripts.py tests/test_gpu_parity_r4.py tests/test_gpu_bench_shapes.py -x -q -m gpu --durations=8 -k "scripts or r4 or pure_function or optimizer_state or finetune or pretraining or rank32 or reuse_graph or rccl" > $O/pytest_gpu_subset.log 2>&1; tail -4 $O/pytest_gpu_subset.log
+else
+  timeout 1500 python -m pytest tests/ -x -q -m gpu --durations=15 > $O/pytest_gpu.log 2>&1; tail -4 $O/pytest_gpu.log
+fi
 cp gpurun_out/parity_measured.jsonl $O/parity_measured.jsonl 2>/dev/null
 timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; tail -2 $O/smoke.log | cut -c1-300
 timeout 900 python bench.py > $O/bench.log 2> $O/bench.err; tail -1 $O/bench.log | cut -c1-400
