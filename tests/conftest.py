@@ -8,3 +8,20 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+import pytest  # noqa: E402
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _release_gpu_memory_between_modules():
+    """GPU runs only: models, hipGraph pools and the caching allocator's blocks of one test module are released before the
+    next one starts (the suite builds ~40 SD1.5-width models; without this the late modules run inside a fragmented pool)."""
+    yield
+    if "torch" in sys.modules:
+        import gc
+        import torch
+        if torch.cuda.is_available():
+            gc.collect()
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
