@@ -303,6 +303,7 @@ __global__ __launch_bounds__(X40_THREADS, 2) void attn_fwd40_kernel(AttnFwdArgs 
       static_for<0, 8>([&](auto Gc) {
         constexpr int gp = decltype(Gc)::value;
         pv_mfma(XA{}, Gc, std::integral_constant<bool, (!HAS_NEXT || gp < 2)>{});     // (guarded at region entry: see x40_mfma_acc)
+        __builtin_amdgcn_sched_barrier(0);       // the gap's VALU stays BEHIND its MFMA (see the note at the second half)
         constexpr int lo = HAS_NEXT ? x40_op_end(gp - 1) : 6 * gp, hi_ = HAS_NEXT ? x40_op_end(gp) : 6 * (gp + 1);
         sm_ops(XB{}, std::integral_constant<int, lo>{}, std::integral_constant<int, hi_>{});
         __builtin_amdgcn_sched_barrier(0);
@@ -313,6 +314,7 @@ __global__ __launch_bounds__(X40_THREADS, 2) void attn_fwd40_kernel(AttnFwdArgs 
         static_for<0, 6>([&](auto Gc) {
           constexpr int gp = decltype(Gc)::value;
           s_mfma(XA{}, Gc);
+          __builtin_amdgcn_sched_barrier(0);
           sm_ops(XB{}, std::integral_constant<int, x40_op_end(7 + gp)>{}, std::integral_constant<int, x40_op_end(8 + gp)>{});
           __builtin_amdgcn_sched_barrier(0);
         });
@@ -331,6 +333,11 @@ __global__ __launch_bounds__(X40_THREADS, 2) void attn_fwd40_kernel(AttnFwdArgs 
       static_for<0, 8>([&](auto Gc) {
         constexpr int gp = decltype(Gc)::value;
         pv_mfma(XB{}, Gc, std::integral_constant<bool, !HAS_NEXT>{});
+        // Pin the gap's exp2 / pack work BEHIND its MFMA.  Without this the compiler is free to move the builtin VALU of a gap in
+        // front of the gap's inline-asm MFMA (it sees no dependence), and it did: the first exp2 of block A's new scores then
+        // sat ONE matrix instruction behind the S^T MFMA that writes them instead of two -- 10 wait states where the 8-pass
+        // MFMA needs 11 (tools/isa_mfma_hazards.py; no wrong result was ever observed, the margin was simply gone).
+        __builtin_amdgcn_sched_barrier(0);
         if constexpr (HAS_NEXT) {
           v_reads_after(Gc);
           sm_ops(XA{}, std::integral_constant<int, x40_op_end(gp - 1)>{}, std::integral_constant<int, x40_op_end(gp)>{});
@@ -341,6 +348,7 @@ __global__ __launch_bounds__(X40_THREADS, 2) void attn_fwd40_kernel(AttnFwdArgs 
         static_for<0, 6>([&](auto Gc) {
           constexpr int gp = decltype(Gc)::value;
           s_mfma(XB{}, Gc);
+          __builtin_amdgcn_sched_barrier(0);
           v_reads_after(std::integral_constant<int, 8 + gp>{});
           sm_ops(XA{}, std::integral_constant<int, x40_op_end(7 + gp)>{}, std::integral_constant<int, x40_op_end(8 + gp)>{});
           __builtin_amdgcn_sched_barrier(0);
