@@ -50,16 +50,18 @@ def test_lint_flags_a_reader_behind_too_few_wait_states_and_accepts_enough():
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc")
-def test_attention_fwd40_listing_has_no_early_reader_of_an_mfma_result(tmp_path):
-    src = os.path.join(ROOT, "ctrlora_amd", "csrc", "attention_fwd40.hip")
-    out = tmp_path / "attention_fwd40.s"
+@pytest.mark.parametrize("source,key,min_mfma", [("attention_fwd40.hip", "attn_fwd40", 60),      # inline-asm MFMAs: the case the tool exists for
+                                                 ("attention_tr.hip", "attn_", 1000)])            # builtin MFMAs beside inline-asm LDS reads: the
+def test_attention_listings_have_no_early_reader_of_an_mfma_result(tmp_path, source, key, min_mfma):     # compiler's own nops must satisfy the model
+    src = os.path.join(ROOT, "ctrlora_amd", "csrc", source)
+    out = tmp_path / (source + ".s")
     r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-S", "--cuda-device-only",
                         src, "-o", str(out)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = out.read_text().split("\n")
-    ks = [k for k in lint.kernels(lines) if "attn_fwd40" in k[0]]
-    assert ks, "kernel not found in the listing"
-    found = [f for name, lo, hi in ks for f in lint.scan(lines, lo, hi)]
-    assert found == [], "\n".join(f"line {ln}: {s}  <- line {mln} ({have} of {need} wait states)" for ln, s, mln, _, have, need in found[:10])
-    n_mfma = sum(1 for l in lines if "v_mfma_f32_32x32x16_bf16" in l)
-    assert n_mfma >= 60, "the listing should contain the kernel's unrolled MFMA stream"
+    ks = [k for k in lint.kernels(lines) if key in k[0]]
+    assert ks, "no kernel found in the listing"
+    found = [(name,) + f for name, lo, hi in ks for f in lint.scan(lines, lo, hi)]
+    assert found == [], "\n".join(f"{name[:60]} line {ln}: {s}  <- line {mln} ({have} of {need} wait states)"
+                                   for name, ln, s, mln, _, have, need in found[:10])
+    assert sum(1 for l in lines if "\tv_mfma_f32_" in l) >= min_mfma, "the listing should contain the kernels' MFMA streams"

@@ -12,12 +12,14 @@ cannot schedule in front of it (round 4: a drain without a data dependence on th
 Model: time in issue slots (4 clocks).  Every instruction takes one slot, `s_nop k` takes k + 1; an MFMA cannot ISSUE before
 the matrix pipe has finished accepting the previous one (P slots after that one's issue), which is what makes "two unrelated
 MFMAs in between" a sufficient distance.  P = 8 for the 32x32 shapes, 4 for 16x16 (measured issue intervals).
-The scan is linear over the kernel's listing (no branch following: a hazard that only exists across a loop back-edge is not
-seen; waits and barriers are counted as one slot, i.e. never in the kernel's favour)."""
+The scan is linear over the kernel's listing (fall-through paths only: the state is dropped behind an unconditional branch, a
+hazard that only exists across a taken branch or a loop back-edge is not seen; waits and barriers are counted as one slot, i.e.
+never in the kernel's favour)."""
 import re
 import sys
 
 REG = re.compile(r"\b([va])(\d+)\b|\b([va])\[(\d+):(\d+)\]")
+LOAD_LIKE = ("ds_read", "ds_load", "global_load", "buffer_load", "scratch_load", "flat_load")
 STORE_LIKE = ("global_store", "buffer_store", "scratch_store", "flat_store", "ds_write", "ds_store", "global_atomic", "ds_add")
 
 
@@ -63,6 +65,10 @@ def scan(lines, lo, hi):
         if op == "s_nop":
             t += int(ops[0], 0) + 1
             continue
+        if op in ("s_branch", "s_setpc_b64", "s_endpgm"):      # what follows is reached by jumps only: nothing known in flight
+            inflight = []
+            t += 1
+            continue
         if op.startswith("v_mfma") or op.startswith("v_smfmac"):
             t = max(t, pipe_free)
             p = passes(op)
@@ -71,8 +77,11 @@ def scan(lines, lo, hi):
             inflight = [f for f in inflight if t - f[0] < 64]
             t += 1
             continue
+        # sources and destinations alike (RAW and WAW) -- except the destination of a load: its data arrives hundreds of clocks
+        # later, long after any MFMA in flight has written the register (the allocator re-uses dead accumulators this way)
+        is_load = op.startswith(LOAD_LIKE) and not op.startswith(STORE_LIKE)
         touched = set()
-        for o in (ops if op.startswith(STORE_LIKE) else ops):          # sources and destinations alike (RAW and WAW)
+        for o in (ops[1:] if is_load else ops):
             touched |= regs_of(o)
         if touched:
             for (ti, p, dst, mln, mtext) in inflight:
