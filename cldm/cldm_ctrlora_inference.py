@@ -44,8 +44,10 @@ class ControlNetInference(ControlNet):
             _replace(self, n, SwitchableGroupNorm(m.num_groups, m.num_channels) if isinstance(m, nn.GroupNorm)
                      else SwitchableLayerNorm(m.normalized_shape, m.eps, m.elementwise_affine))
         self._bank_exec = {}
+        self._active_bank = None     # index of the last switch_lora() (None: the holders' own weights, no LoRA)
 
     def switch_lora(self, index: int):
+        self._active_bank = index
         for n, lora in zip(self._linear_names, self.loras_list[index]):
             self.get_submodule(n).set_lora_layer(lora)
         for n, z in zip(self._zero_names, self.zero_convs_list[index]):
@@ -88,8 +90,26 @@ class ControlNetInference(ControlNet):
             self._bank_exec[index] = ex
         return ex
 
+    def _unswitched_state(self):
+        """Before any switch_lora(): the reference's modules then run on their OWN zero-conv / norm weights with no LoRA
+        attached (cldm/switchable.py:17-20,37-40,58-61; cldm/lora.py:286-287)."""
+        skip = ("loras_list.", "zero_convs_list.", "norms_list.", ".lora_layer.", ".conv_layer.", ".norm_layer.")
+        return {k: v for k, v in self.state_dict().items() if not any(s in k for s in skip)}
+
     def forward(self, hint, timesteps, context, **kwargs):
-        raise NotImplementedError("use ControlInferenceLDM.apply_model (per-bank execution) for multi-LoRA inference")
+        """:100-114 -- the 13 zero-conv outputs of the ACTIVE bank (the one of the last switch_lora(i)) for a 4-channel
+        latent hint, NCHW fp32.  Runs that bank's executor, as ControlInferenceLDM.apply_model does per bank."""
+        from ctrlora_amd.engine import ControlNetE, CtrLoRAEngine
+        if self._active_bank is None:
+            ex = self._bank_exec.get(None)
+            if ex is None:
+                ex = ControlNetE(self._unswitched_state(), self.net_cfg(), self._engine_dtype(), self._device(), need_bwd=False)
+                self._bank_exec[None] = ex
+        else:
+            ex = self.bank_executor(self._active_bank)
+        eng = CtrLoRAEngine.__new__(CtrLoRAEngine)
+        eng.cfg, eng.dtype, eng.device, eng.unet, eng.controls = ex.cfg, ex.dtype, ex.device, None, [ex]
+        return eng.control_outputs(hint, timesteps, context, 0)
 
 
 class ControlInferenceLDM(ControlLDM):

@@ -127,6 +127,7 @@ class _PretrainDP:
             self.inner.attach(ex)        # buckets of the base-ControlNet gradients leave from the backward's stage hooks
         self.world_size = self.inner.world_size
         self._enabled = True             # False on non-final gradient-accumulation micro-steps
+        self._mask_sent = False          # this optimizer step's used-bank mask is already on the wire
         self.live = []                   # banks exchanged by the last optimizer step (on every rank)
         self.used = []                   # tasks this rank back-propagated through since its last optimizer step
 
@@ -142,6 +143,11 @@ class _PretrainDP:
     def note_used(self, task):
         if task not in self.used:
             self.used.append(task)
+        if self.enabled and self.inner.world_size > 1 and self.inner._mask_pre is None and not self._mask_sent:
+            # final micro-step of the optimizer step, called at the START of its forward (apply_model /
+            # engine_train_step): the used-bank mask travels while the step computes (BankedGradAllReduce.prefetch_mask)
+            self.inner.prefetch_mask(self.used)
+            self._mask_sent = True
 
     def on_backward_done(self):
         self.note_used(self.cm._task)
@@ -149,6 +155,7 @@ class _PretrainDP:
             return
         self.live = self.inner.exchange(self.used)
         self.used = []
+        self._mask_sent = False
         if self.opt is not None:
             for t in self.live:
                 self.opt.mark_used(t)

@@ -17,7 +17,13 @@ class _Switchable:
                 tgt.bias.data.copy_(self.bias.data)
 
     def forward(self, x):
-        raise RuntimeError(f"{type(self).__name__} holds parameters only; run the enclosing ControlNetInference")
+        """Stand-alone use (cldm/switchable.py:17-20,37-40,58-61): the active bank's layer when one is set, else this
+        holder's own weights -- plain torch modules outside the engine (the enclosing ControlNetInference executes on
+        the HIP executors and never calls this)."""
+        tgt = self._active()
+        if tgt is not None:
+            return tgt(x)
+        return super().forward(x)
 
 
 class SwitchableGroupNorm(_Switchable, nn.GroupNorm):

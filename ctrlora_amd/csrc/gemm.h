@@ -18,7 +18,10 @@ enum GemmAct {
   // GEGLU fused into the projection (attention.py:49-56), inference / no-grad forwards only: W's rows are
   // permuted so that every 160-column tile holds 80 value columns followed by their 80 gate columns; the
   // epilogue writes value * gelu(gate) into C[M, N/2] (ldc).  Needs N % 160 == 0, no rowbias / residual.
-  ACT_GEGLU = 2
+  ACT_GEGLU = 2,
+  // The same fusion for the x-stationary kernel (gemm_xs.hip) ONLY: W's rows stay in their natural order [value (N / 2) | gate
+  // (N / 2)] (attention.py:55: chunk(2, dim=-1)).  Needs K1 in {320, 640}, K2 in {0, 128}, N % 64 == 0; other kernels return CL_EINVAL.
+  ACT_GEGLU_SPLIT = 3
 };
 
 struct GemmParams {
@@ -53,6 +56,9 @@ struct GemmParams {
 };
 
 int launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);
+// x-stationary streaming product (gemm_xs.hip, bf16, launch configuration 34): CL_EINVAL when the product is not one it covers.
+// nsplit: column runs per group (0 = the launcher's rule).
+int launch_gemm_xs(const GemmParams& p, hipStream_t stream, int nsplit);
 // Device scratch for the deterministic split-K path (fp32 partial slabs).  Owned by the host;
 // one workspace per process, used stream-ordered by whichever stream launches the GEMM.
 void gemm_set_workspace(void* p, long bytes);

@@ -1141,7 +1141,7 @@ struct TuneKey {
 static std::map<TuneKey, std::pair<int, int>> g_tune;
 
 int gemm_tune_set(int dtype, int mode, int M, int N, int K1, int K2, int geglu, int cfg, int splitk) {
-  if (cfg < 0 || cfg > 33 || splitk < 0 || splitk > 64) return CL_EINVAL;
+  if (cfg < 0 || cfg > 34 || splitk < 0 || splitk > 64) return CL_EINVAL;
   g_tune[TuneKey{{dtype, mode, M, N, K1, K2, geglu ? 1 : 0}}] = std::make_pair(cfg, splitk);
   return CL_OK;
 }
@@ -1203,6 +1203,7 @@ static int launch_t_cfg(const GemmParams& p, hipStream_t stream, int cfg) {
         case 2: case 3: case 4: case 5: case 23: return 160;
         case 31: case 32: return (lines && p.N % 80 == 0) ? 80 : 128;
         case 33: return (lines && p.N % 320 == 0) ? 320 : 128;
+        case 34: return 32;    // x-stationary kernel: 32-column chunks (its own launcher re-checks the groups)
         default: return lines ? ((c == 8 || c == 12 || c == 14 || c == 16 || c == 18 || c == 20 || c == 10 || c == 25 || c == 27 || c == 29) ? 160 : 128) : 128;
       }
     };
@@ -1294,6 +1295,15 @@ static int launch_t_cfg(const GemmParams& p, hipStream_t stream, int cfg) {
         return launch_cfg<T, 128, 128, 2, 2, 2, 4>(p, stream);
       return launch_fl<T, 128, 320, 2, 4, 2>(p, stream);
     }
+    case 34: {   // x-stationary streaming kernel (gemm_xs.hip): wide-N / short-K linears, K in {320, 640} (+ 128); the table's
+      // split column carries its column-run count.  Anything it does not cover takes the rules above.
+      if constexpr (sizeof(T) == 2) {
+        const int rc = launch_gemm_xs(p, stream, t_force_sk);
+        if (rc != CL_EINVAL) return rc;
+      }
+      t_force_sk = 0;
+      return launch_t_cfg<T>(p, stream, -1);
+    }
     // small-M tiles of the generic kernel (8x8 / 16x16 levels, text-context projections): offered to the tuner
     case 22: return launch_cfg<T, 64, 128, 2, 2, 1, 4>(p, stream);
     case 23: return launch_cfg<T, 64, 160, 2, 2, 1, 4>(p, stream);
@@ -1312,6 +1322,8 @@ int launch_gemm(const GemmParams& p, int dtype, hipStream_t stream) {
   if (p.atomic == 0 && p.splitk > 1) return CL_EINVAL;
   if (p.rowbias && p.rows_per_batch <= 0) return CL_EINVAL;
   if (p.act == ACT_GEGLU && (p.N % 160 || p.rowbias || p.residual || p.atomic || p.alpha != 1.0f)) return CL_EINVAL;
+  if (p.act == ACT_GEGLU_SPLIT)   // natural-order GEGLU rows: the x-stationary kernel's contract only (gemm_xs.hip)
+    return dtype == CL_BF16 ? launch_gemm_xs(p, stream, g_gemm_force_splitk) : CL_EINVAL;
   if (p.a1_group_n < 0 || p.a2_group_n < 0) return CL_EINVAL;
   if (p.alpha_n < 0 || p.alpha_n % 8 || p.alpha_n > p.N || (p.alpha_n && p.act == ACT_GEGLU)) return CL_EINVAL;
   if ((p.a1_group_n || p.a2_group_n) && p.mode != GEMM_LINEAR) return CL_EINVAL;

@@ -571,10 +571,21 @@ class SpatialTransformerE:
         n2, s2 = self.ln2.fwd(ctx, h1)
         h2, sv2 = self.attn2.fwd(ctx, n2, c, B, N, Nkv, residual=h1, kv_cache=kv_cache)
         n3, s3 = self.ln3.fwd(ctx, h2)
-        if not ctx.record and self.ff_proj.geglu_ok():
+        L = self.ff_proj
+        if (not ctx.record and ctx.dtype == torch.bfloat16 and L.N % 64 == 0
+                and hip.xs_geglu_ok(B * N, L.K, 0 if L.Wm is not None else L.r)):
+            # the same fusion on the x-stationary kernel (csrc/gemm_xs.hip): W's rows in their natural [value | gate] order
+            tp = None
+            if L.r and L.Wm is None:
+                tp = ctx.new(B * N, L.r)
+                hip.gemm(n3, L.A, tp)
+            gg = ctx.new(B * N, 4 * self.C)
+            hip.gemm(n3, L.W if L.Wm is None else L.Wm, gg, a2=tp, w2=L.B if tp is not None else None, bias=L.bias,
+                     act=hip.ACT_GEGLU_SPLIT, N=L.N)
+            p = None
+        elif not ctx.record and self.ff_proj.geglu_ok():
             # no backward will need the 8C-wide pre-activation: value * gelu(gate) is formed in the projection's
             # epilogue (half the output bytes, no separate GEGLU pass)
-            L = self.ff_proj
             Wg, bg, Bg = L.geglu_pack()
             tp = None
             if Bg is not None:

@@ -421,6 +421,8 @@ class ControlNetE:
         # the last encoder stage: their LoRA gradients are final only then, so their trainables move from their blocks' stages
         # to the tail of the flat buffer, next to time_embed (the data-parallel hook reports a span when it is final).
         self.emb_sum = 0
+        # order of rounds 1-3 (no hoist): optimizer states of those builds were saved as ONE flat tensor in this order
+        self.legacy_item_names = [t.name for t in self.tr.items]
         if self.emb_groups and HOIST_EMB_BWD:
             hoisted = set()
             for grp, ls in self.emb_groups:

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libctrlora_hip.so")
 
 BF16, F32 = 0, 1
 LINEAR, CONV_S1, CONV_S2, CONV_UP2, CONV_T2, CONV_S2A = 0, 1, 2, 3, 4, 5
-ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_GEGLU_SPLIT = 0, 1, 2, 3
 
 
 class HipError(RuntimeError):
@@ -142,10 +142,25 @@ def lib():
             L.cl_debug_groupnorm_form(int(gn3), int(gn1))
         if os.environ.get("CTRLORA_GEMM_TUNED", "1") != "0":
             load_gemm_table(os.environ.get("CTRLORA_GEMM_TABLE", GEMM_TABLE_PATH))
+            if XS_ENABLED:      # round 5: signatures the x-stationary kernel (csrc/gemm_xs.hip, configuration 34) won
+                load_gemm_table(GEMM_XS_TABLE_PATH, clear=False)
     return _lib
 
 
 GEMM_TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tuned_gfx950.json")
+GEMM_XS_TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tuned_gfx950_xs.json")
+# A/B switch: 0 = no product goes to the x-stationary streaming kernel (neither through the launch table nor as the fused
+# GEGLU projection of the no-grad forwards)
+XS_ENABLED = os.environ.get("CTRLORA_GEMM_XS", "1") != "0"
+
+
+def xs_geglu_ok(M: int, K: int, r: int) -> bool:
+    """Does the fused GEGLU projection of a no-grad forward go to the x-stationary kernel (act = ACT_GEGLU_SPLIT, natural row
+    order)?  Measured against the tile kernels' fused GEGLU (profiles/r05_gemm_xs/probe_xs_res_geglu.log): K = 320 wins at
+    every M (91 vs 102 us at 32768 rows, 310 vs 450 at 131072), K = 640 from 16384 rows (305 vs 339 us at 32768; 89 vs 78 at 8192)."""
+    if not XS_ENABLED or r not in (0, 128):
+        return False
+    return (K == 320 and M >= 128) or (K == 640 and M >= 16384)
 
 
 def load_gemm_table(path: str, clear: bool = True) -> int:

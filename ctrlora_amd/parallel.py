@@ -121,7 +121,13 @@ class BankedGradAllReduce:
         self.tasks = list(banks.keys())
         self.banks = dict(banks)
         self.bucket_elems = max(1, bucket_bytes // 4)
+        # The LoRA banks may travel in bf16 (CTRLORA_DP_PAYLOAD=bf16, as in fine-tuning); the SHARED base-ControlNet gradients
+        # stay fp32 unless CTRLORA_DP_PAYLOAD_SHARED=bf16 opts them in as well (they went out in fp32 unconditionally
+        # before the overlapped form existed)
         self.payload_dtype = payload_dtype if payload_dtype is not None else payload_dtype_from_env()
+        import os
+        self.shared_payload_dtype = payload_dtype if payload_dtype is not None else (
+            torch.bfloat16 if os.environ.get("CTRLORA_DP_PAYLOAD_SHARED", "f32").lower() in ("bf16", "bfloat16") else None)
         # overlapped form (attach): buckets of the backward-ordered shared buffer launched from the executor's
         # stage-completion hook, as GradAllReduce does for fine-tuning
         self._ex = None
@@ -129,8 +135,14 @@ class BankedGradAllReduce:
         self._pending: List = []
         self.enabled = True
         self.launches = 0                 # bucket all-reduces issued by the hook since the last exchange()
+        self.last_launches = 0            # ... during the step the last exchange() closed
         self.launches_before_last_stage = 0
         self.exposed_tail_elems = 0       # elements of the shared buffer that were reduced only in exchange()
+        # "which banks are live on ANY rank" (prefetch_mask): exchanged while the step computes, read without a stream sync
+        self._mask_pre = None
+        self._mask_stream = None
+        self._mask_host = None
+        self.mask_prefetch_hits = 0
 
     def attach(self, executor):
         """Overlap the exchange of the base-ControlNet gradients (360 M floats at SD1.5 width: ~1.4 GB fp32 -- the reference's
@@ -144,18 +156,85 @@ class BankedGradAllReduce:
         executor.on_stage_done = self._stage_done
         return self
 
+    def reset(self):
+        """Drop the hook's per-step state: wait for (and forget) every bucket already in flight, rewind the cursor.  Called at
+        the start of every backward pass (an aborted backward, or `enabled` flipped off after buckets went out, must not leave
+        a stale cursor: part of the buffer would be reduced twice and part skipped in the next step)."""
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+        self._lo = self._hi = 0
+        self.launches = 0
+        self.launches_before_last_stage = 0
+
+    def __setattr__(self, name, value):
+        if name == "enabled" and not value and getattr(self, "_pending", None):
+            object.__setattr__(self, name, value)
+            self.reset()
+            return
+        object.__setattr__(self, name, value)
+
     def _stage_done(self, start, end):
         if not self.enabled or self.world_size == 1 or self._ex is None:
             return
+        if start == 0 and (self._lo or self._hi or self._pending):
+            self.reset()                    # first stage of a new backward (offset 0) with leftovers of an unfinished one
         if start == self._last_stage_start:
             self.launches_before_last_stage = self.launches
         if start != self._hi:
             return                          # out-of-order report: left to exchange()
         self._hi = end
         if self._hi - self._lo >= self.bucket_elems:
-            self._pending.append(all_reduce_slice(self._ex.tr.flat_grad[self._lo:self._hi], self.group, self.payload_dtype))
+            self._pending.append(all_reduce_slice(self._ex.tr.flat_grad[self._lo:self._hi], self.group, self.shared_payload_dtype))
             self.launches += 1
             self._lo = self._hi
+
+    @torch.no_grad()
+    def prefetch_mask(self, used_tasks):
+        """Start the MAX all-reduce of the used-bank mask BEFORE the forward pass of the final micro-step -- the tasks a rank
+        trains in an optimizer step are known when its last batch is drawn (datasets/multi_task_scheduler.py:45-59) -- and
+        land the result in pinned host memory from a side stream.  exchange() then reads it after one event wait that has
+        long been satisfied, instead of a `mask.tolist()` that blocks the host until the whole backward has drained and
+        leaves the GPU idle while the collectives are launched.  A COLLECTIVE: every rank calls it at the same point."""
+        if self.world_size == 1:
+            return
+        used = frozenset(used_tasks)
+        assert used <= set(self.tasks), f"unknown task(s) {sorted(used - set(self.tasks))}"
+        if self._mask_pre is not None:
+            if self._mask_pre[0] == used:
+                return
+            raise RuntimeError("the used-task set changed after its mask exchange was started; ranks would diverge")
+        ref = self.shared[0] if self.shared else next(iter(self.banks.values()))
+        mask = torch.tensor([1 if t in used else 0 for t in self.tasks], dtype=torch.int32, device=ref.device)
+        work = dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
+        if mask.is_cuda:
+            if self._mask_stream is None:
+                self._mask_stream = torch.cuda.Stream(device=mask.device)
+                self._mask_host = torch.empty(len(self.tasks), dtype=torch.int32).pin_memory()
+            with torch.cuda.stream(self._mask_stream):
+                work.wait()                                  # stream-level: the side stream waits for the collective
+                self._mask_host.copy_(mask, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._mask_stream)
+            self._mask_pre = (used, mask, ev, True)
+        else:
+            self._mask_pre = (used, mask, work, False)
+
+    def _live_mask(self, used):
+        pre, self._mask_pre = self._mask_pre, None
+        if pre is not None:
+            if pre[0] != frozenset(used):
+                raise RuntimeError("exchange() got a different used-task set than prefetch_mask(); ranks would diverge")
+            self.mask_prefetch_hits += 1
+            if pre[3]:
+                pre[2].synchronize()
+                return self._mask_host.tolist()
+            pre[2].wait()
+            return pre[1].tolist()
+        ref = self.shared[0] if self.shared else next(iter(self.banks.values()))
+        mask = torch.tensor([1 if t in used else 0 for t in self.tasks], dtype=torch.int32, device=ref.device)
+        dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)
+        return mask.tolist()
 
     @torch.no_grad()
     def exchange(self, used_tasks) -> List[str]:
@@ -163,17 +242,14 @@ class BankedGradAllReduce:
         assert used <= set(self.tasks), f"unknown task(s) {sorted(used - set(self.tasks))}"
         if self.world_size == 1:
             return [t for t in self.tasks if t in used]
-        ref = self.shared[0] if self.shared else next(iter(self.banks.values()))
-        mask = torch.tensor([1 if t in used else 0 for t in self.tasks], dtype=torch.int32, device=ref.device)
-        dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)
-        live = [t for t, m in zip(self.tasks, mask.tolist()) if m]
+        live = [t for t, m in zip(self.tasks, self._live_mask(used)) if m]
         work = list(self._pending)
         self._pending = []
         if self._ex is not None:            # the part of the shared buffer the hook has not launched yet
             n = self._ex.tr.flat_grad.numel()
             self.exposed_tail_elems = n - self._lo
             if self._lo < n:
-                work.append(all_reduce_slice(self._ex.tr.flat_grad[self._lo:n], self.group, self.payload_dtype))
+                work.append(all_reduce_slice(self._ex.tr.flat_grad[self._lo:n], self.group, self.shared_payload_dtype))
             self._lo = self._hi = 0
         else:
             work += [dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for buf in self.shared]

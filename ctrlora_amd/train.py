@@ -160,12 +160,31 @@ class FusedAdamW(torch.optim.Optimizer):
                         raise KeyError(f"optimizer state lacks {len(missing)} tensors, e.g. {missing[:3]}")
                     for t in ex.tr.items:
                         dst[t.offset:t.offset + t.master.numel()].copy_(src[t.name].reshape(-1))
-                else:       # rounds 1-3: one flat tensor in the flat buffer's order of the build that wrote it
-                    if getattr(ex, "emb_sum", 0):
-                        raise RuntimeError("this optimizer state was saved in flat-buffer order by an older build; resume it "
-                                           "with CTRLORA_HOIST_EMB_BWD=0 (that build's order) and save again")
-                    dst.copy_(src)
+                else:       # rounds 1-3: ONE flat tensor in the flat buffer's order of the build that wrote it (no emb hoist)
+                    _load_legacy_flat(ex, dst, src)
         _restore_param_groups(self, sd)
+
+
+def _load_legacy_flat(ex, dst, src):
+    """A flat moment tensor saved by rounds 1-3 -> this build's layout.  Those builds laid the trainables out in
+    `ex.legacy_item_names` order (backward-completion order without the emb_layers hoist), every tensor padded to 64 floats
+    (packing.TrainableSet.materialize); the tensors are found by walking that order and copied to today's offsets."""
+    from .engine.packing import rup
+    names = getattr(ex, "legacy_item_names", None) or [t.name for t in ex.tr.items]
+    by_name = {t.name: t for t in ex.tr.items}
+    if sorted(names) != sorted(by_name):
+        raise KeyError("the legacy optimizer state does not describe this model's trainable set")
+    off = 0
+    spans = []
+    for n in names:
+        k = by_name[n].master.numel()
+        spans.append((by_name[n], off, k))
+        off += rup(k, 64)
+    if off != src.numel():
+        raise ValueError(f"legacy optimizer state holds {src.numel()} floats, the legacy layout of this model has {off}")
+    src = src.reshape(-1)
+    for t, o, k in spans:
+        dst[t.offset:t.offset + k].copy_(src[o:o + k])
 
 
 def _restore_param_groups(opt, sd):
@@ -244,18 +263,33 @@ class PretrainAdamW(torch.optim.Optimizer):
             hip.zero_(self.banks[task].flat_grad)
 
     def state_dict(self):
-        pack = lambda st: dict(m=st["m"].clone(), v=st["v"].clone(), step=int(st["step"].item()))
-        return dict(base=pack(self._base), banks={k: pack(v) for k, v in self._bank_state.items()}, active=list(self.active),
+        """Moments BY PARAMETER NAME (format 2), like FusedAdamW: the flat buffers' order is a detail of a build."""
+        def pack(ts, st):
+            by = lambda buf: {t.name: buf[t.offset:t.offset + t.master.numel()].clone() for t in ts.items}
+            return dict(m=by(st["m"]), v=by(st["v"]), step=int(st["step"].item()))
+        return dict(format="by_name", version=2, base=pack(self.executor.tr, self._base),
+                    banks={k: pack(self.banks[k], v) for k, v in self._bank_state.items()}, active=list(self.active),
                     param_groups=[{k: v for k, v in g.items() if k != "params"} for g in self.param_groups])
 
     def load_state_dict(self, sd):
-        def unpack(st, src):
-            st["m"].copy_(src["m"]); st["v"].copy_(src["v"]); st["step"].fill_(int(src["step"]))
+        def unpack(ts, st, src):
+            for key in ("m", "v"):
+                if isinstance(src[key], dict):
+                    missing = [t.name for t in ts.items if t.name not in src[key]]
+                    if missing:
+                        raise KeyError(f"optimizer state lacks {len(missing)} tensors, e.g. {missing[:3]}")
+                    for t in ts.items:
+                        st[key][t.offset:t.offset + t.master.numel()].copy_(src[key][t.name].reshape(-1))
+                else:       # format 1 (rounds 2-4): raw flat buffers; only valid for an unchanged layout -- check what can be checked
+                    if src[key].numel() != st[key].numel():
+                        raise ValueError(f"flat optimizer state of {src[key].numel()} floats does not fit this build's {st[key].numel()}")
+                    st[key].copy_(src[key])
+            st["step"].fill_(int(src["step"]))
         if set(sd["banks"]) != set(self._bank_state):
             raise KeyError(f"optimizer state holds banks {sorted(sd['banks'])}, the model has {sorted(self._bank_state)}")
-        unpack(self._base, sd["base"])
+        unpack(self.executor.tr, self._base, sd["base"])
         for k, src in sd["banks"].items():
-            unpack(self._bank_state[k], src)
+            unpack(self.banks[k], self._bank_state[k], src)
         self.active = list(sd["active"])
         _restore_param_groups(self, sd)
 

@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 /* the version this header describes; cl_abi_version() returns the one the loaded library was built from */
-#define CL_ABI_VERSION 6
+#define CL_ABI_VERSION 7
 int cl_abi_version(void);
 /* the hipError_t behind the most recent CL_ELAUNCH return (diagnostics) */
 int cl_last_hip_error(void);
@@ -55,7 +55,7 @@ int cl_gemm_force_config(int cfg);
 /* tuning hook: impose the split-K factor of the workspace path on every following contraction (0 = built-in rule) */
 int cl_gemm_force_splitk(int splitk);
 /* Measured launch table: the contraction with this signature (dtype CL_BF16/CL_F32, cl_gemm_mode, M, N, K1, K2,
- * geglu = GEGLU epilogue) is launched with tile configuration `cfg` and split-K factor `splitk` (0 = built-in rule
+ * geglu = GEGLU epilogue (act 2)) is launched with tile configuration `cfg` and split-K factor `splitk` (0 = built-in rule
  * for the factor) instead of the built-in choice.  The host loads ctrlora_amd/gemm_tuned_gfx950.json (written by
  * tools/gemm_autotune.py from timings on an MI355X) through this entry at start-up; signatures not in the table
  * keep the built-in rules, and every configuration re-checks its own preconditions at launch. */
@@ -94,7 +94,10 @@ typedef struct cl_gemm_params {
   const void* rowbias; long ldrb; int rows_per_batch;
   const void* residual; long ldr;
   float alpha, beta;
-  int act;                            /* 0 none, 1 SiLU                                      */
+  int act;                            /* 0 none, 1 SiLU, 2 GEGLU (value / gate rows of W interleaved per 160-row tile, C is
+                                         [M, N/2]: ldm/modules/attention.py:49-56 fused into the projection; no-grad forwards),
+                                         3 (ABI 7) the same fusion with W's rows in their natural [value | gate] order:
+                                         bf16, K1 in {320, 640}, K2 in {0, 128}, N % 64 == 0 only -- CL_EINVAL otherwise   */
   void* C; long ldc;
   int out_f32;                        /* store fp32 regardless of dtype                      */
   int atomic;                         /* fp32 atomicAdd into C (gradient accumulation)       */

@@ -130,3 +130,38 @@ def test_checkpoint_readers_and_create_model(tmp_path):
     path.write_text(yaml.safe_dump(cfg))
     model = create_model(str(path))
     assert type(model).__name__ == "ControlFinetuneLDM" and next(model.parameters()).device.type == "cpu"
+
+
+def test_switchable_holders_run_standalone_and_inference_net_tracks_the_active_bank():
+    """cldm/switchable.py:17-20,37-40,58-61: a holder runs its active bank's layer, or its own weights when none is set;
+    ControlNetInference.switch_lora(i) records the bank that ControlNetInference.forward executes
+    (cldm/cldm_ctrlora_inference.py:100-130)."""
+    import torch.nn as nn
+    from cldm.switchable import SwitchableConv2d, SwitchableGroupNorm, SwitchableLayerNorm
+    x = torch.randn(2, 4, 5, 6)
+    conv = SwitchableConv2d(4, 8, 1)
+    assert torch.allclose(conv(x), nn.functional.conv2d(x, conv.weight, conv.bias))
+    bank = nn.Conv2d(4, 8, 1)
+    conv.set_conv_layer(bank)
+    assert torch.equal(conv(x), bank(x))
+    gn, gbank = SwitchableGroupNorm(2, 4), nn.GroupNorm(2, 4)
+    gbank.weight.data.fill_(3.0)
+    assert torch.allclose(gn(x), nn.functional.group_norm(x, 2, gn.weight, gn.bias, gn.eps))
+    gn.set_norm_layer(gbank)
+    assert torch.equal(gn(x), gbank(x))
+    ln, lbank = SwitchableLayerNorm(6), nn.LayerNorm(6)
+    lbank.bias.data.fill_(0.5)
+    ln.set_norm_layer(lbank)
+    assert torch.equal(ln(x), lbank(x))
+    ln.weight.data.fill_(2.0)
+    ln.copy_weights()
+    assert torch.equal(lbank.weight.data, ln.weight.data)
+    from cldm.cldm_ctrlora_inference import ControlNetInference
+    a = _cfg("inference/ctrlora_sd15_rank128_2loras.yaml")["model"]["params"]["control_stage_config"]["params"]
+    net = ControlNetInference(**{**_tiny(a), "lora_rank": 8, "lora_num": 2})
+    assert net._active_bank is None
+    net.switch_lora(1)
+    assert net._active_bank == 1
+    lin = net.get_submodule(net._linear_names[0])
+    assert lin.lora_layer is net.loras_list[1][0]
+    assert "forward" in ControlNetInference.__dict__      # the module itself is callable after switch_lora (GPU test: test_gpu_parity.py)

@@ -413,6 +413,17 @@ def test_inference_and_pretrain_drop_in_classes_match_reference_goldens():
     with torch.no_grad():
         eps = m.apply_model(cu(inp["z"]), cu(inp["t"]), conds)
     assert rel_l2(eps, g["eps_multi"]) < 1e-4
+    # ControlNetInference.forward (reference :100-114): after switch_lora(i) the module itself runs bank i
+    from oracle import ref_model
+    bank_sd = [sd_a, {k: (sd_5[k] if arch.is_trainable(k) else v) for k, v in sd_a.items()}]
+    for i in (1, 0):
+        m.control_model.switch_lora(i)
+        with torch.no_grad():
+            outs = m.control_model(cu(inp["hint_z"]), cu(inp["t"]), cu(inp["ctx"]))
+        want = ref_model.controlnet_forward(bank_sd[i], cfg, inp["hint_z"], inp["t"], inp["ctx"])
+        assert len(outs) == len(want) == 13
+        for k, (o, w) in enumerate(zip(outs, want)):
+            assert rel_l2(o, w) < 1e-4, (i, k)
     del m
     # ---- pre-train model: the task named in cond selects the LoRA bank
     pt = bench.build_model("ctrlora_pretrain_sd15_9tasks_rank128.yaml", 0, tiny=True)

@@ -239,10 +239,10 @@ def _pretrain_dp_worker(rank, world, port, q):
                     tot[task] = gt if tot[task] is None else tot[task] + gt
                     if r == rank:                       # this rank's own backward
                         cm._task = task
-                        opt.mark_used(task); dp.note_used(task)
-                        cm.executor().tr.flat_grad += gb
+                        dp.enabled = micro == 1             # the trainer sets it BEFORE the micro-step's forward (trainer.py:142)
+                        opt.mark_used(task); dp.note_used(task)     # (apply_model: start of the forward; the final micro-step
+                        cm.executor().tr.flat_grad += gb            #  puts the used-bank mask on the wire here)
                         cm.bank(task).flat_grad += gt
-                        dp.enabled = micro == 1
                         dp.on_backward_done()
             opt.step(); opt.zero_grad()
             for k, p in ref_p.items():
@@ -262,6 +262,7 @@ def _pretrain_dp_worker(rank, world, port, q):
         dist.all_gather(got, blob)
         ok &= all(torch.equal(got[0], g) for g in got[1:])
         ok &= [int(opt._bank_state[t]["step"]) for t in cm.tasks] == [4, 4, 4] and sorted(opt.active) == sorted(cm.tasks)
+        ok &= dp.inner.mask_prefetch_hits == len(_SCHED[0])      # every optimizer step read the mask it had sent ahead
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

@@ -52,7 +52,7 @@ class Recorder:
             # grouped second segment (a2_group_n): the launcher's signature carries the per-group K2 = columns of W2
             k2 = 0 if a2 is None else (kw["w2"].shape[1] if kw.get("a2_group_n") else a2.shape[1])
             geglu = 1 if kw.get("act", 0) == hip.ACT_GEGLU else 0
-            if not kw.get("atomic", False):
+            if not kw.get("atomic", False) and kw.get("act", 0) != hip.ACT_GEGLU_SPLIT:   # (act 3 has one kernel: nothing to choose)
                 key = (hip.dt(a1), int(mode), int(M), int(N), int(k1), int(k2), geglu)
                 e = self.calls.get(key)
                 if e is None:
@@ -113,6 +113,8 @@ def candidates(key):
         if c in W128 and N % 128 and N % 160 == 0:
             continue                      # keep the tile width the heuristic would use for this N
         cfgs.append(c)
+    if mode == hip.LINEAR and K1 in (320, 640) and K2 in (0, 128) and N % 32 == 0 and M >= 128:
+        cfgs.append(34)                   # x-stationary streaming kernel (gemm_xs.hip); its split column = column runs per group
     if geglu:
         cfgs = [c for c in cfgs if c in GEGLU_OK]
     steps = (taps * K1 + K2) // 64
@@ -237,7 +239,7 @@ def main():
         base = time_us(run, args.reps)
         cfgs, sks = candidates(key)
         if only is not None:
-            cfgs, sks = only, [0, 1, 2]
+            cfgs, sks = only, ([0, 1, 2, 4] if 34 in only else [0, 1, 2])
         best = (base, -1, 0)
         per_cfg = []
         for c in cfgs:                                   # tile configuration at the launcher's own split rule

@@ -88,6 +88,96 @@ static void case_linear(const char* name, int dtype, int M, int N, int K1, int K
   report(name, num, den, odt == CL_BF16 ? 4e-3 : 2e-5);
 }
 
+// ---------------- x-stationary streaming kernel (configuration 34, gemm_xs.hip) ----------------
+// groups > 1: output columns [g N / groups, (g + 1) N / groups) take their second K segment from columns [g K2, (g + 1) K2) of A2
+static float g_xs_beta = 0.f;      // != 0: the next case_xs adds beta * residual
+static bool g_xs_geglu = false;    // the next case_xs is a fused GEGLU projection (N = value | gate rows, output N / 2 columns)
+static void case_xs(const char* name, int M, int N, int K1, int K2, bool bias, int groups, float alpha, int alpha_n, int nsplit,
+                    bool timeit = false) {
+  const int dtype = CL_BF16;
+  const float beta = g_xs_beta; const bool geglu = g_xs_geglu;
+  const int NO = geglu ? N / 2 : N;     // output columns
+  Buf A1, W1, A2, W2, C, C2, R; std::vector<float> hb(N);
+  if (beta != 0.f) R.init((size_t)M * NO, dtype);
+  A1.init((size_t)M * K1, dtype); W1.init((size_t)N * K1, dtype, 0.1f);
+  if (K2) { A2.init((size_t)M * K2 * groups, dtype); W2.init((size_t)N * K2, dtype, 0.1f); }
+  float* dbias = nullptr;
+  if (bias) { for (auto& v : hb) v = frand(); HIPCHK(hipMalloc(&dbias, N * 4)); HIPCHK(hipMemcpy(dbias, hb.data(), N * 4, hipMemcpyHostToDevice)); }
+  C.init((size_t)M * NO, dtype, 1.0f, true); C2.init((size_t)M * NO, dtype, 1.0f, true);
+  GemmParams p{}; p.A1 = A1.d; p.lda1 = K1; p.K1 = K1; p.W1 = W1.d; p.ldw1 = K1;
+  if (K2) { p.A2 = A2.d; p.lda2 = K2 * groups; p.K2 = K2; p.W2 = W2.d; p.ldw2 = K2; if (groups > 1) p.a2_group_n = N / groups; }
+  p.M = M; p.N = N; p.mode = GEMM_LINEAR; p.zero_page = g_zero; p.bias = dbias;
+  p.alpha = alpha; p.alpha_n = alpha_n; p.C = C.d; p.ldc = NO; p.splitk = 1;
+  if (beta != 0.f) { p.residual = R.d; p.ldr = NO; p.beta = beta; }
+  if (geglu) p.act = ACT_GEGLU_SPLIT;
+  HIPCHK(hipMemset(C.d, 0xff, (size_t)M * NO * 2));
+  const int rc = launch_gemm_xs(p, 0, nsplit);
+  HIPCHK(hipDeviceSynchronize());
+  if (rc) { printf("[FAIL] %s rc=%d\n", name, rc); g_fail++; return; }
+  C.download(dtype);
+  double num = 0, den = 0;
+  const int rows_checked = M <= 2048 ? M : 96;
+  for (int t = 0; t < rows_checked; ++t) {
+    const int m = M <= 2048 ? t : (int)(((long)t * 7919 + (t % 3 == 0 ? M - 1 - t : 13)) % M);
+    auto dotrow = [&](int n) {
+      double s = 0;
+      const int g = groups > 1 ? n / (N / groups) : 0;
+      for (int k = 0; k < K1; ++k) s += (double)A1.h[(size_t)m * K1 + k] * W1.h[(size_t)n * K1 + k];
+      for (int k = 0; k < K2; ++k) s += (double)A2.h[(size_t)m * K2 * groups + g * K2 + k] * W2.h[(size_t)n * K2 + k];
+      if (bias) s += hb[n];
+      return s;
+    };
+    for (int n = 0; n < NO; ++n) {
+      double s = dotrow(n);
+      if (geglu) { const double g = dotrow(NO + n); s *= 0.5 * g * (1.0 + std::erf(g * 0.70710678118654752440)); }
+      else if (!(alpha_n > 0 && n >= alpha_n)) s *= alpha;
+      if (beta != 0.f) s += (double)beta * R.h[(size_t)m * NO + n];
+      const double d = C.h[(size_t)m * NO + n] - s; num += d * d; den += s * s;
+    }
+  }
+  report(name, num, den, 4e-3);
+  // bitwise repeatability + agreement with the tile kernels on the same parameters
+  std::vector<uint16_t> r0((size_t)M * NO), r1((size_t)M * NO);
+  HIPCHK(hipMemcpy(r0.data(), C.d, r0.size() * 2, hipMemcpyDeviceToHost));
+  int diff = 0;
+  for (int rep = 0; rep < 3; ++rep) {
+    HIPCHK(hipMemset(C.d, 0xff, (size_t)M * NO * 2));
+    launch_gemm_xs(p, 0, nsplit);
+    HIPCHK(hipMemcpy(r1.data(), C.d, r1.size() * 2, hipMemcpyDeviceToHost));
+    diff += memcmp(r0.data(), r1.data(), r0.size() * 2) != 0;
+  }
+  p.C = C2.d;
+  const int keep = g_gemm_force_cfg; g_gemm_force_cfg = -1;
+  if (!geglu) launch_gemm(p, dtype, 0);       // (the tile kernels' GEGLU wants permuted rows: no cross-check there)
+  g_gemm_force_cfg = keep;
+  HIPCHK(hipDeviceSynchronize());
+  C2.download(dtype);
+  double n2 = 0, d2 = 0;
+  if (!geglu) for (size_t i = 0; i < (size_t)M * NO; ++i) { const double d = C.h[i] - C2.h[i]; n2 += d * d; d2 += (double)C2.h[i] * C2.h[i]; }
+  printf("       repeat launches differing: %d of 3; vs tile kernels rel_l2 %.2e%s\n", diff, std::sqrt(n2 / (d2 + 1e-30)),
+         (diff || std::sqrt(n2 / (d2 + 1e-30)) > 4e-3) ? "  <-- FAIL" : "");
+  if (diff || std::sqrt(n2 / (d2 + 1e-30)) > 4e-3) g_fail++;
+  if (timeit) {
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    auto timed = [&](int cfg) {
+      float best = 1e9f;
+      for (int rep = 0; rep < 4; ++rep) {
+        HIPCHK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 20; ++i) { if (cfg == 34) launch_gemm_xs(p, 0, nsplit); else launch_gemm(p, dtype, 0); }
+        HIPCHK(hipEventRecord(e1, 0)); HIPCHK(hipEventSynchronize(e1));
+        float ms; HIPCHK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms / 20);
+      }
+      return best * 1e3;
+    };
+    const double fl = 2.0 * M * N * (K1 + K2);
+    const float t_xs = timed(34), t_tile = geglu ? 0.f : timed(-1);
+    printf("[TIME] %-44s xs %7.2f us (%6.1f TF/s)   tile kernels (rules) %7.2f us\n", name, t_xs, fl / t_xs * 1e-6, t_tile);
+  }
+  hipFree(A1.d); hipFree(W1.d); hipFree(C.d); hipFree(C2.d); if (K2) { hipFree(A2.d); hipFree(W2.d); } if (dbias) hipFree(dbias);
+  if (R.d) hipFree(R.d);
+  g_xs_beta = 0.f; g_xs_geglu = false;
+}
+
 // ---------------- GEGLU-fused projection ----------------
 static void case_geglu(const char* name, int dtype, int M, int half, int K1, int K2, bool out_f32) {
   const int N = 2 * half;
@@ -393,7 +483,64 @@ int main(int argc, char** argv) {
       time_case("gemm bf16 131072x2560x1280 no stores", CL_BF16, GEMM_LINEAR, 131072, 2560, 1280, 0, 0, 0);
       g_probe_act = 0;
     }
+    if (which == 5) {   // round 5: the training-batch wide-N / short-K products, with and without their stores
+      const int sh[][3] = {{32768, 2560, 320}, {32768, 1280, 320}, {32768, 960, 320}, {8192, 5120, 640}, {2048, 10240, 1280}};
+      for (auto& q : sh) {
+        g_probe_act = 0;  time_case("gemm bf16 wide-N normal", CL_BF16, GEMM_LINEAR, q[0], q[1], q[2], 0, 0, 0);
+        g_probe_act = 77; time_case("gemm bf16 wide-N no stores", CL_BF16, GEMM_LINEAR, q[0], q[1], q[2], 0, 0, 0);
+      }
+      g_probe_act = 0;
+    }
     return 0;
+  }
+  if (argc > 1 && !strcmp(argv[1], "--xs")) {   // x-stationary kernel: correctness on ragged / grouped cases, then the production shapes
+    case_xs("xs 300x320x320 bias", 300, 320, 320, 0, true, 1, 1.f, 0, 0);
+    case_xs("xs 1000x960x320+128 groups 3 alpha_n", 1000, 960, 320, 128, true, 3, 0.37f, 320, 0);
+    case_xs("xs 129x64x320 no bias alpha", 129, 64, 320, 0, false, 1, 0.5f, 0, 0);
+    case_xs("xs 640x2560x320+128 nsplit 4", 640, 2560, 320, 128, true, 1, 1.f, 0, 4);
+    case_xs("xs 2048x3200x320 (run > 80 chunks)", 2048, 3200, 320, 0, true, 1, 1.f, 0, 1);
+    case_xs("xs 500x1920x640 groups 3", 500, 1920, 640, 0, true, 1, 0.25f, 640, 0);
+    case_xs("xs 384x1280x640+128 groups 2", 384, 1280, 640, 128, true, 2, 1.f, 0, 0);
+    case_xs("xs 256x5120x640+128", 256, 5120, 640, 128, true, 1, 1.f, 0, 0);
+    g_xs_beta = 1.0f;  case_xs("xs res 300x320x320 bias beta 1", 300, 320, 320, 0, true, 1, 1.f, 0, 0);
+    g_xs_beta = -0.5f; case_xs("xs res 1000x320x320+128 alpha", 1000, 320, 320, 128, true, 1, 0.7f, 0, 2);
+    g_xs_beta = 1.0f;  case_xs("xs res 515x640x640+128", 515, 640, 640, 128, true, 1, 1.f, 0, 0);
+    g_xs_beta = 2.0f;  case_xs("xs res 640x1280x640 nsplit 4", 640, 1280, 640, 0, false, 1, 1.f, 0, 4);
+    g_xs_geglu = true; case_xs("xs geglu 300x(2*320)x320", 300, 640, 320, 0, true, 1, 1.f, 0, 0);
+    g_xs_geglu = true; case_xs("xs geglu 1000x(2*1280)x320+128", 1000, 2560, 320, 128, true, 1, 1.f, 0, 0);
+    g_xs_geglu = true; case_xs("xs geglu 384x(2*2560)x640 nsplit 3", 384, 5120, 640, 0, true, 1, 1.f, 0, 3);
+    g_xs_geglu = true; case_xs("xs geglu 257x(2*96)x640+128 (3 blocks)", 257, 192, 640, 128, false, 1, 1.f, 0, 1);
+    const int ns[] = {0, 1, 2, 4};
+    for (int n : ns) {
+      char nm[96];
+      snprintf(nm, sizeof nm, "xs 32768x2560x320 nsplit %d", n);       case_xs(nm, 32768, 2560, 320, 0, true, 1, 1.f, 0, n, true);
+      snprintf(nm, sizeof nm, "xs 32768x2560x320+128 nsplit %d", n);   case_xs(nm, 32768, 2560, 320, 128, true, 1, 1.f, 0, n, true);
+      snprintf(nm, sizeof nm, "xs 32768x1280x320 nsplit %d", n);       case_xs(nm, 32768, 1280, 320, 0, false, 1, 1.f, 0, n, true);
+      snprintf(nm, sizeof nm, "xs 32768x960x320+128 g3 nsplit %d", n); case_xs(nm, 32768, 960, 320, 128, false, 3, 0.2f, 320, n, true);
+      snprintf(nm, sizeof nm, "xs 32768x320x320 nsplit %d", n);        case_xs(nm, 32768, 320, 320, 0, true, 1, 1.f, 0, n, true);
+      snprintf(nm, sizeof nm, "xs 8192x5120x640 nsplit %d", n);        case_xs(nm, 8192, 5120, 640, 0, true, 1, 1.f, 0, n, true);
+      snprintf(nm, sizeof nm, "xs 8192x5120x640+128 nsplit %d", n);    case_xs(nm, 8192, 5120, 640, 128, true, 1, 1.f, 0, n, true);
+      snprintf(nm, sizeof nm, "xs 8192x1920x640+128 g3 nsplit %d", n); case_xs(nm, 8192, 1920, 640, 128, false, 3, 0.2f, 640, n, true);
+      snprintf(nm, sizeof nm, "xs 8192x2560x640 nsplit %d", n);        case_xs(nm, 8192, 2560, 640, 0, false, 1, 1.f, 0, n, true);
+      g_xs_beta = 1.f; snprintf(nm, sizeof nm, "xs res 32768x320x320 nsplit %d", n);     case_xs(nm, 32768, 320, 320, 0, true, 1, 1.f, 0, n, true);
+      g_xs_beta = 1.f; snprintf(nm, sizeof nm, "xs res 32768x320x320+128 nsplit %d", n); case_xs(nm, 32768, 320, 320, 128, true, 1, 1.f, 0, n, true);
+      g_xs_beta = 1.f; snprintf(nm, sizeof nm, "xs res 8192x640x640 nsplit %d", n);      case_xs(nm, 8192, 640, 640, 0, true, 1, 1.f, 0, n, true);
+      g_xs_beta = 1.f; snprintf(nm, sizeof nm, "xs res 131072x320x320 nsplit %d", n);    case_xs(nm, 131072, 320, 320, 0, true, 1, 1.f, 0, n, true);
+      g_xs_geglu = true; snprintf(nm, sizeof nm, "xs geglu 32768x2560x320 nsplit %d", n);   case_xs(nm, 32768, 2560, 320, 0, true, 1, 1.f, 0, n, true);
+      g_xs_geglu = true; snprintf(nm, sizeof nm, "xs geglu 131072x2560x320 nsplit %d", n);  case_xs(nm, 131072, 2560, 320, 0, true, 1, 1.f, 0, n, true);
+      g_xs_geglu = true; snprintf(nm, sizeof nm, "xs geglu 32768x5120x640 nsplit %d", n);   case_xs(nm, 32768, 5120, 640, 0, true, 1, 1.f, 0, n, true);
+      g_xs_geglu = true; snprintf(nm, sizeof nm, "xs geglu 8192x5120x640 nsplit %d", n);    case_xs(nm, 8192, 5120, 640, 0, true, 1, 1.f, 0, n, true);
+    }
+    // the tile kernels' fused GEGLU on the same products (rows permuted per 160-column tile), for the comparison
+    g_gemm_force_cfg = -1;
+    g_probe_act = ACT_GEGLU;
+    time_case("tile GEGLU 32768x2560x320", CL_BF16, GEMM_LINEAR, 32768, 2560, 320, 0, 0, 0);
+    time_case("tile GEGLU 131072x2560x320", CL_BF16, GEMM_LINEAR, 131072, 2560, 320, 0, 0, 0);
+    time_case("tile GEGLU 32768x5120x640", CL_BF16, GEMM_LINEAR, 32768, 5120, 640, 0, 0, 0);
+    time_case("tile GEGLU 8192x5120x640", CL_BF16, GEMM_LINEAR, 8192, 5120, 640, 0, 0, 0);
+    g_probe_act = 0;
+    printf("%s\n", g_fail ? "XS PROBE: FAILURES" : "XS PROBE: all pass");
+    return g_fail ? 1 : 0;
   }
   if (argc > 1 && !strcmp(argv[1], "--stagger")) {   // two workgroups per CU, the second one held back once
     for (int st : {0, 4000, 8000, 12000, 16000, 24000, 0}) {

@@ -59,11 +59,17 @@ __device__ __forceinline__ void vm_wait(int n) {
   }
 }
 
-// K = 16 * KS elements; N = 32 * NCH columns; M = 128 * gridDim.x rows
-template <int KS, int NCH>
-__global__ __launch_bounds__(256, 1) void stream_gemm_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
-                                                             uint16_t* __restrict__ Y) {
-  constexpr int K = 16 * KS, N = 32 * NCH, ROWB = K * 2, CPRW = ROWB / 16;   // bytes / 16-byte slots per W row
+// K = 16 * KS elements; a workgroup owns 128 rows x (32 * NCH) columns starting at column 32 * NCH * blockIdx.y of an output
+// that is N = 32 * NCH * gridDim.y wide; M = 128 * gridDim.x rows.  WIDE: T21 of the CDNA4 guide -- v_permlane32_swap pairs the
+// half-waves' 4-column groups so that every lane stores 16 bytes (2 dwordx4 instead of 4 dwordx2 per chunk).  MINW: minimum
+// waves per SIMD the register budget is sized for (2 = two workgroups per CU when the ring fits twice in the LDS).
+template <int KS, int NCH, bool WIDE, int MINW>
+__global__ __launch_bounds__(256, MINW) void stream_gemm_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W0,
+                                                                uint16_t* __restrict__ Y0) {
+  constexpr int K = 16 * KS, ROWB = K * 2, CPRW = ROWB / 16;   // bytes / 16-byte slots per W row
+  const int N = 32 * NCH * (int)gridDim.y;
+  const uint16_t* W = W0 + (long)blockIdx.y * 32 * NCH * K;
+  uint16_t* Y = Y0 + (long)blockIdx.y * 32 * NCH;
   constexpr int CHUNK = 32 * ROWB, PIECES = CHUNK / 1024, NJ = (PIECES + 3) / 4, RING = 3;
   static_assert(CPRW % 8 == 0, "the source-side swizzle permutes slots inside aligned groups of 8");
   extern __shared__ __attribute__((aligned(16))) char smem[];          // RING chunks of W
@@ -107,18 +113,32 @@ __global__ __launch_bounds__(256, 1) void stream_gemm_kernel(const uint16_t* __r
   issue(0);
   if (NCH > 1) issue(1);
   uint16_t* yrow = Y + (row0 + l31) * N + 4 * hi;      // lane (m = l31, hi): columns 8 (r / 4) + 4 hi + (r % 4) of the chunk
+  uint16_t* yrow_w = Y + (row0 + l31) * N + 8 * hi;   // WIDE: lanes 0-31 store columns 16 p .. + 7, lanes 32-63 columns 16 p + 8 .. + 15
   auto store_chunk = [&](int c, const f32x16_t& a) {
+    if constexpr (WIDE) {
 #pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {
-      u32x2_t w = {pack2bf(a[4 * q4], a[4 * q4 + 1]), pack2bf(a[4 * q4 + 2], a[4 * q4 + 3])};
-      *reinterpret_cast<u32x2_t*>(yrow + c * 32 + 8 * q4) = w;
+      for (int p2 = 0; p2 < 2; ++p2) {
+        uint32_t ax = pack2bf(a[8 * p2], a[8 * p2 + 1]), ay = pack2bf(a[8 * p2 + 2], a[8 * p2 + 3]);          // group k = 2 p2
+        uint32_t bx = pack2bf(a[8 * p2 + 4], a[8 * p2 + 5]), by = pack2bf(a[8 * p2 + 6], a[8 * p2 + 7]);      // group k + 1
+        auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+        auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+        u32x4_t w = {rx[0], ry[0], rx[1], ry[1]};
+        *reinterpret_cast<u32x4_t*>(yrow_w + c * 32 + 16 * p2) = w;
+      }
+    } else {
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        u32x2_t w = {pack2bf(a[4 * q4], a[4 * q4 + 1]), pack2bf(a[4 * q4 + 2], a[4 * q4 + 3])};
+        *reinterpret_cast<u32x2_t*>(yrow + c * 32 + 8 * q4) = w;
+      }
     }
   };
+  constexpr int SPC = WIDE ? 2 : 4;     // store instructions per chunk
   for (int c = 0; c < NCH; ++c) {
     // This wave's requests of chunk c have landed when at most the vector-memory operations issued AFTER them are outstanding
     // (gfx9 family: one vmcnt for loads and stores, retired in issue order -- the compiler's own waitcnt insertion relies on it):
     // the requests of chunk c + 1 (issued one iteration ago) and the 4 stores each of chunks c - 3 and c - 2.
-    vm_wait((c + 1 < NCH ? DMA_PER_CHUNK : 0) + (c >= 2 ? 4 : 0) + (c >= 3 ? 4 : 0));
+    vm_wait((c + 1 < NCH ? DMA_PER_CHUNK : 0) + (c >= 2 ? SPC : 0) + (c >= 3 ? SPC : 0));
     __builtin_amdgcn_s_barrier();                      // every wave's pieces landed; chunk c - 1's buffer is free
     if (c + 2 < NCH) issue(c + 2);
     const uint32_t base = lds0 + (c % RING) * CHUNK;
@@ -142,8 +162,9 @@ __global__ __launch_bounds__(256, 1) void stream_gemm_kernel(const uint16_t* __r
 static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
 static float bf2f(uint16_t v) { uint32_t u = ((uint32_t)v) << 16; float f; memcpy(&f, &u, 4); return f; }
 
-template <int KS, int NCH> static int run(int M) {
-  constexpr int K = 16 * KS, N = 32 * NCH;
+template <int KS, int NCH, bool WIDE = false, int MINW = 1> static int run(int M, int nsplit = 1) {
+  constexpr int K = 16 * KS;
+  const int N = 32 * NCH * nsplit;
   constexpr int LDS = 3 * 32 * K * 2;
   std::vector<uint16_t> hx((size_t)M * K), hw((size_t)N * K), hy((size_t)M * N);
   uint32_t st = 12345;
@@ -155,13 +176,13 @@ template <int KS, int NCH> static int run(int M) {
   HIPCHK(hipMemcpy(dx, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
   HIPCHK(hipMemset(dy, 0xff, hy.size() * 2));
-  auto kern = &stream_gemm_kernel<KS, NCH>;
+  auto kern = &stream_gemm_kernel<KS, NCH, WIDE, MINW>;
   if (LDS > 65536) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-  hipLaunchKernelGGL(kern, dim3(M / 128), dim3(256), LDS, 0, dx, dw, dy);
+  hipLaunchKernelGGL(kern, dim3(M / 128, nsplit), dim3(256), LDS, 0, dx, dw, dy);
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(hy.data(), dy, hy.size() * 2, hipMemcpyDeviceToHost));
   double num = 0, den = 0; int bad = 0;
-  for (int t = 0; t < 64; ++t) {
+  for (int t = 0; t < 24; ++t) {
     const int r = (int)(((long)t * 7919 + 13) % M);
     for (int n = 0; n < N; ++n) {
       double ref = 0;
@@ -173,27 +194,43 @@ template <int KS, int NCH> static int run(int M) {
   }
   const double rel = std::sqrt(num / (den + 1e-30));
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(kern, dim3(M / 128), dim3(256), LDS, 0, dx, dw, dy);
+  for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(kern, dim3(M / 128, nsplit), dim3(256), LDS, 0, dx, dw, dy);
   HIPCHK(hipDeviceSynchronize());
   float best = 1e9f, sum = 0;
   for (int rep = 0; rep < 5; ++rep) {
     hipEventRecord(e0);
-    for (int i = 0; i < 50; ++i) hipLaunchKernelGGL(kern, dim3(M / 128), dim3(256), LDS, 0, dx, dw, dy);
+    for (int i = 0; i < 50; ++i) hipLaunchKernelGGL(kern, dim3(M / 128, nsplit), dim3(256), LDS, 0, dx, dw, dy);
     hipEventRecord(e1);
     HIPCHK(hipDeviceSynchronize());
     float ms; hipEventElapsedTime(&ms, e0, e1);
     best = ms < best ? ms : best; sum += ms;
   }
   const double us = best / 50 * 1e3, flops = 2.0 * M * N * K, bytes = 2.0 * ((double)M * K + (double)M * N + (double)N * K);
-  printf("[%s] (M, N, K) = (%d, %d, %d): rel-L2 %.2e, %d of %d sampled elements off;  %.2f us per launch (mean %.2f), %.0f TF/s, %.2f TB/s algorithmic\n",
-         (bad == 0 && rel < 5e-3) ? "PASS" : "FAIL", M, N, K, rel, bad, 64 * N, us, sum / 250 * 1e3, flops / us * 1e-6, bytes / us * 1e-6);
+  printf("[%s] wide=%d minw=%d nsplit=%d (M, N, K) = (%d, %d, %d): rel-L2 %.2e, %d of %d sampled elements off;  %.2f us per launch (mean %.2f), %.0f TF/s, %.2f TB/s algorithmic\n",
+         (bad == 0 && rel < 5e-3) ? "PASS" : "FAIL", (int)WIDE, MINW, nsplit, M, N, K, rel, bad, 24 * N, us, sum / 250 * 1e3, flops / us * 1e-6, bytes / us * 1e-6);
   hipFree(dx); hipFree(dw); hipFree(dy);
   return 0;
 }
 
 int main() {
   if (run<20, 10>(32768)) return 2;     // (32768, 320, 320): 53 launches per training step at 16.7-17.8 us in the product
-  if (run<20, 10>(131072)) return 2;    // the same product at the DDIM batch (B = 32 rows): 4 tiles per CU
-  if (run<40, 20>(8192)) return 2;      // (8192, 640, 640): 52 launches at 14.3-16.6 us (64 workgroups only: needs another split)
+  if (run<20, 10, true>(32768)) return 2;
+  if (run<20, 10, true, 2>(32768)) return 2;
+  // round 5: the wide-N / short-K class: GEGLU projection (32768, 2560, 320) 121 us in the product
+  if (run<20, 80>(32768)) return 2;
+  if (run<20, 80, true>(32768)) return 2;
+  if (run<20, 80, true, 2>(32768)) return 2;
+  if (run<20, 40, true>(32768, 2)) return 2;          // the same product, output width split over two workgroups (512 workgroups)
+  if (run<20, 40, true, 2>(32768, 2)) return 2;
+  if (run<20, 40, true>(32768)) return 2;             // (32768, 1280, 320): 50.5 us
+  if (run<20, 30, true>(32768)) return 2;             // (32768, 960, 320): 39.6 us
+  if (run<20, 40, true, 2>(32768)) return 2;
+  if (run<20, 30, true, 2>(32768)) return 2;
+  if (run<40, 40, true>(8192, 4)) return 2;           // (8192, 5120, 640): 91 us; 64 row blocks x 4 column splits
+  if (run<40, 20, true>(8192, 8)) return 2;
+  if (run<40, 20, true>(8192, 4)) return 2;           // (8192, 2560, 640): 40.5 us
+  if (run<40, 20, true>(8192, 1)) return 2;           // (8192, 640, 640)
+  if (run<40, 5, true>(8192, 4)) return 2;            // the same, 256 workgroups
+  if (run<20, 80, true>(131072)) return 2;            // DDIM batch GEGLU projection
   return 0;
 }
