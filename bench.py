@@ -636,7 +636,16 @@ def main():
     ap.add_argument("--pretrain-only", action="store_true",
                     help="evidence run, not the headline: one-GPU Base-ControlNet pre-training steps (BASELINE configs[3])")
     ap.add_argument("--tiny", action="store_true", help="debug: narrow model")
+    ap.add_argument("--tag-gemm", default=None, metavar="JSON",
+                    help="profiling aid: tag every contraction launch with its product signature (extra empty workgroups, "
+                         "csrc/debug_hooks.h) and write the tag table here -- tools/prof_shapes.py joins it with a rocprofv3 "
+                         "kernel trace of THIS run into a per-shape table of the replayed step")
     args = ap.parse_args()
+    if args.tag_gemm:
+        import atexit
+        from ctrlora_amd import hip as _hip
+        _hip.lib().cl_debug_gemm_tag(1)
+        atexit.register(lambda: json.dump(_hip.gemm_tags(), open(args.tag_gemm, "w")))
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))        # `python bench.py --gpus N` starts its own ranks

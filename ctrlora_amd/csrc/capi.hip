@@ -55,6 +55,10 @@ int cl_debug_groupnorm_form(int three_pass, int one_pass) {
   g_gn_three_pass = three_pass ? 1 : 0; g_gn_one_pass = one_pass ? 1 : 0; return CL_OK;
 }
 
+int cl_debug_gemm_tag(int on) { g_gemm_tag_on = on ? 1 : 0; return CL_OK; }
+int cl_debug_gemm_tag_count(void) { return gemm_tag_count(); }
+int cl_debug_gemm_tag_get(int i, long* out12) { return out12 ? gemm_tag_get(i, out12) : CL_EINVAL; }
+
 int cl_gemm(const cl_gemm_params* p, int dtype, void* stream) {
   if (!p) return CL_EINVAL;
   GemmParams g{};
@@ -67,6 +71,7 @@ int cl_gemm(const cl_gemm_params* p, int dtype, void* stream) {
   g.residual = p->residual; g.ldr = p->ldr; g.alpha = p->alpha; g.beta = p->beta; g.act = p->act;
   g.C = p->C; g.ldc = p->ldc; g.out_f32 = p->out_f32; g.atomic = p->atomic; g.splitk = p->splitk < 1 ? 1 : p->splitk;
   g.a1_group_n = p->a1_group_n; g.a2_group_n = p->a2_group_n; g.alpha_n = p->alpha_n;
+  g.ln_gamma = p->ln_gamma; g.ln_beta = p->ln_beta; g.ln_eps = p->ln_eps; g.ln_stats = p->ln_stats;
   return launch_gemm(g, dtype, S(stream));
 }
 

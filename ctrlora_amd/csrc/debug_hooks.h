@@ -15,6 +15,15 @@ int cl_debug_attention_fuse_delta(int on);
 /* GroupNorm launch forms: three_pass = 1 forces partial -> finalize -> apply; one_pass = 0 disables the one-launch
  * register-resident form (defaults 0, 1) */
 int cl_debug_groupnorm_form(int three_pass, int one_pass);
+/* Launch tags for the contraction kernels (profiling aid: which SHAPE is a gemm dispatch of a kernel trace?).  While on, every
+ * cl_gemm product signature {dtype, mode, M, N, K1, K2, act, residual} gets a small integer tag in order of first appearance
+ * (1 .. 255) and each kernel it launches gets `tag` extra workgroups that exit at once -- so a trace row's Grid_Size names the
+ * signature: workgroups = real grid + tag (tools/prof_shapes.py decodes it from the table below).  Results are unchanged.
+ * cl_debug_gemm_tag_get(i, out): out[0..11] = dtype, mode, M, N, K1, K2, act, has_residual, tag, real workgroups of the main
+ * kernel, workgroup size, launches so far; returns CL_EINVAL past the end. */
+int cl_debug_gemm_tag(int on);
+int cl_debug_gemm_tag_count(void);
+int cl_debug_gemm_tag_get(int i, long* out12);
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,12 @@ struct GemmParams {
   // alpha applies to output columns [0, alpha_n) only (0 = all columns): the producer of a fused q | k | v writes
   // q * (d_head^-0.5 * log2 e) -- the attention kernels' pre-scaled-Q contract -- and leaves k, v alone.  Multiple of 8.
   int alpha_n;
+  // LayerNorm as a PROLOGUE of the product (x-stationary kernel only, gemm_xs.hip; bf16, K1 in {320, 640}, K2 = 0):
+  // A1 holds the UN-normalised rows; the kernel forms LN(row) = (row - mean) * rstd * gamma + beta over the K1 columns in
+  // registers (fp32 statistics, two passes, rounded to bf16 exactly as the stand-alone cl_layernorm_fwd stores it) before
+  // the MFMAs -- BasicTransformerBlock's norm1/2/3 (ldm/modules/attention.py:271-275) never exist in HBM.  ln_stats
+  // (optional, [M][2] fp32: mean, rstd) is what cl_layernorm_bwd needs when a backward pass follows.
+  const float* ln_gamma; const float* ln_beta; float ln_eps; float* ln_stats;
 };
 
 int launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);
@@ -85,5 +91,11 @@ int gemm_tune_set(int dtype, int mode, int M, int N, int K1, int K2, int geglu, 
 void gemm_tune_clear();
 int gemm_tune_size();
 extern int g_gemm_force_cfg;   // tuning/probe hook (tile configuration override), -1 = heuristic
+// launch tags (csrc/debug_hooks.h: cl_debug_gemm_tag): extra, immediately exiting workgroups that name the product signature
+extern int g_gemm_tag_on;
+int gemm_cur_tag();                                   // tag of the product being launched on this thread (0 = tagging off)
+void gemm_tag_note(long real_wgs, int wg_size);       // the main kernel's real grid, for the table
+int gemm_tag_count();
+int gemm_tag_get(int i, long* out12);
 
 }  // namespace cl

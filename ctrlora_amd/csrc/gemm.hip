@@ -40,6 +40,7 @@
 #include "gemm.h"
 #include <algorithm>
 #include <map>
+#include <vector>
 #include <utility>
 #include "mma.h"
 
@@ -63,6 +64,34 @@ static void ws_for(hipStream_t st, void** p, long* bytes) {
 }
 void gemm_get_workspace(void** p, long* bytes) { ws_for(t_stream, p, bytes); }
 void gemm_get_workspace_for(hipStream_t st, void** p, long* bytes) { ws_for(st, p, bytes); }
+
+// ---- launch tags (debug hook)
+int g_gemm_tag_on = 0;
+static thread_local int t_tag = 0;
+struct TagEntry { long v[12]; };
+static std::vector<TagEntry> g_tags;
+int gemm_cur_tag() { return t_tag; }
+void gemm_tag_note(long real_wgs, int wg_size) {
+  if (t_tag > 0 && t_tag <= (int)g_tags.size()) { g_tags[t_tag - 1].v[9] = real_wgs; g_tags[t_tag - 1].v[10] = wg_size; }
+}
+int gemm_tag_count() { return (int)g_tags.size(); }
+int gemm_tag_get(int i, long* out) {
+  if (i < 0 || i >= (int)g_tags.size()) return CL_EINVAL;
+  for (int k = 0; k < 12; ++k) out[k] = g_tags[i].v[k];
+  return CL_OK;
+}
+static int tag_for(const GemmParams& p, int dtype) {
+  if (!g_gemm_tag_on) return 0;
+  const long key[8] = {dtype, p.mode, p.M, p.N, p.K1, p.K2, p.act, p.residual ? 1 : 0};
+  for (size_t i = 0; i < g_tags.size(); ++i)
+    if (std::equal(key, key + 8, g_tags[i].v)) { ++g_tags[i].v[11]; return (int)i + 1; }
+  if (g_tags.size() >= 255) return 0;
+  TagEntry e{};
+  std::copy(key, key + 8, e.v);
+  e.v[8] = (long)g_tags.size() + 1; e.v[11] = 1;
+  g_tags.push_back(e);
+  return (int)g_tags.size();
+}
 
 template <int N> __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -233,6 +262,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_kernel(GemmParams p, i
 
   // ---- XCD-aware tile id: XCD x (= workgroup id mod 8) owns tiles [x*nt/8, (x+1)*nt/8)
   const int nt = tiles_m * tiles_n;
+  if ((int)blockIdx.x >= nt * max(p.splitk, 1)) return;     // launch-tag workgroups (debug_hooks.h)
   int pid = blockIdx.x;
   const int zsplit = pid / nt;
   pid -= zsplit * nt;
@@ -891,6 +921,7 @@ template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int R, int PRI
 __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_fl_kernel(GemmParams p, int tiles_m, int tiles_n,
                                                                  float* __restrict__ slab) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)blockIdx.x >= tiles_m * tiles_n * max(p.splitk, 1)) return;     // launch-tag workgroups (debug_hooks.h)
   fl_tile<T, BM, BN, WGM, WGN, MODE, R, PRIO>(p, tiles_m, tiles_n, slab, (int)blockIdx.x, smem);
 }
 
@@ -1017,7 +1048,8 @@ static int launch_cfg(const GemmParams& p0, hipStream_t stream) {
     p.splitk = (ksub + per - 1) / per;
   }
   const long grid = tiles * p.splitk;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), SMEM, stream, p, tm, tn, slab);
+  gemm_tag_note(grid, NW * 64);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(grid + t_tag)), dim3(NW * 64), SMEM, stream, p, tm, tn, slab);
   if (slab) {
     const long total = (long)p.M * (p.N / 8);
     int rg = (int)((total + 255) / 256); if (rg > 4096) rg = 4096;
@@ -1099,10 +1131,12 @@ static int launch_fl_mode(const GemmParams& p0, hipStream_t stream) {
     if (grid > nvirt) grid = nvirt;
     if (grid < nvirt) grid -= grid % 8;
     if (grid < 1) grid = nvirt;
-    hipLaunchKernelGGL((gemm_fl_persist_kernel<T, BM, BN, WGM, WGN, MODE, R, PRIO>), dim3((unsigned)grid), dim3(NW * 64),
+    gemm_tag_note(grid, NW * 64);     // (persistent form: the walk tolerates extra workgroups -- they start past nvirt)
+    hipLaunchKernelGGL((gemm_fl_persist_kernel<T, BM, BN, WGM, WGN, MODE, R, PRIO>), dim3((unsigned)(grid + t_tag)), dim3(NW * 64),
                        SMEM, stream, p, tm, tn, slab, (int)nvirt, (SMEM <= 80 * 1024 && grid == 2L * device_cus() && nvirt >= 2 * grid) ? g_fl_persist_stagger : 0);
   } else {
-    hipLaunchKernelGGL((gemm_fl_kernel<T, BM, BN, WGM, WGN, MODE, R, PRIO>), dim3((unsigned)nvirt), dim3(NW * 64), SMEM,
+    gemm_tag_note(nvirt, NW * 64);
+    hipLaunchKernelGGL((gemm_fl_kernel<T, BM, BN, WGM, WGN, MODE, R, PRIO>), dim3((unsigned)(nvirt + t_tag)), dim3(NW * 64), SMEM,
                        stream, p, tm, tn, slab);
   }
   if (slab) {
@@ -1322,7 +1356,8 @@ int launch_gemm(const GemmParams& p, int dtype, hipStream_t stream) {
   if (p.atomic == 0 && p.splitk > 1) return CL_EINVAL;
   if (p.rowbias && p.rows_per_batch <= 0) return CL_EINVAL;
   if (p.act == ACT_GEGLU && (p.N % 160 || p.rowbias || p.residual || p.atomic || p.alpha != 1.0f)) return CL_EINVAL;
-  if (p.act == ACT_GEGLU_SPLIT)   // natural-order GEGLU rows: the x-stationary kernel's contract only (gemm_xs.hip)
+  t_tag = tag_for(p, dtype);
+  if (p.act == ACT_GEGLU_SPLIT || p.ln_gamma)   // natural-order GEGLU rows / LayerNorm prologue: the x-stationary kernel only (gemm_xs.hip)
     return dtype == CL_BF16 ? launch_gemm_xs(p, stream, g_gemm_force_splitk) : CL_EINVAL;
   if (p.a1_group_n < 0 || p.a2_group_n < 0) return CL_EINVAL;
   if (p.alpha_n < 0 || p.alpha_n % 8 || p.alpha_n > p.N || (p.alpha_n && p.act == ACT_GEGLU)) return CL_EINVAL;

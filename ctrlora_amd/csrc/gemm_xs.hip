@@ -22,8 +22,10 @@
 //   * one counted vmcnt covers the DMA ring AND the stores (gfx9: one counter, in-order retirement).
 // Measured (profiles/r05_gemm_xs/): (32768, 2560, 320) 107 -> 70 us, (32768, 1280, 320) 55 -> 44, (8192, 5120, 640) 79 -> 70.
 //
-// Not covered (the launcher returns CL_EINVAL and gemm.hip falls back to its own rules): fp32 storage, conv modes, residual /
-// rowbias / activation epilogues, fp32 output, K segments other than {320, 640} (+ {0, 128}), grouped first segments.
+// Epilogues: bias, alpha / alpha_n, beta * residual (XS_RES), fused GEGLU on natural-order rows (XS_GEGLU, act 3).  Prologue: LayerNorm
+// of the x rows in registers (GemmParams::ln_gamma).
+// Not covered (the launcher returns CL_EINVAL and gemm.hip falls back to its own rules): fp32 storage, conv modes, rowbias / SiLU,
+// fp32 output, K segments other than {320, 640} (+ {0, 128}), grouped first segments.
 #include <type_traits>
 #include "gemm.h"
 
@@ -57,18 +59,36 @@ __device__ __forceinline__ void xs_vm_wait(int n) {
 
 enum { XS_PLAIN = 0, XS_RES = 1, XS_GEGLU = 2 };
 
+// gelu(g) = 0.5 g (1 + erf(g / sqrt 2)) for the bf16 GEGLU epilogue: erfc by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute,
+// three orders below the bf16 rounding of the product it feeds; ocml's erff costs ~4x the VALU issue, and the 16 evaluations per
+// lane and block were what bounded the fused projection: 310 us with it at (131072, 2560, 320) against 310 for the plain product
+// that stores twice the bytes).  1 + erf is formed without cancellation on either side: c = erfc(|z|), then c or 2 - c.
+__device__ __forceinline__ float gelu_as(float g) {
+  const float z = fabsf(g) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float pl = fmaf(1.061405429f, t, -1.453152027f);
+  pl = fmaf(pl, t, 1.421413741f);
+  pl = fmaf(pl, t, -0.284496736f);
+  pl = fmaf(pl, t, 0.254829592f);
+  const float c = pl * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+  return 0.5f * g * (g < 0.f ? c : 2.0f - c);
+}
+
 // 16 bytes, global -> VGPRs, outside the compiler's own vmcnt bookkeeping (the caller waits with a counted vmcnt and then ties
 // the registers with an empty asm); early-clobber: the destination may not alias the address pair
 __device__ __forceinline__ void xs_gload128(u32x4_t& dst, const void* src) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(src) : "memory");
 }
 
+}  // namespace
+
 // KS1 / KS2: 16-element k-steps of the two K segments.  RING: LDS chunk slots.  MINW: waves per SIMD the register budget allows for
 // (2 = two workgroups per CU).  EPI: XS_PLAIN  C = (acc + bias) alpha;  XS_RES  ... + beta residual;  XS_GEGLU  W's rows are
 // [value (N / 2) | gate (N / 2)], C[M, N / 2] = (value + bias) * gelu(gate + bias) -- chunks alternate value / gate rows of the same
 // 32 output columns.  cpw: 32-column output blocks per workgroup; blockIdx.y selects the run of columns.
-template <int KS1, int KS2, int RING, int MINW, int EPI>
+template <int KS1, int KS2, int RING, int MINW, int EPI, bool LNP = false>
 __global__ __launch_bounds__(256, MINW) void gemm_xs_kernel(GemmParams p, int cpw) {
+  static_assert(!LNP || KS2 == 0, "the LayerNorm prologue normalises the first K segment: no second one");
   constexpr int KS = KS1 + KS2;
   constexpr int ROWB = KS * 32;                 // bytes of one [W | B] row image
   constexpr int CPRW = ROWB / 16;               // 16-byte slots per row
@@ -88,7 +108,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_xs_kernel(GemmParams p, int cp
   const int ncols = GEGLU ? p.N / 2 : p.N;      // output columns
   const int n_base = (int)blockIdx.y * cpw * 32;
   const int nob = min(cpw, (ncols - n_base) / 32);       // output blocks of this workgroup
-  if (nob <= 0) return;
+  if (nob <= 0 || (int)blockIdx.x >= (p.M + 127) / 128) return;      // (past M: launch-tag workgroups, csrc/debug_hooks.h)
   const int nch = nob * CPB;                             // chunks (= loop iterations)
   // rows past M repeat row M - 1: same operands, same results, the same bytes stored twice -- no predication anywhere, so the
   // instruction counts the vmcnt arithmetic relies on are exact
@@ -106,6 +126,76 @@ __global__ __launch_bounds__(256, MINW) void gemm_xs_kernel(GemmParams p, int cp
 #pragma unroll
       for (int j = 0; j < KS2; ++j) xa[KS1 + j] = *reinterpret_cast<const u32x4_t*>(tp + j * 32);
     }
+  }
+  float* lnaff = reinterpret_cast<float*>(smem + RING * CHUNK) + cpw * CPB * 32;     // LNP: gamma[K1] | beta[K1] (fp32)
+  if constexpr (LNP) {
+    for (int i = tid; i < 16 * KS1; i += 256) { lnaff[i] = p.ln_gamma[i]; lnaff[16 * KS1 + i] = p.ln_beta[i]; }
+    // LayerNorm prologue (attention.py:271-275 norm1/2/3, cl_layernorm_fwd's arithmetic): lanes (l31, hi = 0 / 1) hold one row
+    // between them -- 8 KS1 elements each; two passes over the registers (mean, then centred squares), fp32; the normalised row
+    // is rounded to bf16 as the stand-alone kernel stores it and goes back into the fragment registers
+    constexpr float invK = 1.0f / (16 * KS1);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < KS1; ++j) {
+      const uint32_t w[4] = {xa[j].x, xa[j].y, xa[j].z, xa[j].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sum += __uint_as_float(w[e] << 16) + __uint_as_float(w[e] & 0xffff0000u);
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * invK;
+    // (the fragments pass through an empty asm between the passes: otherwise the compiler keeps all 16 KS1 unpacked floats
+    // of pass one alive for passes two and three -- 250 spilled registers)
+#pragma unroll
+    for (int j = 0; j < KS1; ++j) asm volatile("" : "+v"(xa[j]));
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < KS1; ++j) {
+      const uint32_t w[4] = {xa[j].x, xa[j].y, xa[j].z, xa[j].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d0 = __uint_as_float(w[e] << 16) - mean, d1 = __uint_as_float(w[e] & 0xffff0000u) - mean;
+        sq += d0 * d0 + d1 * d1;
+      }
+    }
+    sq += __shfl_xor(sq, 32, 64);
+#pragma unroll
+    for (int j = 0; j < KS1; ++j) asm volatile("" : "+v"(xa[j]));
+    const float rstd = rsqrtf(sq * invK + p.ln_eps);
+    if (p.ln_stats && blockIdx.y == 0 && hi == 0) { p.ln_stats[row * 2] = mean; p.ln_stats[row * 2 + 1] = rstd; }
+    // gamma | beta from their LDS image (staged below the bias image by the whole workgroup), four k-steps at a time so that
+    // the affine vectors of the whole row are never live together
+    __syncthreads();
+    const uint32_t ga = (uint32_t)(uintptr_t)lnaff + hi * 32;          // gamma of k = 16 j + 8 hi .. + 7 at ga + 64 j
+    u32x4_t rr[2][4];                                                 // (raw LDS reads, one k-step ahead: the compiler would issue all 4 KS1 at once)
+    rr[0][0] = xs_rd128<0>(ga); rr[0][1] = xs_rd128<16>(ga); rr[0][2] = xs_rd128<KS1 * 64>(ga); rr[0][3] = xs_rd128<KS1 * 64 + 16>(ga);
+    sfor<0, KS1>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      if constexpr (j + 1 < KS1) {
+        constexpr int n = j + 1;
+        rr[n & 1][0] = xs_rd128<n * 64>(ga); rr[n & 1][1] = xs_rd128<n * 64 + 16>(ga);
+        rr[n & 1][2] = xs_rd128<KS1 * 64 + n * 64>(ga); rr[n & 1][3] = xs_rd128<KS1 * 64 + n * 64 + 16>(ga);
+        xs_lgkm<4>();
+      } else {
+        xs_lgkm<0>();
+      }
+      u32x4_t (&r)[4] = rr[j & 1];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(r[q]));
+      const float gg[8] = {__uint_as_float(r[0].x), __uint_as_float(r[0].y), __uint_as_float(r[0].z), __uint_as_float(r[0].w),
+                           __uint_as_float(r[1].x), __uint_as_float(r[1].y), __uint_as_float(r[1].z), __uint_as_float(r[1].w)};
+      const float bb[8] = {__uint_as_float(r[2].x), __uint_as_float(r[2].y), __uint_as_float(r[2].z), __uint_as_float(r[2].w),
+                           __uint_as_float(r[3].x), __uint_as_float(r[3].y), __uint_as_float(r[3].z), __uint_as_float(r[3].w)};
+      const uint32_t w[4] = {xa[j].x, xa[j].y, xa[j].z, xa[j].w};
+      uint32_t o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v0 = (__uint_as_float(w[e] << 16) - mean) * rstd * gg[2 * e] + bb[2 * e];
+        const float v1 = (__uint_as_float(w[e] & 0xffff0000u) - mean) * rstd * gg[2 * e + 1] + bb[2 * e + 1];
+        o[e] = pack2bf(v0, v1);
+      }
+      xa[j] = u32x4_t{o[0], o[1], o[2], o[3]};
+      asm volatile("" : "+v"(xa[j]));        // (volatile: ordered before the next k-step's reads -- the arithmetic cannot be sunk past them)
+    });
   }
   // bias image: [nob * 32 floats] (GEGLU: value part, then the gate part)
   float* sb = reinterpret_cast<float*>(smem + RING * CHUNK);
@@ -174,7 +264,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_xs_kernel(GemmParams p, int cp
   auto store_block = [&](int b, f32x16_t a, const f32x16_t& gate) {
     if constexpr (GEGLU) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) a[i] *= gelu_f(gate[i]);
+      for (int i = 0; i < 16; ++i) a[i] *= gelu_as(gate[i]);
     } else {
       const float al = (alpha_n > 0 && n_base + b * 32 >= alpha_n) ? 1.0f : alpha;
 #pragma unroll
@@ -269,7 +359,9 @@ __global__ __launch_bounds__(256, MINW) void gemm_xs_kernel(GemmParams p, int cp
   });
 }
 
-template <int KS1, int KS2, int RING, int MINW, int EPI>
+namespace {
+
+template <int KS1, int KS2, int RING, int MINW, int EPI, bool LNP = false>
 int launch_xs(const GemmParams& p, hipStream_t stream, int nsplit) {
   constexpr int KS = KS1 + KS2, CHUNK = 32 * KS * 32, CPB = EPI == XS_GEGLU ? 2 : 1, MAXB = 80 / CPB;
   const int ncols = EPI == XS_GEGLU ? p.N / 2 : p.N;
@@ -291,17 +383,27 @@ int launch_xs(const GemmParams& p, hipStream_t stream, int nsplit) {
     nsplit = k;
   }
   const int cpw = bpg / nsplit;
-  const int smem = RING * CHUNK + cpw * CPB * 32 * 4;
-  auto kern = &gemm_xs_kernel<KS1, KS2, RING, MINW, EPI>;
+  const int smem = RING * CHUNK + cpw * CPB * 32 * 4 + (LNP ? 2 * 16 * KS1 * 4 : 0);
+  auto kern = &gemm_xs_kernel<KS1, KS2, RING, MINW, EPI, LNP>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RING * CHUNK + 2560 * 4) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RING * CHUNK + 2560 * 4 + (LNP ? 2 * 16 * KS1 * 4 : 0)) != hipSuccess)
       return CL_ELAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)rb, (unsigned)(groups * nsplit)), dim3(256), smem, stream, p, cpw);
+  // launch tag: `tag` extra (empty) columns of workgroups -- the trace shows (rb + tag) * groups * nsplit workgroups
+  gemm_tag_note((long)rb * groups * nsplit, 256);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(rb + gemm_cur_tag()), (unsigned)(groups * nsplit)), dim3(256), smem, stream, p, cpw);
   CL_CHECK_LAUNCH();
   return CL_OK;
+}
+
+template <int EPI>
+int launch_xs_ln(const GemmParams& p, hipStream_t stream, int nsplit) {
+  if (p.K2 || !p.ln_beta) return CL_EINVAL;
+  if (p.K1 == 320) return launch_xs<20, 0, 3, 2, EPI, true>(p, stream, nsplit);
+  if (p.K1 == 640) return launch_xs<40, 0, 3, 1, EPI, true>(p, stream, nsplit);
+  return CL_EINVAL;
 }
 
 template <int EPI>
@@ -324,6 +426,10 @@ int launch_gemm_xs(const GemmParams& p, hipStream_t stream, int nsplit) {
   if (p.a2_group_n && (p.a2_group_n % 32 || p.N % p.a2_group_n || !p.K2)) return CL_EINVAL;
   if (p.lda1 % 8 || p.ldw1 % 8 || p.ldc % 8 || (p.K2 && (p.lda2 % 8 || p.ldw2 % 8)) || (p.residual && p.ldr % 8)) return CL_EINVAL;   // 16-byte vectors
   if ((long)32 * p.ldw1 * 2 + 1536 >= (1L << 31) || (p.K2 && (long)32 * p.ldw2 * 2 + 1536 >= (1L << 31))) return CL_EINVAL;
+  if (p.ln_gamma) {
+    if (p.residual) return CL_EINVAL;
+    return geglu ? launch_xs_ln<XS_GEGLU>(p, stream, nsplit) : launch_xs_ln<XS_PLAIN>(p, stream, nsplit);
+  }
   if (geglu) return launch_xs_k<XS_GEGLU>(p, stream, nsplit);
   if (p.residual) return launch_xs_k<XS_RES>(p, stream, nsplit);
   return launch_xs_k<XS_PLAIN>(p, stream, nsplit);

@@ -131,30 +131,40 @@ class Ctx:
 # --------------------------------------------------------------------------- linear
 
 def linear_fwd(ctx: Ctx, L: LinearW, x, out=None, residual=None, act=hip.ACT_NONE, alpha=1.0, beta=1.0,
-               out_f32=False, alpha_n=0):
+               out_f32=False, alpha_n=0, ln=None):
     """y = (x W^T + b [+ (x A^T) B^T]) * alpha + beta * residual.  Returns (y, t = x A^T or None).
-    alpha_n > 0: alpha multiplies output columns [0, alpha_n) only (the q part of a fused q | k | v)."""
+    alpha_n > 0: alpha multiplies output columns [0, alpha_n) only (the q part of a fused q | k | v).
+    ln = (gamma, beta, eps, stats): x is UN-normalised and LayerNorm runs as the product's prologue (ln_prologue_ok)."""
     M = x.shape[0]
     t = None
     merged = L.Wm is not None and not ctx.record      # inference executor: W + B A already folded
+    assert ln is None or not (L.r and not merged), "LayerNorm prologue: the product may not carry a live LoRA segment"
     if L.r and not merged:
         t = ctx.new(M, L.r)
         hip.gemm(x, L.A, t)
     if out is None:
         out = ctx.new(M, L.N, torch.float32 if out_f32 else None)
     hip.gemm(x, L.Wm if merged else L.W, out, a2=t, w2=L.B if t is not None else None, bias=L.bias, residual=residual,
-             alpha=alpha, beta=beta if residual is not None else 0.0, act=act, out_f32=out_f32, alpha_n=alpha_n)
+             alpha=alpha, beta=beta if residual is not None else 0.0, act=act, out_f32=out_f32, alpha_n=alpha_n, ln=ln)
     return out, t
 
 
-def group_fwd(ctx: Ctx, grp, x, alpha=1.0, alpha_n=0):
+def ln_prologue_ok(ctx: Ctx, M: int, N: int, K: int, lora_live: bool, act=hip.ACT_NONE) -> bool:
+    """May LayerNorm(x) . W^T run as ONE launch here (hip.xs_ln_ok: the x-stationary kernel normalises its rows in registers)?
+    Only where nothing else reads the normalised tensor: a product with a live LoRA segment needs it for t = LN(x) A^T and, in
+    training, for dA (cldm/lora.py:285-291) -- the frozen UNet and the LoRA-merged inference executors qualify."""
+    return ctx.dtype == torch.bfloat16 and not lora_live and hip.xs_ln_ok(M, N, K, act)
+
+
+def group_fwd(ctx: Ctx, grp, x, alpha=1.0, alpha_n=0, ln=None):
     """Every member of a packing.LoraGroup applied to x in two launches: (y [M, G N] (+ bias), t [M, G r] or None).
     alpha / alpha_n: as linear_fwd (the first member's output scaled in the product's epilogue)."""
     M = x.shape[0]
     y = ctx.new(M, grp.G * grp.N)
     if grp.Wm is not None and not ctx.record:              # inference executor: W + B A folded, one plain product
-        hip.gemm(x, grp.Wm, y, bias=grp.bias, alpha=alpha, alpha_n=alpha_n)
+        hip.gemm(x, grp.Wm, y, bias=grp.bias, alpha=alpha, alpha_n=alpha_n, ln=ln)
         return y, None
+    assert ln is None, "LayerNorm prologue: the grouped product carries live LoRA segments"
     t = ctx.new(M, grp.G * grp.r)
     hip.gemm(x, grp.A, t)
     hip.gemm(x, grp.W, y, a2=t, w2=grp.B, bias=grp.bias, a2_group_n=grp.N, alpha=alpha, alpha_n=alpha_n)
@@ -256,6 +266,12 @@ class LayerNormOp:
         stats = torch.empty((x.shape[0], 2), dtype=torch.float32, device=ctx.device) if ctx.record else None
         hip.layernorm_fwd(x, out, self.w.gamma, self.w.beta, self.eps, stats)
         return out, stats
+
+    def prologue(self, ctx: Ctx, rows: int):
+        """(gamma, beta, eps, stats) for a product that normalises its own input rows (hip.gemm(ln=...)); stats [rows, 2]
+        (mean, rstd) only when a backward pass will want them."""
+        stats = torch.empty((rows, 2), dtype=torch.float32, device=ctx.device) if ctx.record else None
+        return (self.w.gamma, self.w.beta, self.eps, stats)
 
     def bwd(self, ctx: Ctx, x, dy, stats, accum=None):
         out = ctx.new(*x.shape)
@@ -398,8 +414,23 @@ class AttnE:
     def _prescaled(self, ctx: Ctx) -> bool:
         return PRESCALE_Q and ctx.dtype == torch.bfloat16
 
-    def _group_fwd(self, ctx: Ctx, x, alpha=1.0, alpha_n=0):
-        return group_fwd(ctx, self.group, x, alpha=alpha, alpha_n=alpha_n)
+    def _group_fwd(self, ctx: Ctx, x, alpha=1.0, alpha_n=0, ln=None):
+        return group_fwd(ctx, self.group, x, alpha=alpha, alpha_n=alpha_n, ln=ln)
+
+    def ln_fusable(self, ctx: Ctx, M: int) -> bool:
+        """Can the LayerNorm in front of this attention be the prologue of the product that reads it (q | k | v of a
+        self-attention, to_q of a cross-attention)?"""
+        # "live": the normalised tensor is an operand of something else too -- t = LN(x) A^T of an unmerged LoRA, or the
+        # weight gradient of a dense weight that trains (pre-training / ft_with_lora = False)
+        live = lambda L: (bool(L.r) and not (L.Wm is not None and not ctx.record)) or (ctx.record and L.tW is not None)
+        if self.is_self:
+            if self.fused_qkv is not None:
+                return ln_prologue_ok(ctx, M, 3 * self.inner, self.fused_qkv.K, live(self.fused_qkv))
+            if self.group is not None:
+                return ln_prologue_ok(ctx, M, 3 * self.inner, self.group.K, not (self.group.Wm is not None and not ctx.record)
+                                      or any(ctx.record and L.tW is not None for L in self.group.members))
+            return False          # three separate products would each normalise the rows again
+        return ln_prologue_ok(ctx, M, self.inner, self.q.K, live(self.q))
 
     def _group_bwd(self, ctx: Ctx, dy, need_dx: bool, accum=None):
         """dy [M, G N] -> (dx [M, K] (+ accum) or None, u [M, G r])."""
@@ -430,27 +461,30 @@ class AttnE:
         v, tv = linear_fwd(ctx, self.v, c)
         return k, v, tk, tv
 
-    def fwd(self, ctx: Ctx, xn, c, B, N, Nkv, residual, kv_cache=None):
+    def fwd(self, ctx: Ctx, xn, c, B, N, Nkv, residual, kv_cache=None, ln=None):
+        """ln = LayerNormOp.prologue(...): xn is the UN-normalised input and the product that reads it applies the norm
+        (only where ln_fusable() said so)."""
         inner, H = self.inner, self.heads
         tq = tk = tv = None
         pre = self._prescaled(ctx)
         qa = self.q_alpha if pre else 1.0
         if self.is_self:
             if self.fused_qkv is not None:
-                qkv, _ = linear_fwd(ctx, self.fused_qkv, xn, alpha=qa, alpha_n=inner if pre else 0)
+                qkv, _ = linear_fwd(ctx, self.fused_qkv, xn, alpha=qa, alpha_n=inner if pre else 0, ln=ln)
                 q, k, v = qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:]
             elif self.group is not None:
-                qkv, t = self._group_fwd(ctx, xn, alpha=qa, alpha_n=inner if pre else 0)
+                qkv, t = self._group_fwd(ctx, xn, alpha=qa, alpha_n=inner if pre else 0, ln=ln)
                 q, k, v = qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:]
                 if t is not None:
                     r = self.group.r
                     tq, tk, tv = t[:, :r], t[:, r:2 * r], t[:, 2 * r:]
             else:
+                assert ln is None
                 q, tq = linear_fwd(ctx, self.q, xn, alpha=qa)
                 k, tk = linear_fwd(ctx, self.k, xn)
                 v, tv = linear_fwd(ctx, self.v, xn)
         else:
-            q, tq = linear_fwd(ctx, self.q, xn, alpha=qa)
+            q, tq = linear_fwd(ctx, self.q, xn, alpha=qa, ln=ln)
             if kv_cache is not None:
                 k, v, tk, tv = kv_cache
             else:
@@ -566,14 +600,36 @@ class SpatialTransformerE:
         h0, _ = linear_fwd(ctx, self.proj_in, xn)                    # 1x1 conv == per-token linear
         if not (ctx.record and self.proj_in.tW is not None):         # operand of proj_in's dW when it trains
             xn = None
-        n1, s1 = self.ln1.fwd(ctx, h0)
-        h1, sv1 = self.attn1.fwd(ctx, n1, None, B, N, N, residual=h0)
-        n2, s2 = self.ln2.fwd(ctx, h1)
-        h2, sv2 = self.attn2.fwd(ctx, n2, c, B, N, Nkv, residual=h1, kv_cache=kv_cache)
-        n3, s3 = self.ln3.fwd(ctx, h2)
+        # norm1 / norm2 / norm3 (attention.py:271-275) run as the PROLOGUE of the product that reads them wherever nothing else
+        # needs the normalised tensor (ln_prologue_ok): then n_i below is the un-normalised input and s_i the statistics the
+        # product wrote for the backward pass
+        M = B * N
+        if self.attn1.ln_fusable(ctx, M):
+            l1 = self.ln1.prologue(ctx, M)
+            n1, s1 = h0, l1[3]
+        else:
+            l1 = None
+            n1, s1 = self.ln1.fwd(ctx, h0)
+        h1, sv1 = self.attn1.fwd(ctx, n1, None, B, N, N, residual=h0, ln=l1)
+        if self.attn2.ln_fusable(ctx, M):
+            l2 = self.ln2.prologue(ctx, M)
+            n2, s2 = h1, l2[3]
+        else:
+            l2 = None
+            n2, s2 = self.ln2.fwd(ctx, h1)
+        h2, sv2 = self.attn2.fwd(ctx, n2, c, B, N, Nkv, residual=h1, kv_cache=kv_cache, ln=l2)
         L = self.ff_proj
-        if (not ctx.record and ctx.dtype == torch.bfloat16 and L.N % 64 == 0
-                and hip.xs_geglu_ok(B * N, L.K, 0 if L.Wm is not None else L.r)):
+        ff_live = (bool(L.r) and not (L.Wm is not None and not ctx.record)) or (ctx.record and L.tW is not None)
+        xs_geglu = (not ctx.record and ctx.dtype == torch.bfloat16 and L.N % 64 == 0
+                    and hip.xs_geglu_ok(M, L.K, 0 if L.Wm is not None else L.r))
+        tile_geglu = not xs_geglu and not ctx.record and L.geglu_ok()
+        if not tile_geglu and ln_prologue_ok(ctx, M, L.N, L.K, ff_live, hip.ACT_GEGLU_SPLIT if xs_geglu else hip.ACT_NONE):
+            l3 = self.ln3.prologue(ctx, M)
+            n3, s3 = h2, l3[3]
+        else:
+            l3 = None
+            n3, s3 = self.ln3.fwd(ctx, h2)
+        if xs_geglu:
             # the same fusion on the x-stationary kernel (csrc/gemm_xs.hip): W's rows in their natural [value | gate] order
             tp = None
             if L.r and L.Wm is None:
@@ -581,9 +637,9 @@ class SpatialTransformerE:
                 hip.gemm(n3, L.A, tp)
             gg = ctx.new(B * N, 4 * self.C)
             hip.gemm(n3, L.W if L.Wm is None else L.Wm, gg, a2=tp, w2=L.B if tp is not None else None, bias=L.bias,
-                     act=hip.ACT_GEGLU_SPLIT, N=L.N)
+                     act=hip.ACT_GEGLU_SPLIT, N=L.N, ln=l3)
             p = None
-        elif not ctx.record and self.ff_proj.geglu_ok():
+        elif tile_geglu:
             # no backward will need the 8C-wide pre-activation: value * gelu(gate) is formed in the projection's
             # epilogue (half the output bytes, no separate GEGLU pass)
             Wg, bg, Bg = L.geglu_pack()
@@ -595,7 +651,7 @@ class SpatialTransformerE:
             hip.gemm(n3, Wg, gg, a2=tp, w2=Bg, bias=bg, act=hip.ACT_GEGLU, N=L.N)
             p = None
         else:
-            p, tp = linear_fwd(ctx, self.ff_proj, n3)                # [M, 8C]
+            p, tp = linear_fwd(ctx, self.ff_proj, n3, ln=l3)         # [M, 8C]
             gg = ctx.new(B * N, 4 * self.C)
             hip.geglu_fwd(p, gg)
         h3, tf = linear_fwd(ctx, self.ff_out, gg, residual=h2)

@@ -48,6 +48,7 @@ class GemmParams(C.Structure):
         ("C", C.c_void_p), ("ldc", C.c_long),
         ("out_f32", C.c_int), ("atomic", C.c_int), ("splitk", C.c_int),
         ("a1_group_n", C.c_int), ("a2_group_n", C.c_int), ("alpha_n", C.c_int),
+        ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float), ("ln_stats", C.c_void_p),
     ]
 
 
@@ -118,6 +119,9 @@ _DEBUG_SIGS = {
     "cl_debug_attention_variant": [_I],
     "cl_debug_attention_fuse_delta": [_I],
     "cl_debug_groupnorm_form": [_I, _I],
+    "cl_debug_gemm_tag": [_I],
+    "cl_debug_gemm_tag_count": [],
+    "cl_debug_gemm_tag_get": [_I, _P],
 }
 
 
@@ -154,13 +158,41 @@ GEMM_XS_TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "g
 XS_ENABLED = os.environ.get("CTRLORA_GEMM_XS", "1") != "0"
 
 
+# A/B switch: 0 = every LayerNorm stays its own launch
+LN_PROLOGUE = os.environ.get("CTRLORA_LN_PROLOGUE", "1") != "0"
+
+
+def xs_ln_ok(M: int, N: int, K: int, act: int = 0) -> bool:
+    """Can LayerNorm(x) . W^T run as ONE launch (LayerNorm as the x-stationary kernel's prologue, csrc/gemm_xs.hip)?  The
+    kernel's own preconditions: bf16 (the caller checks the dtype), K in {320, 640} with no second K segment, whole 32-column
+    output blocks, a GEGLU product only where xs_geglu_ok() sends it to this kernel anyway."""
+    if not (XS_ENABLED and LN_PROLOGUE) or K not in (320, 640) or M < 128:
+        return False
+    if act == ACT_GEGLU_SPLIT:
+        return N % 64 == 0 and xs_geglu_ok(M, K, 0)
+    return act == ACT_NONE and N % 32 == 0
+
+
+def gemm_tags():
+    """Launch-tag table of the contraction kernels (csrc/debug_hooks.h: cl_debug_gemm_tag; tools/prof_shapes.py)."""
+    L = lib()
+    out = []
+    buf = (C.c_long * 12)()
+    for i in range(int(L.cl_debug_gemm_tag_count())):
+        _chk(L.cl_debug_gemm_tag_get(i, C.cast(buf, C.c_void_p)), "cl_debug_gemm_tag_get")
+        v = list(buf)
+        out.append(dict(dtype=v[0], mode=v[1], M=v[2], N=v[3], K1=v[4], K2=v[5], act=v[6], residual=v[7], tag=v[8],
+                        workgroups=v[9], wg_size=v[10], launches=v[11]))
+    return out
+
+
 def xs_geglu_ok(M: int, K: int, r: int) -> bool:
     """Does the fused GEGLU projection of a no-grad forward go to the x-stationary kernel (act = ACT_GEGLU_SPLIT, natural row
-    order)?  Measured against the tile kernels' fused GEGLU (profiles/r05_gemm_xs/probe_xs_res_geglu.log): K = 320 wins at
-    every M (91 vs 102 us at 32768 rows, 310 vs 450 at 131072), K = 640 from 16384 rows (305 vs 339 us at 32768; 89 vs 78 at 8192)."""
+    order)?  Measured against the tile kernels' fused GEGLU (profiles/r05_gemm_xs/probe_xs_fast_gelu.log): K = 320 at every M
+    (73 vs 102 us at 32768 rows, 280 vs 450 at 131072), K = 640 from 8192 rows (253 vs 324 us at 32768; 71 vs 78 at 8192)."""
     if not XS_ENABLED or r not in (0, 128):
         return False
-    return (K == 320 and M >= 128) or (K == 640 and M >= 16384)
+    return (K == 320 and M >= 128) or (K == 640 and M >= 8192)
 
 
 def load_gemm_table(path: str, clear: bool = True) -> int:
@@ -270,10 +302,11 @@ def zero_page(device) -> torch.Tensor:
 
 def gemm(a1, w1, out, *, a2=None, w2=None, bias=None, rowbias=None, rows_per_batch=0, residual=None,
          alpha=1.0, beta=0.0, act=ACT_NONE, mode=LINEAR, conv=None, k1=None, out_f32=False, atomic=False,
-         splitk=1, M=None, N=None, dtype=None, a1_group_n=0, a2_group_n=0, alpha_n=0):
+         splitk=1, M=None, N=None, dtype=None, a1_group_n=0, a2_group_n=0, alpha_n=0, ln=None):
     """out[M,N] = act(a1.w1^T + a2.w2^T + bias + rowbias[m // rows_per_batch]) * alpha + beta * residual.
 
     a1: [M,K1] (LINEAR) or the NHWC activation [B*Hin*Win, C] (conv modes, conv=(B,Hin,Win,Hout,Wout)).
+    ln = (gamma, beta, eps, stats or None): LayerNorm of a1's rows as a prologue of the product (xs_ln_ok() says when).
     """
     p = GemmParams()
     if _workspace is None:
@@ -299,6 +332,8 @@ def gemm(a1, w1, out, *, a2=None, w2=None, bias=None, rowbias=None, rows_per_bat
     p.C = out.data_ptr(); p.ldc = ld(out)
     p.out_f32 = int(out_f32); p.atomic = int(atomic); p.splitk = splitk
     p.a1_group_n = a1_group_n; p.a2_group_n = a2_group_n; p.alpha_n = alpha_n
+    if ln is not None:
+        p.ln_gamma = ln[0].data_ptr(); p.ln_beta = ln[1].data_ptr(); p.ln_eps = ln[2]; p.ln_stats = ptr(ln[3])
     _chk(lib().cl_gemm(C.byref(p), dty, stream()), "cl_gemm")
     return out
 

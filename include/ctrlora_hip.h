@@ -112,6 +112,12 @@ typedef struct cl_gemm_params {
    * projection of a CrossAttention writes q * (d_head^-0.5 * log2 e) and plain k, v in ONE launch: the pre-scaled-Q
    * contract of cl_attention_*_v2 (CL_ATTN_Q_PRESCALED). */
   int alpha_n;
+  /* ABI 7: LayerNorm as a prologue of the product (ldm/modules/attention.py:271-275: x + attn(norm(x)) -- the norm never
+   * exists in memory).  ln_gamma != NULL: A1 holds the UN-normalised rows and the kernel forms (row - mean) * rstd * gamma
+   * + beta over the K1 columns before the contraction (fp32 statistics; rounded to `dtype` like cl_layernorm_fwd's output).
+   * ln_stats (may be NULL): [M][2] fp32 {mean, rstd} for cl_layernorm_bwd.  bf16, linear mode, K1 in {320, 640}, K2 = 0,
+   * no rowbias / residual only -- CL_EINVAL otherwise (the caller then runs cl_layernorm_fwd itself). */
+  const float* ln_gamma; const float* ln_beta; float ln_eps; float* ln_stats;
 } cl_gemm_params;
 
 /* Generic entry; the named operators below are thin fillers of cl_gemm_params. */

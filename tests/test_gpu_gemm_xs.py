@@ -137,3 +137,43 @@ def test_xs_configuration_falls_back_to_the_tile_kernels_for_what_it_does_not_co
         L.cl_gemm_force_config(-1)
     assert rel_l2(y.cpu().double(), want) < 2.5e-3
     assert rel_l2(y2.cpu().double(), x2.double() @ W2.double().t()) < 2.5e-3
+
+
+@pytest.mark.parametrize("M,N,K,geglu", [(1000, 960, 320, False), (4100, 320, 320, False), (2048, 1920, 640, False),
+                                         (1000, 2560, 320, True), (515, 5120, 640, True)])
+def test_xs_layernorm_prologue_vs_fp64_and_vs_the_layernorm_kernel(M, N, K, geglu):
+    """hip.gemm(ln=...): LayerNorm(x) . W^T in one launch (BasicTransformerBlock norm1/2/3 -> the product that reads them,
+    ldm/modules/attention.py:271-275).  Against fp64 (LayerNorm in double, rounded to bf16 where the stand-alone kernel
+    rounds, then the product), against cl_layernorm_fwd + the same product, and the (mean, rstd) it leaves for the backward."""
+    hip, L = _need_gpu()
+    g = torch.Generator().manual_seed(M + N + K + 7)
+    x = ((torch.randn(M, K, generator=g) * 1.7 + 0.6)).to(torch.bfloat16)
+    W = _mk(g, N, K, scale=0.05)
+    gamma, beta, bias = 1 + 0.3 * torch.randn(K, generator=g), 0.3 * torch.randn(K, generator=g), torch.randn(N, generator=g)
+    xn = torch.nn.functional.layer_norm(x.double(), (K,), gamma.double(), beta.double(), 1e-5).to(torch.bfloat16)
+    h = xn.double() @ W.double().t() + bias.double()
+    want = h[:, :N // 2] * torch.nn.functional.gelu(h[:, N // 2:]) if geglu else h
+    NO = N // 2 if geglu else N
+    act = hip.ACT_GEGLU_SPLIT if geglu else hip.ACT_NONE
+    xd, Wd, gd, bd, biasd = x.cuda(), W.cuda(), gamma.cuda(), beta.cuda(), bias.cuda()
+    stats = torch.full((M, 2), float("nan"), device="cuda")
+    outs = []
+    for _ in range(2):
+        y = torch.full((M, NO), float("nan"), dtype=torch.bfloat16, device="cuda")
+        hip.gemm(xd, Wd, y, bias=biasd, act=act, N=N, ln=(gd, bd, 1e-5, stats))
+        outs.append(y.cpu())
+    assert rel_l2(outs[0].double(), want) < 2.5e-3
+    assert torch.equal(outs[0], outs[1])
+    # the two-launch form it replaces
+    n2, st2 = torch.empty_like(xd), torch.empty(M, 2, device="cuda")
+    hip.layernorm_fwd(xd, n2, gd, bd, 1e-5, st2)
+    y2 = torch.empty(M, NO, dtype=torch.bfloat16, device="cuda")
+    hip.gemm(n2, Wd, y2, bias=biasd, act=act, N=N)
+    assert rel_l2(outs[0].double(), y2.cpu().double()) < 1.5e-3       # (a different summation order flips a few bf16 roundings)
+    assert torch.allclose(stats.cpu(), st2.cpu(), rtol=2e-6, atol=1e-7)
+    mu = x.double().mean(1)
+    assert torch.allclose(stats[:, 0].cpu().double(), mu, rtol=1e-5, atol=1e-6)
+    # refused where the kernel has no instance: a second K segment, fp32
+    with pytest.raises(hip.HipError):
+        hip.gemm(xd, Wd, torch.empty(M, NO, dtype=torch.bfloat16, device="cuda"), a2=xd[:, :128].contiguous(),
+                 w2=Wd[:, :128].contiguous(), bias=biasd, act=act, N=N, ln=(gd, bd, 1e-5, None))

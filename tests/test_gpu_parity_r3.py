@@ -80,6 +80,38 @@ def test_inference_executor_sd15_latent64_eps_vs_oracle():
         assert rel_l2(eps_kv, eps) < 1e-6            # the cache holds exactly what the uncached call computes
         if cmp_ is not None:
             assert e < 1.3 * cmp_ + 1e-3, (e, cmp_)
+        if B == 16:
+            # round 5: LayerNorm as the prologue of the product that reads it (csrc/gemm_xs.hip): 42 of the 69 launches gone
+            # (the C = 320 / 640 levels of both networks: 14 transformer blocks x 3 norms) and the same ACCURACY as with every
+            # LayerNorm as its own launch.  The two eps tensors themselves differ at the bf16 noise level (measured 7.9e-3 for
+            # 8.6e-3 against the oracle): the statistics are summed in another order, a few normalised values round the other way,
+            # and ~100 bf16-rounded layers amplify any perturbation to their own rounding noise -- so the gate is each form
+            # against the ORACLE, and the two errors against each other
+            from ctrlora_amd import hip
+            calls = {"n": 0}
+            orig = hip.layernorm_fwd
+
+            def counting(*a, **k):
+                calls["n"] += 1
+                return orig(*a, **k)
+            hip.layernorm_fwd = counting
+            try:
+                assert hip.LN_PROLOGUE and hip.XS_ENABLED
+                calls["n"] = 0
+                model.apply_model(x, t, cond)
+                n_on = calls["n"]
+                hip.LN_PROLOGUE = False
+                calls["n"] = 0
+                eps_off = model.apply_model(x, t, cond)
+                n_off = calls["n"]
+            finally:
+                hip.LN_PROLOGUE = True
+                hip.layernorm_fwd = orig
+            d, e_off = rel_l2(eps, eps_off), rel_l2(eps_off, ref)
+            _record("inference_ln_prologue_vs_separate_layernorm", eps_diff=d, ln_launches_on=n_on, ln_launches_off=n_off,
+                    eps_on_vs_oracle=e, eps_off_vs_oracle=e_off)
+            assert n_off == 69 and n_on == 27, (n_on, n_off)
+            assert d < BF16_EPS and e_off < BF16_EPS and abs(e - e_off) < 0.15 * e_off, (d, e, e_off)
 
 
 def test_lora_fold_is_as_accurate_as_the_two_segment_executor_small_update():

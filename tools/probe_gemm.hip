@@ -92,10 +92,11 @@ static void case_linear(const char* name, int dtype, int M, int N, int K1, int K
 // groups > 1: output columns [g N / groups, (g + 1) N / groups) take their second K segment from columns [g K2, (g + 1) K2) of A2
 static float g_xs_beta = 0.f;      // != 0: the next case_xs adds beta * residual
 static bool g_xs_geglu = false;    // the next case_xs is a fused GEGLU projection (N = value | gate rows, output N / 2 columns)
+static bool g_xs_ln = false;       // the next case_xs normalises its rows first (LayerNorm prologue; K2 must be 0)
 static void case_xs(const char* name, int M, int N, int K1, int K2, bool bias, int groups, float alpha, int alpha_n, int nsplit,
                     bool timeit = false) {
   const int dtype = CL_BF16;
-  const float beta = g_xs_beta; const bool geglu = g_xs_geglu;
+  const float beta = g_xs_beta; const bool geglu = g_xs_geglu, ln = g_xs_ln;
   const int NO = geglu ? N / 2 : N;     // output columns
   Buf A1, W1, A2, W2, C, C2, R; std::vector<float> hb(N);
   if (beta != 0.f) R.init((size_t)M * NO, dtype);
@@ -110,6 +111,26 @@ static void case_xs(const char* name, int M, int N, int K1, int K2, bool bias, i
   p.alpha = alpha; p.alpha_n = alpha_n; p.C = C.d; p.ldc = NO; p.splitk = 1;
   if (beta != 0.f) { p.residual = R.d; p.ldr = NO; p.beta = beta; }
   if (geglu) p.act = ACT_GEGLU_SPLIT;
+  std::vector<float> lg(K1), lb(K1), xn;      // LayerNorm prologue: the CPU reference normalises in double and rounds to bf16
+  float *dlg = nullptr, *dlb = nullptr, *dstats = nullptr;
+  if (ln) {
+    for (size_t i = 0; i < A1.h.size(); ++i) A1.h[i] = h_bf2f(h_f2bf(A1.h[i] * 1.7f + 0.6f));
+    A1.upload();
+    for (int k = 0; k < K1; ++k) { lg[k] = 1.0f + 0.3f * frand(); lb[k] = 0.3f * frand(); }
+    HIPCHK(hipMalloc(&dlg, K1 * 4)); HIPCHK(hipMalloc(&dlb, K1 * 4)); HIPCHK(hipMalloc(&dstats, (size_t)M * 8));
+    HIPCHK(hipMemcpy(dlg, lg.data(), K1 * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dlb, lb.data(), K1 * 4, hipMemcpyHostToDevice));
+    p.ln_gamma = dlg; p.ln_beta = dlb; p.ln_eps = 1e-5f; p.ln_stats = dstats;
+    xn.resize(A1.h.size());
+    for (int m = 0; m < M; ++m) {
+      double mu = 0, var = 0;
+      for (int k = 0; k < K1; ++k) mu += A1.h[(size_t)m * K1 + k];
+      mu /= K1;
+      for (int k = 0; k < K1; ++k) { const double d = A1.h[(size_t)m * K1 + k] - mu; var += d * d; }
+      const double rstd = 1.0 / std::sqrt(var / K1 + 1e-5);
+      for (int k = 0; k < K1; ++k) xn[(size_t)m * K1 + k] = h_bf2f(h_f2bf((float)((A1.h[(size_t)m * K1 + k] - mu) * rstd * lg[k] + lb[k])));
+    }
+  }
+  const std::vector<float>& XA = ln ? xn : A1.h;
   HIPCHK(hipMemset(C.d, 0xff, (size_t)M * NO * 2));
   const int rc = launch_gemm_xs(p, 0, nsplit);
   HIPCHK(hipDeviceSynchronize());
@@ -122,7 +143,7 @@ static void case_xs(const char* name, int M, int N, int K1, int K2, bool bias, i
     auto dotrow = [&](int n) {
       double s = 0;
       const int g = groups > 1 ? n / (N / groups) : 0;
-      for (int k = 0; k < K1; ++k) s += (double)A1.h[(size_t)m * K1 + k] * W1.h[(size_t)n * K1 + k];
+      for (int k = 0; k < K1; ++k) s += (double)XA[(size_t)m * K1 + k] * W1.h[(size_t)n * K1 + k];
       for (int k = 0; k < K2; ++k) s += (double)A2.h[(size_t)m * K2 * groups + g * K2 + k] * W2.h[(size_t)n * K2 + k];
       if (bias) s += hb[n];
       return s;
@@ -136,6 +157,21 @@ static void case_xs(const char* name, int M, int N, int K1, int K2, bool bias, i
     }
   }
   report(name, num, den, 4e-3);
+  if (ln) {   // the statistics the kernel hands to the backward pass
+    std::vector<float> st((size_t)M * 2);
+    HIPCHK(hipMemcpy(st.data(), dstats, st.size() * 4, hipMemcpyDeviceToHost));
+    double worst = 0;
+    for (int m = 0; m < M; ++m) {
+      double mu = 0, var = 0;
+      for (int k = 0; k < K1; ++k) mu += A1.h[(size_t)m * K1 + k];
+      mu /= K1;
+      for (int k = 0; k < K1; ++k) { const double d = A1.h[(size_t)m * K1 + k] - mu; var += d * d; }
+      const double rstd = 1.0 / std::sqrt(var / K1 + 1e-5);
+      worst = std::max(worst, std::max(std::fabs(st[2 * m] - mu) / (std::fabs(mu) + 1e-3), std::fabs(st[2 * m + 1] - rstd) / rstd));
+    }
+    printf("       LayerNorm statistics (mean, rstd) worst relative error %.2e%s\n", worst, worst > 1e-5 ? "  <-- FAIL" : "");
+    if (worst > 1e-5) g_fail++;
+  }
   // bitwise repeatability + agreement with the tile kernels on the same parameters
   std::vector<uint16_t> r0((size_t)M * NO), r1((size_t)M * NO);
   HIPCHK(hipMemcpy(r0.data(), C.d, r0.size() * 2, hipMemcpyDeviceToHost));
@@ -148,12 +184,12 @@ static void case_xs(const char* name, int M, int N, int K1, int K2, bool bias, i
   }
   p.C = C2.d;
   const int keep = g_gemm_force_cfg; g_gemm_force_cfg = -1;
-  if (!geglu) launch_gemm(p, dtype, 0);       // (the tile kernels' GEGLU wants permuted rows: no cross-check there)
+  if (!geglu && !ln) launch_gemm(p, dtype, 0);       // (the tile kernels' GEGLU wants permuted rows, and they have no LayerNorm prologue: no cross-check there)
   g_gemm_force_cfg = keep;
   HIPCHK(hipDeviceSynchronize());
   C2.download(dtype);
   double n2 = 0, d2 = 0;
-  if (!geglu) for (size_t i = 0; i < (size_t)M * NO; ++i) { const double d = C.h[i] - C2.h[i]; n2 += d * d; d2 += (double)C2.h[i] * C2.h[i]; }
+  if (!geglu && !ln) for (size_t i = 0; i < (size_t)M * NO; ++i) { const double d = C.h[i] - C2.h[i]; n2 += d * d; d2 += (double)C2.h[i] * C2.h[i]; }
   printf("       repeat launches differing: %d of 3; vs tile kernels rel_l2 %.2e%s\n", diff, std::sqrt(n2 / (d2 + 1e-30)),
          (diff || std::sqrt(n2 / (d2 + 1e-30)) > 4e-3) ? "  <-- FAIL" : "");
   if (diff || std::sqrt(n2 / (d2 + 1e-30)) > 4e-3) g_fail++;
@@ -170,12 +206,13 @@ static void case_xs(const char* name, int M, int N, int K1, int K2, bool bias, i
       return best * 1e3;
     };
     const double fl = 2.0 * M * N * (K1 + K2);
-    const float t_xs = timed(34), t_tile = geglu ? 0.f : timed(-1);
+    const float t_xs = timed(34), t_tile = (geglu || ln) ? 0.f : timed(-1);
     printf("[TIME] %-44s xs %7.2f us (%6.1f TF/s)   tile kernels (rules) %7.2f us\n", name, t_xs, fl / t_xs * 1e-6, t_tile);
   }
   hipFree(A1.d); hipFree(W1.d); hipFree(C.d); hipFree(C2.d); if (K2) { hipFree(A2.d); hipFree(W2.d); } if (dbias) hipFree(dbias);
   if (R.d) hipFree(R.d);
-  g_xs_beta = 0.f; g_xs_geglu = false;
+  if (dlg) { hipFree(dlg); hipFree(dlb); hipFree(dstats); }
+  g_xs_beta = 0.f; g_xs_geglu = false; g_xs_ln = false;
 }
 
 // ---------------- GEGLU-fused projection ----------------
@@ -510,8 +547,15 @@ int main(int argc, char** argv) {
     g_xs_geglu = true; case_xs("xs geglu 1000x(2*1280)x320+128", 1000, 2560, 320, 128, true, 1, 1.f, 0, 0);
     g_xs_geglu = true; case_xs("xs geglu 384x(2*2560)x640 nsplit 3", 384, 5120, 640, 0, true, 1, 1.f, 0, 3);
     g_xs_geglu = true; case_xs("xs geglu 257x(2*96)x640+128 (3 blocks)", 257, 192, 640, 128, false, 1, 1.f, 0, 1);
-    const int ns[] = {0, 1, 2, 4};
-    for (int n : ns) {
+    g_xs_ln = true; case_xs("xs LN 300x960x320 alpha_n", 300, 960, 320, 0, true, 1, 0.3f, 320, 0);
+    g_xs_ln = true; case_xs("xs LN 1000x320x320 nsplit 2", 1000, 320, 320, 0, false, 1, 1.f, 0, 2);
+    g_xs_ln = true; case_xs("xs LN 515x1920x640", 515, 1920, 640, 0, true, 1, 1.f, 0, 0);
+    g_xs_ln = true; g_xs_geglu = true; case_xs("xs LN geglu 700x(2*1280)x320", 700, 2560, 320, 0, true, 1, 1.f, 0, 0);
+    g_xs_ln = true; g_xs_geglu = true; case_xs("xs LN geglu 384x(2*2560)x640", 384, 5120, 640, 0, true, 1, 1.f, 0, 0);
+    const bool quick = argc > 2 && !strcmp(argv[2], "quick");
+    const int ns_all[] = {0, 1, 2, 4};
+    for (int n : ns_all) {
+      if (quick && n) break;
       char nm[96];
       snprintf(nm, sizeof nm, "xs 32768x2560x320 nsplit %d", n);       case_xs(nm, 32768, 2560, 320, 0, true, 1, 1.f, 0, n, true);
       snprintf(nm, sizeof nm, "xs 32768x2560x320+128 nsplit %d", n);   case_xs(nm, 32768, 2560, 320, 128, true, 1, 1.f, 0, n, true);
@@ -531,6 +575,12 @@ int main(int argc, char** argv) {
       g_xs_geglu = true; snprintf(nm, sizeof nm, "xs geglu 32768x5120x640 nsplit %d", n);   case_xs(nm, 32768, 5120, 640, 0, true, 1, 1.f, 0, n, true);
       g_xs_geglu = true; snprintf(nm, sizeof nm, "xs geglu 8192x5120x640 nsplit %d", n);    case_xs(nm, 8192, 5120, 640, 0, true, 1, 1.f, 0, n, true);
     }
+    g_xs_ln = true; case_xs("xs LN 131072x960x320", 131072, 960, 320, 0, true, 1, 0.3f, 320, 0, true);
+    g_xs_ln = true; case_xs("xs LN 131072x320x320", 131072, 320, 320, 0, false, 1, 1.f, 0, 0, true);
+    g_xs_ln = true; case_xs("xs LN 32768x1920x640", 32768, 1920, 640, 0, true, 1, 1.f, 0, 0, true);
+    g_xs_ln = true; g_xs_geglu = true; case_xs("xs LN geglu 131072x2560x320", 131072, 2560, 320, 0, true, 1, 1.f, 0, 0, true);
+    g_xs_ln = true; g_xs_geglu = true; case_xs("xs LN geglu 32768x2560x320", 32768, 2560, 320, 0, true, 1, 1.f, 0, 0, true);
+    g_xs_ln = true; g_xs_geglu = true; case_xs("xs LN geglu 32768x5120x640", 32768, 5120, 640, 0, true, 1, 1.f, 0, 0, true);
     // the tile kernels' fused GEGLU on the same products (rows permuted per 160-column tile), for the comparison
     g_gemm_force_cfg = -1;
     g_probe_act = ACT_GEGLU;
