@@ -35,13 +35,63 @@ sys.path.insert(0, ROOT)
 TRAIN_TFLOP_PER_IMAGE = {32: 1.913, 64: 1.941, 128: 1.996, 256: 2.11, 512: 2.33}
 DDIM_TFLOP_PER_STEP_IMAGE = 2.207
 STOCK_BF16_IMAGES_PER_S = 42.3   # profiles/r02_compare_precision.json: stock kernels, bf16 autocast, B=8, one MI355X
+
+
+def stock_reference():
+    """(images/s, source) of the reference's modules on PyTorch-ROCm's own kernels under bf16 autocast, B = 8, one MI355X: the
+    newest tests/tools/compare_stock.py result under profiles/ (re-measured in round 5), else the round-2 figure."""
+    for name in ("r05_compare_precision.json", "r02_compare_precision.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return float(json.load(f)["stock_bf16_autocast"]["images_per_s"]), "profiles/" + name
+        except Exception:
+            continue
+    return STOCK_BF16_IMAGES_PER_S, "profiles/r02_compare_precision.json"
 PEAK_HBM_TBS = 8.0          # TB/s, MI355X_MICROARCH.md
 PEAK_BF16_TFLOPS = 2500.0
+
+
+class _skip_default_init:
+    """Full-width models only: nn.Linear / nn.Conv2d constructors leave their parameters un-drawn (torch's per-layer
+    kaiming_uniform_ over 1.3 G parameters is ~25 s of single-threaded host time per build -- per RANK on a multi-GPU bench,
+    per test in the GPU suite); _fill_default_init() then draws the same distribution from one random block."""
+
+    def __enter__(self):
+        import torch.nn as nn
+        self.saved = (nn.Linear.reset_parameters, nn.modules.conv._ConvNd.reset_parameters)
+        nn.Linear.reset_parameters = lambda m: None
+        nn.modules.conv._ConvNd.reset_parameters = lambda m: None
+
+    def __exit__(self, *a):
+        import torch.nn as nn
+        nn.Linear.reset_parameters, nn.modules.conv._ConvNd.reset_parameters = self.saved
+
+
+def _fill_default_init(model, seed):
+    """torch's default initialisation of every nn.Linear / nn.Conv2d (weight and bias ~ U(-1 / sqrt(fan_in), 1 / sqrt(fan_in)):
+    kaiming_uniform_(a = sqrt 5)) as windows of ONE seeded block of 64 M uniform numbers -- a different window per parameter
+    (offset = crc32 of its name), scaled by its own bound: memory-copy speed instead of a random draw per element."""
+    import zlib
+    import torch.nn as nn
+    block = torch.rand(1 << 26, generator=torch.Generator().manual_seed(seed + 12345)).mul_(2).sub_(1)
+    with torch.no_grad():
+        for name, m in model.named_modules():
+            if not isinstance(m, (nn.Linear, nn.modules.conv._ConvNd)):
+                continue
+            bound = float(m.weight[0].numel()) ** -0.5
+            for pn in ("weight", "bias"):
+                p = getattr(m, pn, None)
+                if p is None:
+                    continue
+                n = p.numel()
+                off = zlib.crc32(f"{name}.{pn}".encode()) % (block.numel() - n) if n < block.numel() else 0
+                p.copy_(block[off:off + n].view(p.shape)).mul_(bound)
 
 
 def build_model(config, seed, rank_override=None, tiny=False, mutate=None):
     """The drop-in path: YAML -> instantiate_from_config, VAE / CLIP replaced by Identity (synthetic latents).
     `mutate(params)` may edit the YAML's model params before instantiation (tests)."""
+    import contextlib
     from ldm.util import instantiate_from_config
     with open(os.path.join(ROOT, "configs", config)) as f:
         cfg = yaml.safe_load(f)["model"]
@@ -55,7 +105,10 @@ def build_model(config, seed, rank_override=None, tiny=False, mutate=None):
             p[k]["params"].update(model_channels=64, context_dim=96)
         p["control_stage_config"]["params"]["lora_rank"] = 32
     torch.manual_seed(seed)
-    model = instantiate_from_config(cfg)
+    with (contextlib.nullcontext() if tiny else _skip_default_init()):
+        model = instantiate_from_config(cfg)
+    if not tiny:
+        _fill_default_init(model, seed)
     # re-draw the zero-initialised parameters (zero convs, proj_out, out conv, LoRA up) so that no path is
     # trivially zero
     g = torch.Generator().manual_seed(seed + 1)
@@ -278,7 +331,56 @@ def vae_bench(device, dtype, B=8, iters=3):
     ms = (time.perf_counter() - t0) / iters * 1e3
     assert torch.isfinite(post.mean).all() and "_enc" in vae.__dict__
     gf = 1117.0 * 2 * B              # GFLOP: 1 117 per 512x512 encode
-    return dict(images=2 * B, ms=round(ms, 2), tflops=round(gf / ms, 1), mfma_frac=round(gf / ms / PEAK_BF16_TFLOPS, 4))
+    out = dict(images=2 * B, ms=round(ms, 2), tflops=round(gf / ms, 1), mfma_frac=round(gf / ms / PEAK_BF16_TFLOPS, 4))
+    try:
+        out["roofline"] = first_stage_roofline(device, dtype, 2 * B)
+    except Exception as e:
+        print(f"[bench] first-stage roofline probe failed: {type(e).__name__}: {e}", file=sys.stderr)
+    return out
+
+
+def first_stage_roofline(device, dtype, NB):
+    """The encoder's kernels at its four resolutions, each timed alone with HIP events on the launching stream (the encode is one
+    serial chain of them: profiles/r05_vae/vae_kernel_stats.txt has the in-run totals): the 3x3 convs of the ResnetBlocks
+    (ldm/modules/diffusionmodules/model.py:97-149) against the MFMA peak, GroupNorm(32)+swish against the HBM peak on
+    algorithmic bytes (one read + one write of the tensor)."""
+    from ctrlora_amd import hip
+
+    def timed(run, iters):
+        for _ in range(2):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    rows = []
+    for H, C, n_conv, n_gn in ((512, 128, 4, 4), (256, 256, 3, 3), (128, 512, 3, 3), (64, 512, 8, 9)):
+        M = NB * H * H
+        x = torch.randn(M, C, device=device).to(dtype)
+        w = (torch.randn(C, 9 * C, device=device) * 0.02).to(dtype)
+        bias = torch.zeros(C, device=device)
+        y = torch.empty(M, C, device=device, dtype=dtype)
+        ms_c = timed(lambda: hip.gemm(x, w, y, bias=bias, mode=hip.CONV_S1, conv=(NB, H, H, H, H), k1=C), 4)
+        fl = 2.0 * M * C * 9 * C
+        gamma, beta = torch.ones(C, device=device), torch.zeros(C, device=device)
+        stats = torch.empty(NB, 32, 2, device=device)
+        ws = torch.empty(max(hip.groupnorm_ws(NB, H * H, C), 1 << 20), device=device)
+        ms_g = timed(lambda: hip.groupnorm_fwd(x, y, gamma, beta, NB, H * H, 1e-6, True, stats, ws), 4)
+        by = 2.0 * M * C * 2
+        rows.append(dict(level=f"{H}x{H}x{C}", conv3x3=dict(n_per_encode=n_conv, ms=round(ms_c, 3), tflops=round(fl / ms_c * 1e-9, 1),
+                                                            mfma_frac=round(fl / ms_c * 1e-9 / PEAK_BF16_TFLOPS, 4)),
+                         groupnorm_swish=dict(n_per_encode=n_gn, ms=round(ms_g, 3), tb_per_s=round(by / ms_g * 1e-9, 2),
+                                              hbm_frac=round(by / ms_g * 1e-9 / 8.0, 4))))
+        del x, w, y, ws
+    t_conv = sum(r["conv3x3"]["ms"] * r["conv3x3"]["n_per_encode"] for r in rows)
+    t_gn = sum(r["groupnorm_swish"]["ms"] * r["groupnorm_swish"]["n_per_encode"] for r in rows)
+    return dict(levels=rows, ms_in_same_channel_convs=round(t_conv, 2), ms_in_groupnorms=round(t_gn, 2),
+                note="isolated launches at the encoder's shapes (16 images); the channel-changing convs, the two stride-2 convs, "
+                     "conv_in and the 4096-token attention are the remainder of `ms`")
 
 
 def ddim_bench(device, dtype, B=16, S=50, tiny=False, loops=5, warm_loops=10, extras=True):
@@ -611,6 +713,61 @@ def spawn_ranks(n, argv):
     return rc if lines else (rc or 1)
 
 
+def dist_dry_run(args, world, rank, local):
+    """The launch path of `--gpus N` without the model (`--dist-dry-run`): process group on 127.0.0.1 (RCCL when the host has
+    GPUs, gloo otherwise), W warm-up + K timed "steps" that all-reduce one 4 MB bucket asynchronously and wait for it -- the
+    exchange pattern of ctrlora_amd.parallel.GradAllReduce -- bracketed exactly like the measured region (synchronize, barrier,
+    MAX over ranks), one JSON line from rank 0.  Cheap first contact for a multi-GPU node; runs on the CPU in the test suite."""
+    import datetime
+    gpu = torch.cuda.is_available()
+    device = torch.device("cuda", local) if gpu else torch.device("cpu")
+    if gpu:
+        torch.cuda.set_device(local)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    multi = world > 1 or "RANK" in os.environ
+    if multi:
+        kw = dict(device_id=device) if gpu else {}
+        dist.init_process_group("nccl" if gpu else "gloo", timeout=datetime.timedelta(seconds=120), **kw)
+    sync = torch.cuda.synchronize if gpu else (lambda: None)
+    bucket = torch.empty(1 << 20, dtype=torch.float32, device=device)
+
+    def step():
+        bucket.fill_(float(rank + 1))
+        if multi:
+            dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=True).wait()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    if multi:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    if multi:
+        dist.barrier()
+    sync()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    if multi:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    want = world * (world + 1) / 2 if multi else float(rank + 1)
+    ok = bool(torch.all(bucket == want))
+    okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    if multi:
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(json.dumps({"metric": "launch-path dry run (no model): 4 MB all-reduce per step", "value": round(args.steps / float(dt), 3),
+                          "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(float(dt) / args.steps * 1e3, 3), "dry_run": True,
+                          "backend": (dist.get_backend() if multi else "none"), "device": device.type,
+                          "allreduce_sum_correct_on_every_rank": bool(int(okt))}))
+    if multi:
+        dist.destroy_process_group()
+    return 0 if int(okt) else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -636,6 +793,10 @@ def main():
     ap.add_argument("--pretrain-only", action="store_true",
                     help="evidence run, not the headline: one-GPU Base-ControlNet pre-training steps (BASELINE configs[3])")
     ap.add_argument("--tiny", action="store_true", help="debug: narrow model")
+    ap.add_argument("--dist-dry-run", action="store_true",
+                    help="launch-path check without the model: the ranks are started, rendezvous on 127.0.0.1, all-reduce a 4 MB "
+                         "bucket per step inside the same barrier / MAX-over-ranks bracket as the timed region, rank 0 prints one "
+                         "JSON line.  RCCL on GPUs, gloo on a CPU-only host (tests/test_bench_spawn.py runs it with 2 ranks)")
     ap.add_argument("--tag-gemm", default=None, metavar="JSON",
                     help="profiling aid: tag every contraction launch with its product signature (extra empty workgroups, "
                          "csrc/debug_hooks.h) and write the tag table here -- tools/prof_shapes.py joins it with a rocprofv3 "
@@ -653,6 +814,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.dist_dry_run:
+        return dist_dry_run(args, world, rank, local)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1 or "RANK" in os.environ:
@@ -802,9 +965,10 @@ def main():
         if world == 1 and args.rank_lora == 128 and args.dtype == "bf16" and not args.tiny and B == 8:
             # context, not credit: the reference's own modules on PyTorch-ROCm eager kernels, bf16 autocast, same workload and
             # GPU model (tests/tools/compare_stock.py -> profiles/r02_compare_precision.json); not re-measured in this run
-            out["vs_stock"] = {"value": round(ips / STOCK_BF16_IMAGES_PER_S, 2), "stock_images_per_s": STOCK_BF16_IMAGES_PER_S,
-                               "kind": "static: profiles/r02_compare_precision.json (reference modules, torch.autocast(bf16), "
-                                       "PyTorch-ROCm eager, B=8, 1x MI355X)"}
+            stock_ips, stock_src = stock_reference()
+            out["vs_stock"] = {"value": round(ips / stock_ips, 2), "stock_images_per_s": stock_ips,
+                               "kind": f"static: {stock_src} (reference modules, torch.autocast(bf16), PyTorch-ROCm eager, B=8, "
+                                       "1x MI355X; tests/tools/compare_stock.py)"}
         achieved = tf_img * ips / world          # per-GPU TFLOP/s
         roof = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,

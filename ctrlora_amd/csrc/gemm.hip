@@ -1175,7 +1175,7 @@ struct TuneKey {
 static std::map<TuneKey, std::pair<int, int>> g_tune;
 
 int gemm_tune_set(int dtype, int mode, int M, int N, int K1, int K2, int geglu, int cfg, int splitk) {
-  if (cfg < 0 || cfg > 34 || splitk < 0 || splitk > 64) return CL_EINVAL;
+  if (cfg < 0 || cfg > 36 || splitk < 0 || splitk > 64) return CL_EINVAL;
   g_tune[TuneKey{{dtype, mode, M, N, K1, K2, geglu ? 1 : 0}}] = std::make_pair(cfg, splitk);
   return CL_OK;
 }
@@ -1235,7 +1235,7 @@ static int launch_t_cfg(const GemmParams& p, hipStream_t stream, int cfg) {
         case 0: case 24: return 64;
         case 1: case 6: case 7: case 22: return 128;
         case 2: case 3: case 4: case 5: case 23: return 160;
-        case 31: case 32: return (lines && p.N % 80 == 0) ? 80 : 128;
+        case 31: case 32: case 35: case 36: return (lines && p.N % 80 == 0) ? 80 : 128;
         case 33: return (lines && p.N % 320 == 0) ? 320 : 128;
         case 34: return 32;    // x-stationary kernel: 32-column chunks (its own launcher re-checks the groups)
         default: return lines ? ((c == 8 || c == 12 || c == 14 || c == 16 || c == 18 || c == 20 || c == 10 || c == 25 || c == 27 || c == 29) ? 160 : 128) : 128;
@@ -1320,6 +1320,14 @@ static int launch_t_cfg(const GemmParams& p, hipStream_t stream, int cfg) {
       if (p.K1 % kps || p.K2 % kps || p.mode != GEMM_LINEAR || p.N % 80)
         return launch_cfg<T, 128, 128, 2, 2, 2, 4>(p, stream);
       return cfg == 31 ? launch_fl<T, 128, 80, 4, 1, 2>(p, stream) : launch_fl<T, 128, 80, 4, 1, 3>(p, stream);
+    }
+    case 35: case 36: {   // 64 x 80 full-line tiles, 4 waves of 16 x 80 (3- / 2-slot ring, 54 / 36 KB: two or three workgroups per CU):
+      // the M = 2048 products of the 16x16 level (N = K = 1280) are 256 workgroups of 4 waves as 128 x 80 tiles -- one wave
+      // per SIMD, nothing to hide a stage's DMA / barrier latency behind (18 us for 6.7 GFLOP); 512 workgroups here
+      const int kps = 128 / (int)sizeof(T);
+      if (p.K1 % kps || p.K2 % kps || p.mode != GEMM_LINEAR || p.N % 80)
+        return launch_cfg<T, 128, 128, 2, 2, 2, 4>(p, stream);
+      return cfg == 35 ? launch_fl<T, 64, 80, 4, 1, 3>(p, stream) : launch_fl<T, 64, 80, 4, 1, 2>(p, stream);
     }
     case 33: {   // full-N 128 x 320 tiles (8 waves of 64 x 80, 2-slot ring, 112 KB of LDS): the K = 320 products of the 64x64 level
       // (M = 32768: 256 workgroups) read x ONCE instead of once per 160-column tile -- they are bound by bytes, not MFMA

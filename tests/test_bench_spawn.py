@@ -1,6 +1,7 @@
 """`python bench.py --gpus N` without a launcher starts its own ranks: the command it builds, the
 pass-through of rank 0's JSON line, and the single retry with --no-graph when the hipGraph data-parallel run fails.
-No GPU, no processes: subprocess.run is replaced."""
+No GPU, no processes: subprocess.run is replaced -- except in the last test, which really starts two ranks (gloo)."""
+import os
 import json
 import subprocess
 import sys
@@ -56,3 +57,21 @@ def test_main_self_spawns_only_without_a_launcher(monkeypatch):
     except SystemExit as e:
         assert e.code == 0
     assert seen.get("n") == 2
+
+
+def test_two_real_ranks_through_spawn_ranks_rendezvous_allreduce_and_print_one_line():
+    """`python bench.py --gpus 2 --dist-dry-run` as a user would type it: bench.py starts its own two ranks under
+    torch.distributed.run (spawn_ranks), they rendezvous on 127.0.0.1 (gloo on this CPU-only host, RCCL on a GPU node),
+    all-reduce a bucket per step inside the timed region's barrier / MAX bracket, and rank 0 prints exactly one JSON line."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-dry-run", "--steps", "3", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dry_run"] and out["steps"] == 3 and out["allreduce_sum_correct_on_every_rank"]
+    assert out["backend"] in ("gloo", "nccl") and out["value"] > 0

@@ -95,7 +95,7 @@ def test_measured_gemm_table_is_well_formed_and_registers():
     assert rows and len({tuple(r[:7]) for r in rows}) == len(rows)
     for dtype, mode, M, N, K1, K2, geglu, cfg, sk in rows:
         assert dtype in (hip.BF16, hip.F32) and 0 <= mode <= 5 and M > 0 and N > 0 and K1 > 0 and K2 >= 0
-        assert geglu in (0, 1) and 0 <= cfg <= 34 and 0 <= sk <= 64
+        assert geglu in (0, 1) and 0 <= cfg <= 36 and 0 <= sk <= 64
         assert not (geglu and cfg not in (2, 8, 10, 12, 14, 16, 18, 20, 23, 25, 27, 29))
     L = hip.lib()
     assert hip.load_gemm_table(hip.GEMM_TABLE_PATH) == len(rows) == L.cl_gemm_tune_size()

@@ -210,9 +210,15 @@ def test_optimizer_state_is_keyed_by_name_not_by_flat_offset(monkeypatch):
         n = t.master.numel()
         assert torch.equal(opt2._m[0][t.offset:t.offset + n], sd["m"][0][t.name].reshape(-1)), t.name
         assert torch.equal(opt2._v[0][t.offset:t.offset + n], sd["v"][0][t.name].reshape(-1)), t.name
-    # a flat (round <= 3) state is refused by a build whose order differs from the one that wrote it
+    # a flat (round <= 3) state -- ONE tensor in the no-hoist order of the build that wrote it -- is remapped by name into a
+    # build whose order differs (no environment variable, no re-save), and loads unchanged into the same order
     legacy = dict(sd, m=[opt2._m[0].clone()], v=[opt2._v[0].clone()])
     legacy.pop("format")
-    with pytest.raises(RuntimeError):
-        opt.load_state_dict(legacy)
+    opt.load_state_dict(legacy)
+    for t in ex.tr.items:
+        n = t.master.numel()
+        assert torch.equal(opt._m[0][t.offset:t.offset + n], sd["m"][0][t.name].reshape(-1)), t.name
+        assert torch.equal(opt._v[0][t.offset:t.offset + n], sd["v"][0][t.name].reshape(-1)), t.name
     opt2.load_state_dict(legacy)                                                # same order: accepted as before
+    with pytest.raises(ValueError):                                             # a flat state of another model is refused
+        opt.load_state_dict(dict(legacy, m=[opt2._m[0][:-64].clone()], v=[opt2._v[0][:-64].clone()]))

@@ -25,8 +25,8 @@ os.environ["CTRLORA_GEMM_TUNED"] = "0"
 import bench  # noqa: E402
 from ctrlora_amd import hip  # noqa: E402
 
-FL = (10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 31, 32, 33)   # full-line (LDS-DMA, 128-byte K lines) configurations
-W80 = (31, 32)                                           # 128 x 80 tiles (linear products, N % 80 == 0)
+FL = (10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 31, 32, 33, 35, 36)   # full-line (LDS-DMA, 128-byte K lines) configurations
+W80 = (31, 32, 35, 36)                                           # 128 x 80 tiles (linear products, N % 80 == 0)
 W320 = (33,)                                             # 128 x 320 full-N tiles (linear products, N % 320 == 0)
 PERSIST = (25, 26, 27, 28, 29, 30)                      # persistent forms of 16 / 17 / 20 / 21 / 10 / 11 (linear only)
 W160 = (2, 5, 10, 12, 14, 16, 18, 20, 23, 25, 27, 29)   # 160-column tiles
