@@ -51,43 +51,6 @@ PEAK_HBM_TBS = 8.0          # TB/s, MI355X_MICROARCH.md
 PEAK_BF16_TFLOPS = 2500.0
 
 
-class _skip_default_init:
-    """Full-width models only: nn.Linear / nn.Conv2d constructors leave their parameters un-drawn (torch's per-layer
-    kaiming_uniform_ over 1.3 G parameters is ~25 s of single-threaded host time per build -- per RANK on a multi-GPU bench,
-    per test in the GPU suite); _fill_default_init() then draws the same distribution from one random block."""
-
-    def __enter__(self):
-        import torch.nn as nn
-        self.saved = (nn.Linear.reset_parameters, nn.modules.conv._ConvNd.reset_parameters)
-        nn.Linear.reset_parameters = lambda m: None
-        nn.modules.conv._ConvNd.reset_parameters = lambda m: None
-
-    def __exit__(self, *a):
-        import torch.nn as nn
-        nn.Linear.reset_parameters, nn.modules.conv._ConvNd.reset_parameters = self.saved
-
-
-def _fill_default_init(model, seed):
-    """torch's default initialisation of every nn.Linear / nn.Conv2d (weight and bias ~ U(-1 / sqrt(fan_in), 1 / sqrt(fan_in)):
-    kaiming_uniform_(a = sqrt 5)) as windows of ONE seeded block of 64 M uniform numbers -- a different window per parameter
-    (offset = crc32 of its name), scaled by its own bound: memory-copy speed instead of a random draw per element."""
-    import zlib
-    import torch.nn as nn
-    block = torch.rand(1 << 26, generator=torch.Generator().manual_seed(seed + 12345)).mul_(2).sub_(1)
-    with torch.no_grad():
-        for name, m in model.named_modules():
-            if not isinstance(m, (nn.Linear, nn.modules.conv._ConvNd)):
-                continue
-            bound = float(m.weight[0].numel()) ** -0.5
-            for pn in ("weight", "bias"):
-                p = getattr(m, pn, None)
-                if p is None:
-                    continue
-                n = p.numel()
-                off = zlib.crc32(f"{name}.{pn}".encode()) % (block.numel() - n) if n < block.numel() else 0
-                p.copy_(block[off:off + n].view(p.shape)).mul_(bound)
-
-
 def build_model(config, seed, rank_override=None, tiny=False, mutate=None):
     """The drop-in path: YAML -> instantiate_from_config, VAE / CLIP replaced by Identity (synthetic latents).
     `mutate(params)` may edit the YAML's model params before instantiation (tests)."""
@@ -105,10 +68,13 @@ def build_model(config, seed, rank_override=None, tiny=False, mutate=None):
             p[k]["params"].update(model_channels=64, context_dim=96)
         p["control_stage_config"]["params"]["lora_rank"] = 32
     torch.manual_seed(seed)
-    with (contextlib.nullcontext() if tiny else _skip_default_init()):
+    # full width: torch's per-layer default initialisation of 1.3 G parameters is ~25 s of host time per build
+    # (ctrlora_amd/fastinit.py: the same distribution from one random block in ~3 s)
+    from ctrlora_amd.fastinit import fill_default_init, skip_default_init
+    with (contextlib.nullcontext() if tiny else skip_default_init()):
         model = instantiate_from_config(cfg)
     if not tiny:
-        _fill_default_init(model, seed)
+        fill_default_init(model, seed)
     # re-draw the zero-initialised parameters (zero convs, proj_out, out conv, LoRA up) so that no path is
     # trivially zero
     g = torch.Generator().manual_seed(seed + 1)
@@ -157,6 +123,27 @@ def conv_kernel_probe(device, dtype, iters=30):
     return dict(kernel="gemm_fl_kernel<bf16,256x160,8 waves> conv3x3 320->320 @64x64 B8 (60.4 GFLOP/launch)",
                 ms=round(ms, 4), achieved=round(flops / ms * 1e-9, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                 frac=round(flops / ms * 1e-9 / PEAK_BF16_TFLOPS, 4), traffic=traffic)
+
+
+def dominant_kernel_rocprof():
+    """The same launch INSIDE the replayed training step, from this round's rocprofv3 kernel trace joined with the launch tags
+    (tools/prof_shapes.py -> profiles/r05_final/train_shapes_in_step.txt): static here, published beside the live HIP-event figure
+    because hot isolated launches run ~8 % faster than the launch does in the step."""
+    path = os.path.join(ROOT, "profiles", "r05_final", "train_shapes_in_step.txt")
+    try:
+        us = n = 0.0
+        for ln in open(path):
+            f = ln.split()
+            # rows: us/step n/step avg_us TF/s TB/s of_roof mode M N K1 K2 act res kernel...
+            if len(f) > 13 and f[6] == "1" and f[7:11] == ["32768", "320", "320", "0"] and f[11] == "0":
+                us += float(f[0]); n += float(f[1])
+        if not n:
+            return None
+        avg = us / n
+        return dict(us_per_launch=round(avg, 2), launches_per_step=int(n), tflops=round(60.4e3 / avg, 1),
+                    frac=round(60.4e3 / avg / PEAK_BF16_TFLOPS, 4), source="profiles/r05_final/train_shapes_in_step.txt (static)")
+    except Exception:
+        return None
 
 
 def family_census(model, opt, data, reps=10):
@@ -984,6 +971,10 @@ def main():
             # families and the whole step stay alongside -- the whole-step fraction is the honest summary of the step.
             roof.update(achieved=dk["achieved"], frac=dk["frac"], traffic=dk["traffic"], kernel=dk["kernel"],
                         ms_per_launch=dk["ms"], algorithmic_bytes_per_launch=43_800_000,
+                        frac_of="the DOMINANT KERNEL at its dominant shape (16 % of the step's GPU time), 30 hot back-to-back "
+                                "launches between HIP events; the step as a whole is roofline.whole_step, the time-weighted "
+                                "contraction family roofline.family -- since round 4 (rounds 1-3 reported the family figure here)",
+                        rocprof=dominant_kernel_rocprof(),
                         traffic_kind="rocprofv3 TCC passes on this launch, FETCH_SIZE (x2: gfx950 correction) + WRITE_SIZE, re-measured in "
                                      "round 4 (profiles/dominant_kernel_traffic.json); static in this run")
             gf = fam.get("gemm")

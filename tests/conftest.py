@@ -8,6 +8,18 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: a second whole-model repeat of a geometry another test already covers in the same "
+                                       "precision class; skipped unless CTRLORA_RUN_SLOW=1 (keeps the driver's GPU run short)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get("CTRLORA_RUN_SLOW") == "1":
+        return
+    import pytest as _pytest
+    skip = _pytest.mark.skip(reason="slow repeat: set CTRLORA_RUN_SLOW=1")
+    for it in items:
+        if "slow" in it.keywords:
+            it.add_marker(skip)
 
 
 import pytest  # noqa: E402

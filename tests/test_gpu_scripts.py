@@ -64,8 +64,9 @@ def test_finetune_script_two_steps_checkpoint_roundtrip_resume_and_sample(assets
     cfg = os.path.join(assets, "finetune_narrow.yaml")
     args = ["--dataroot", os.path.join(assets, "custom"), "--config", cfg, "--sd_ckpt", os.path.join(assets, "sd_synth.ckpt"),
             "--cn_ckpt", os.path.join(assets, "basecn_synth.ckpt"), "--bs", "2", "--max_steps", "3", "--precision", "16",
-            "--ckpt_logger_freq", "2", "--img_logger_freq", "2", "--lr", "1e-4", "-n", "f4", "--num_workers", "2"]   # 2 worker processes: forking the
-    # reference's 16 per epoch from a test process that has run the whole GPU suite cost minutes (304 s in the suite vs 80 s alone)
+            "--ckpt_logger_freq", "2", "--img_logger_freq", "2", "--lr", "1e-4", "-n", "f4", "--num_workers", "0"]   # in-process loading: forking
+    # worker processes every epoch from a test process that has run the whole GPU suite cost minutes (the reference's 16: 304 s in the
+    # suite vs 80 s alone; 2 workers: still the longest test of the suite); tests/test_training_scripts.py covers the datasets' items
     train.main(args)
     lap("train_ctrlora_finetune.main: 3 steps, image logger, checkpoints")
     cks = sorted(glob.glob(os.path.join("runs", "f4", "**", "*.ckpt"), recursive=True))

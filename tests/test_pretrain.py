@@ -41,9 +41,14 @@ def _model(dtype):
 # from step 1 on is then parameter divergence (1.3e-1 .. 2.0e-1, chaotic), not kernel error; that case is gated where it can be:
 # test_gpu_parity_r3.py::test_pretraining_bf16_error_is_flat_on_the_fp32_parameter_trajectory pins the parameters to the fp32
 # trajectory at lr 1e-3 and requires a flat error.  At 1e-4 the trajectories stay together and every step is a kernel check.
+# The bf16 run at the REFERENCE learning rate is back as a fourth case with two gates that say what they measure: step 0 --
+# identical parameters on both sides -- at the kernel tolerance (8e-2); steps 1-2 and the final parameters at a DRIFT bound
+# (2.6e-1 / 5e-2: round 3 measured 1.3e-1 .. 2.0e-1 and 2.8e-2 with correct kernels), which a regression that only shows through
+# real AdamW updates at 1e-3 -- a wrong moment, a bank updated twice -- would exceed by an order of magnitude.
 @pytest.mark.parametrize("dtype,fixture,tol_g,tol_p", [(torch.float32, "pretrain.pt", 1e-3, 5e-3),
                                                          (torch.float32, "pretrain_lr1e-4.pt", 1e-3, 5e-3),
-                                                         (torch.bfloat16, "pretrain_lr1e-4.pt", 9e-2, 5e-3)])
+                                                         (torch.bfloat16, "pretrain_lr1e-4.pt", 9e-2, 5e-3),
+                                                         (torch.bfloat16, "pretrain.pt", (8e-2, 2.6e-1), 5e-2)])
 def test_pretraining_three_steps_two_tasks_vs_reference(dtype, fixture, tol_g, tol_p):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
@@ -78,7 +83,8 @@ def test_pretraining_three_steps_two_tasks_vs_reference(dtype, fixture, tol_g, t
         torch.cuda.synchronize()
         g = gold["steps"][i]
         assert g["task"] == task
-        assert abs(float(loss) - g["loss"]) < (1e-4 if dtype == torch.float32 else 3e-2) * g["loss"], (i, float(loss), g["loss"])
+        ltol = 1e-4 if dtype == torch.float32 else (3e-2 if not isinstance(tol_g, tuple) or i == 0 else 1e-1)
+        assert abs(float(loss) - g["loss"]) < ltol * g["loss"], (i, float(loss), g["loss"])
         ref = unpack(g["grads"])
         ours = current("grad")
         assert set(ref) == set(ours)
@@ -99,7 +105,8 @@ def test_pretraining_three_steps_two_tasks_vs_reference(dtype, fixture, tol_g, t
         print(f"[pretrain {dtype} step {i} {task}] loss {float(loss):.6f} (ref {g['loss']:.6f}); worst grad errors {worst[:3]}")
         # (bf16 at this d_head-8 width, measured: 6.5e-2, 6.8e-2, 6.5e-2 -- flat; parameters after 3 steps 3.1e-3; the gate
         # holds for EVERY step)
-        assert worst[0][0] < tol_g, worst[:5]
+        tol_i = tol_g if not isinstance(tol_g, tuple) else (tol_g[0] if i == 0 else tol_g[1])
+        assert worst[0][0] < tol_i, worst[:5]
         opt.step()
     assert opt.active == ["hed", "canny"]
     ref = unpack(gold["after"])
