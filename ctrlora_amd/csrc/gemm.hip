@@ -1324,8 +1324,9 @@ static int launch_t_cfg(const GemmParams& p, hipStream_t stream, int cfg) {
     case 35: case 36: {   // 64 x 80 full-line tiles, 4 waves of 16 x 80 (3- / 2-slot ring, 54 / 36 KB: two or three workgroups per CU):
       // the M = 2048 products of the 16x16 level (N = K = 1280) are 256 workgroups of 4 waves as 128 x 80 tiles -- one wave
       // per SIMD, nothing to hide a stage's DMA / barrier latency behind (18 us for 6.7 GFLOP); 512 workgroups here
+      // (also the 3x3 convs of the 8x8 level, M = 512: 128 tiles x split-K instead of 16 tiles x 16 splits -- a quarter of the slabs)
       const int kps = 128 / (int)sizeof(T);
-      if (p.K1 % kps || p.K2 % kps || p.mode != GEMM_LINEAR || p.N % 80)
+      if (p.K1 % kps || p.K2 % kps || (p.mode != GEMM_LINEAR && p.K2) || p.N % 80)
         return launch_cfg<T, 128, 128, 2, 2, 2, 4>(p, stream);
       return cfg == 35 ? launch_fl<T, 64, 80, 4, 1, 3>(p, stream) : launch_fl<T, 64, 80, 4, 1, 2>(p, stream);
     }

@@ -106,8 +106,10 @@ def candidates(key):
             continue                      # persistent walk only where a workgroup would own several tiles
         if c in W160 and N % 160:
             continue
-        if c in W80 and (N % 80 or mode != hip.LINEAR or M > 16384):
+        if c in W80 and (N % 80 or (mode != hip.LINEAR and c not in (35, 36)) or M > 16384):
             continue
+        if c in (35, 36) and mode != hip.LINEAR and M > 2048:
+            continue                      # conv modes: the small-M levels only (8x8, 16x16)
         if c in W320 and (N % 320 or mode != hip.LINEAR or M < 8192):
             continue
         if c in W128 and N % 128 and N % 160 == 0:
@@ -239,7 +241,7 @@ def main():
         base = time_us(run, args.reps)
         cfgs, sks = candidates(key)
         if only is not None:
-            cfgs, sks = only, ([0, 1, 2, 4] if 34 in only else [0, 1, 2])
+            cfgs, sks = only, ([0, 1, 2, 4] if 34 in only else ([0, 1, 2, 4, 8] if set(only) <= {35, 36} and key[1] != hip.LINEAR else [0, 1, 2]))
         best = (base, -1, 0)
         per_cfg = []
         for c in cfgs:                                   # tile configuration at the launcher's own split rule
