@@ -51,9 +51,12 @@ PEAK_HBM_TBS = 8.0          # TB/s, MI355X_MICROARCH.md
 PEAK_BF16_TFLOPS = 2500.0
 
 
-def build_model(config, seed, rank_override=None, tiny=False, mutate=None):
+def build_model(config, seed, rank_override=None, tiny=False, mutate=None, fast_init=None):
     """The drop-in path: YAML -> instantiate_from_config, VAE / CLIP replaced by Identity (synthetic latents).
-    `mutate(params)` may edit the YAML's model params before instantiation (tests)."""
+    `mutate(params)` may edit the YAML's model params before instantiation (tests).  fast_init (default: on at full width unless
+    CTRLORA_FAST_INIT=0): the default distributions drawn from one random block (ctrlora_amd/fastinit.py) instead of torch's
+    per-layer calls -- other VALUES than torch.manual_seed(seed) + default init gives; tests whose absolute bf16 gates were
+    calibrated on those pass False."""
     import contextlib
     from ldm.util import instantiate_from_config
     with open(os.path.join(ROOT, "configs", config)) as f:
@@ -71,9 +74,12 @@ def build_model(config, seed, rank_override=None, tiny=False, mutate=None):
     # full width: torch's per-layer default initialisation of 1.3 G parameters is ~25 s of host time per build
     # (ctrlora_amd/fastinit.py: the same distribution from one random block in ~3 s)
     from ctrlora_amd.fastinit import fill_default_init, skip_default_init
-    with (contextlib.nullcontext() if tiny else skip_default_init()):
+    if fast_init is None:
+        fast_init = os.environ.get("CTRLORA_FAST_INIT", "1") != "0"
+    fast_init = bool(fast_init) and not tiny
+    with (skip_default_init() if fast_init else contextlib.nullcontext()):
         model = instantiate_from_config(cfg)
-    if not tiny:
+    if fast_init:
         fill_default_init(model, seed)
     # re-draw the zero-initialised parameters (zero convs, proj_out, out conv, LoRA up) so that no path is
     # trivially zero

@@ -22,6 +22,9 @@ int cl_debug_groupnorm_form(int three_pass, int one_pass);
  * cl_debug_gemm_tag_get(i, out): out[0..11] = dtype, mode, M, N, K1, K2, act, has_residual, tag, real workgroups of the main
  * kernel, workgroup size, launches so far; returns CL_EINVAL past the end. */
 int cl_debug_gemm_tag(int on);
+/* 1 (default) = product signatures WITHOUT a launch-table entry take the x-stationary kernel (gemm_xs.hip) where the rule in
+ * gemm.hip says so; 0 = only where a table entry names configuration 34 (CTRLORA_GEMM_XS=0 sets 0 and drops those entries too) */
+int cl_debug_gemm_xs_rules(int on);
 int cl_debug_gemm_tag_count(void);
 int cl_debug_gemm_tag_get(int i, long* out12);
 #ifdef __cplusplus

@@ -91,6 +91,7 @@ int gemm_tune_set(int dtype, int mode, int M, int N, int K1, int K2, int geglu, 
 void gemm_tune_clear();
 int gemm_tune_size();
 extern int g_gemm_force_cfg;   // tuning/probe hook (tile configuration override), -1 = heuristic
+extern int g_gemm_xs_rules;    // 1 = untabled signatures may take the x-stationary kernel by rule (gemm.hip: launch_t_cfg)
 // launch tags (csrc/debug_hooks.h: cl_debug_gemm_tag): extra, immediately exiting workgroups that name the product signature
 extern int g_gemm_tag_on;
 int gemm_cur_tag();                                   // tag of the product being launched on this thread (0 = tagging off)

@@ -1158,6 +1158,7 @@ static int launch_fl(const GemmParams& p, hipStream_t stream) {
 }
 
 int g_gemm_force_cfg = -1;   // probe / tuning hook: >= 0 forces a tile configuration
+int g_gemm_xs_rules = 1;     // A/B hook (cl_debug_gemm_xs_rules): 0 = the x-stationary kernel only where a table entry names it
 int g_fl128_split_want = 128;   // 128-row full-line tiles: split K while the grid is below this many workgroups
 int g_tiny_m_minsub = 8;        // fallback kernel, M <= 64: minimum 64-byte substeps per K split
 
@@ -1202,6 +1203,21 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
 template <typename T>
 static int launch_t_cfg(const GemmParams& p, hipStream_t stream, int cfg) {
   if (p.act == ACT_GEGLU && cfg != 2 && cfg != 12 && cfg != 8 && cfg != 10 && cfg != 14 && cfg != 16 && cfg != 18 && cfg != 20 && cfg != 23 && cfg != 25 && cfg != 27 && cfg != 29) cfg = -2;   // needs a 2 x 80-column wave pair
+  if constexpr (sizeof(T) == 2) {
+    // No table entry and no forced configuration: the x-stationary kernel by RULE where the measured table took it at the
+    // benchmarked batch sizes (profiles/r05_gemm_xs/autotune_xs.out) -- other batch sizes (pre-training at the reference's
+    // batch 4: M = 16384 at the 64x64 level) have no entry of their own.  K = 320: N >= 320 from 16384 rows, N >= 1280 from 8192;
+    // K = 640: N >= 5120 from 8192 rows, N >= 640 from 32768.  CL_EINVAL (an epilogue it does not cover) falls through.
+    if (cfg == -1 && g_gemm_xs_rules && p.mode == GEMM_LINEAR && p.act == ACT_NONE && !p.rowbias && !p.atomic && !p.out_f32 &&
+        !p.a1_group_n && (p.K2 == 0 || p.K2 == 128)) {
+      const bool k320 = p.K1 == 320 && p.N >= 320 && (p.M >= 16384 || (p.M >= 8192 && p.N >= 1280));   // (N = 128: the tuner kept the tiles)
+      const bool k640 = p.K1 == 640 && ((p.M >= 8192 && p.N >= 5120) || (p.M >= 32768 && p.N >= 640));
+      if (k320 || k640) {
+        const int rc = launch_gemm_xs(p, stream, 0);
+        if (rc != CL_EINVAL) return rc;
+      }
+    }
+  }
   if (cfg < 0) {
     // v2 (64-byte substeps, 4 waves) choices
     if (p.M <= 64 || p.N <= 64) cfg = 0;
