@@ -359,6 +359,10 @@ __global__ __launch_bounds__(256, MINW) void gemm_xs_kernel(GemmParams p, int cp
   });
 }
 
+// (Tried and dropped, profiles/r05_gemm_xs/probe_xs_three_workgroups_per_cu.log: the K = 320 forms with a 2-chunk ring at THREE
+// workgroups per CU (166 VGPRs allow it) -- plain N = 320 15.4 -> 14.6 us, N = 1280 / 2560 unchanged, the residual and GEGLU forms
+// spill at 168 registers and lose 15-100 %.)
+
 namespace {
 
 template <int KS1, int KS2, int RING, int MINW, int EPI, bool LNP = false>
@@ -371,7 +375,7 @@ int launch_xs(const GemmParams& p, hipStream_t stream, int nsplit) {
   const int rb = (p.M + 127) / 128;
   if (nsplit <= 0) {
     // as many workgroups as the chip holds at once (two per CU at K <= 448, one above) where the run stays >= 5 blocks
-    const long want = MINW == 2 ? 512 : 256;
+    const long want = MINW >= 2 ? 256L * MINW : 256;
     nsplit = 1;
     while ((long)rb * groups * nsplit < want && bpg % (nsplit * 2) == 0 && bpg / (nsplit * 2) >= 5) nsplit *= 2;
   }
