@@ -20,7 +20,8 @@ from .packing import TrainableSet, rup
 
 
 class CtrLoRAEngine:
-    overlap_streams = True     # ControlNet trunk || UNet encoder on two HIP streams (forward)
+    # ControlNet trunk || UNet encoder on two HIP streams (forward); CTRLORA_OVERLAP_STREAMS=0: one stream (A/B switch)
+    overlap_streams = os.environ.get("CTRLORA_OVERLAP_STREAMS", "1") != "0"
     overlap_wgrad = os.environ.get("CTRLORA_OVERLAP_WGRAD", "1") != "0"   # weight gradients of stage i || data gradients of stage i+1
 
     def __init__(self, sd_unet: Dict[str, torch.Tensor], sd_controls: Sequence[Dict[str, torch.Tensor]], cfg: NetCfg,
