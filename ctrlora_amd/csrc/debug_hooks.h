@@ -25,6 +25,8 @@ int cl_debug_gemm_tag(int on);
 /* 1 (default) = product signatures WITHOUT a launch-table entry take the x-stationary kernel (gemm_xs.hip) where the rule in
  * gemm.hip says so; 0 = only where a table entry names configuration 34 (CTRLORA_GEMM_XS=0 sets 0 and drops those entries too) */
 int cl_debug_gemm_xs_rules(int on);
+/* LDS ring depth of the weight-gradient kernel: 3 (default since round 5: three workgroups per CU), 4 or 6 */
+int cl_debug_wgrad_ring(int slots);
 int cl_debug_gemm_tag_count(void);
 int cl_debug_gemm_tag_get(int i, long* out12);
 #ifdef __cplusplus

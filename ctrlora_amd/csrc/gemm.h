@@ -83,7 +83,7 @@ struct WgradDesc {
   int tap, Hin, Win, Hout, Wout, stride, pad, reserved;
 };
 int launch_wgrad_tn_group(const WgradDesc* probs, int n, const void* zero_page, hipStream_t stream);
-extern int g_wgrad_blocks, g_wgrad_min_steps, g_wgrad_ring;
+extern int g_wgrad_blocks, g_wgrad_min_steps, g_wgrad_ring, g_wgrad_rows;
 extern int g_fl128_split_want, g_tiny_m_minsub;
 extern int g_fl_persist_stagger;
 extern int g_gemm_force_splitk;   // tuning hook: > 0 imposes the split-K factor of the workspace path

@@ -23,6 +23,7 @@
 // 77 us for a 29 MB problem, time proportional to the number of workgroups.)  Deterministic as a bonus.
 #include "gemm.h"
 #include "mma.h"
+#include <algorithm>
 
 namespace cl {
 
@@ -51,12 +52,14 @@ struct WgradProb {
 constexpr int WGRAD_MAX_PROBS = 24;
 struct WgradGroup { int n; int pad; WgradProb p[WGRAD_MAX_PROBS]; };
 
-// 4 waves (2 x 2), 128 (n) x 128 (k) output tile, 32 rows of m per pipeline step, R-slot ring
-// (R - 1 steps of DMA in flight).
-template <int R>
+// 4 waves (2 x 2), 128 (n) x 128 (k) output tile, ROWS (32 or 64) rows of m per pipeline step, R-slot ring
+// (R - 1 steps of DMA in flight).  ROWS = 64 (round 5): two 32-deep MFMA batches per barrier -- at 32 rows a step is 16 MFMAs per
+// wave (256 matrix-pipe cycles) behind a barrier, a counted vmcnt and the LDS transpose reads' latency.
+template <int R, int ROWS = 32>
 __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const WgradGroup grp, const void* __restrict__ zero_page) {
-  constexpr int TILE = 32 * 256;          // one operand tile: 32 rows x 256 bytes
+  constexpr int TILE = ROWS * 256;        // one operand tile: ROWS rows x 256 bytes
   constexpr int SLOT = 2 * TILE;
+  constexpr int NI = ROWS / 16;           // DMA instructions (4 rows each) per wave and operand tile
   static_assert(R * SLOT >= 4 * 32 * 68 * 4, "epilogue staging must fit in the ring");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const WgradGroup grp, 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 1, wk = wave & 1;
   const int n0 = (tile / tiles_k) * 128, k0 = (tile % tiles_k) * 128;
-  const int steps_total = (M + 31) / 32;
+  const int steps_total = (M + ROWS - 1) / ROWS;
   const int sbeg = split * steps_per_split;
   const int send = min(steps_total, sbeg + steps_per_split);
   const int total = send - sbeg;
@@ -86,10 +89,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const WgradGroup grp, 
   // wave w issues instructions 2w, 2w+1 of each operand tile.
   const int lr4 = lane >> 4, lslot = lane & 15;
   const char* zsrc = (const char*)zero_page + (lslot & 3) * 16;
-  int rowi[2]; const char* sdy[2]; const char* sx[2];
+  int rowi[NI]; const char* sdy[NI]; const char* sx[NI];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = (2 * wave + j) * 4 + lr4;                         // 0..31 within the step
+  for (int j = 0; j < NI; ++j) {
+    const int row = (NI * wave + j) * 4 + lr4;                        // 0..ROWS-1 within the step
     const int f = ((row & 3) | (((row >> 3) & 1) << 2)) << 1;
     const int chunk = lslot ^ f;                                      // logical 16-byte chunk of the row
     rowi[j] = row;
@@ -101,19 +104,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const WgradGroup grp, 
   auto issue = [&](int step, int slot) {
     char* base = smem + slot * SLOT;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const long m = (long)step * 32 + rowi[j];
+    for (int j = 0; j < NI; ++j) {
+      const long m = (long)step * ROWS + rowi[j];
       const bool ok = m < M;                                          // rows past M contribute zeros
-      glds16(ok ? sdy[j] + m * lddy * 2 : zsrc, base + (2 * wave + j) * 1024);
+      glds16(ok ? sdy[j] + m * lddy * 2 : zsrc, base + (NI * wave + j) * 1024);
       if (P.tap < 0) {                                                 // (wave-uniform)
-        glds16(ok ? sx[j] + m * ldx * 2 : zsrc, base + TILE + (2 * wave + j) * 1024);
+        glds16(ok ? sx[j] + m * ldx * 2 : zsrc, base + TILE + (NI * wave + j) * 1024);
       } else {   // conv tap: dy row (b, oy, ox) pairs with input pixel (oy s + ky - pad, ox s + kx - pad)
         const int mi = (int)m, ox = mi % P.Wout, t2 = mi / P.Wout, oy = t2 % P.Hout, ob = t2 / P.Hout;
         const int ky = P.tap / 3, kx = P.tap - 3 * ky;
         const int iy = oy * P.stride + ky - P.pad, ix = ox * P.stride + kx - P.pad;
         const bool okx = ok & ((unsigned)iy < (unsigned)P.Hin) & ((unsigned)ix < (unsigned)P.Win);
         const long xr = ((long)ob * P.Hin + iy) * P.Win + ix;
-        glds16(okx ? sx[j] + xr * ldx * 2 : zsrc, base + TILE + (2 * wave + j) * 1024);
+        glds16(okx ? sx[j] + xr * ldx * 2 : zsrc, base + TILE + (NI * wave + j) * 1024);
       }
     }
   };
@@ -141,32 +144,36 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const WgradGroup grp, 
   for (int s = 0; s < R - 1; ++s)
     if (s < total) issue(sbeg + s, s);
   for (int s = 0; s < total; ++s) {
-    // own DMA of step s landed; R-2 newer steps (4 instructions per wave each) may stay in flight
-    if (s + R - 1 <= total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * 4) : "memory");
+    // own DMA of step s landed; R-2 newer steps (2 NI instructions per wave each) may stay in flight
+    if (s + R - 1 <= total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * 2 * NI) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();          // step s visible to all; slot (s-1)%R no longer read
     __builtin_amdgcn_sched_barrier(0);
     if (s + R - 1 < total) issue(sbeg + s + R - 1, (s + R - 1) % R);
     const uint32_t base = lds0 + (s % R) * SLOT;
-    u32x4_t af[4], bfr[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const u32x2_t lo = lds_read_tr16(base + aoff[i]), hi = lds_read_tr16(base + aoff[i] + 1024);
-      af[i] = u32x4_t{lo.x, lo.y, hi.x, hi.y};
+    for (int sub = 0; sub < ROWS / 32; ++sub) {      // one 32-deep MFMA batch per 32 rows of the step
+      const uint32_t sb = base + sub * (32 * 256);
+      u32x4_t af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const u32x2_t lo = lds_read_tr16(sb + aoff[i]), hi = lds_read_tr16(sb + aoff[i] + 1024);
+        af[i] = u32x4_t{lo.x, lo.y, hi.x, hi.y};
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const u32x2_t lo = lds_read_tr16(sb + boff[i]), hi = lds_read_tr16(sb + boff[i] + 1024);
+        bfr[i] = u32x4_t{lo.x, lo.y, hi.x, hi.y};
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { asm volatile("" : "+v"(af[i])); asm volatile("" : "+v"(bfr[i])); }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Mma<bf16_t>::run(af[i], bfr[j], acc[i][j]);
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const u32x2_t lo = lds_read_tr16(base + boff[i]), hi = lds_read_tr16(base + boff[i] + 1024);
-      bfr[i] = u32x4_t{lo.x, lo.y, hi.x, hi.y};
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { asm volatile("" : "+v"(af[i])); asm volatile("" : "+v"(bfr[i])); }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) Mma<bf16_t>::run(af[i], bfr[j], acc[i][j]);
   }
   __syncthreads();
 
@@ -228,25 +235,33 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradGroup grp)
   *dst = o;
 }
 
-// tuning knobs (probe): workgroups wanted per GROUP, minimum 32-row steps per split, ring depth
-int g_wgrad_blocks = 512, g_wgrad_min_steps = 8, g_wgrad_ring = 4;
+// tuning knobs (probe): workgroups wanted per GROUP, minimum 32-row steps per split, ring depth, rows of m per step.
+// Round 5 (profiles/r05_final/probe_wgrad_forms.log): ring 3 (48 KB: THREE workgroups per CU) instead of 4 (64 KB: two) --
+// the nine-tap groups of pre-training 284 -> 239 us at 320 -> 320 / 64x64, 186 -> 152 at 640 -> 640 / 32x32; 64-row steps
+// (two MFMA batches per barrier; 2-slot ring to keep two workgroups per CU) measured no better than 32-row steps: 277 / 181 us.
+int g_wgrad_blocks = 512, g_wgrad_min_steps = 8, g_wgrad_ring = 3, g_wgrad_rows = 32;
 
 static int launch_group(WgradGroup& grp, int nblocks, int nred, const void* zero_page, hipStream_t stream) {
-#define WGRAD_LAUNCH(RR)                                                                                   \
-  do {                                                                                                     \
-    static bool attr_set = false;                                                                          \
-    if (!attr_set) {                                                                                       \
-      if (RR * 16384 > 65536 &&                                                                            \
-          hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tn_kernel<RR>),                         \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, RR * 16384) != hipSuccess)       \
-        return CL_ELAUNCH;                                                                                 \
-      attr_set = true;                                                                                     \
-    }                                                                                                      \
-    hipLaunchKernelGGL(wgrad_tn_kernel<RR>, dim3(nblocks), dim3(256), RR * 16384, stream, grp, zero_page); \
+#define WGRAD_LAUNCH(RR, ROWS)                                                                                          \
+  do {                                                                                                                  \
+    static bool attr_set = false;                                                                                       \
+    constexpr int LDSB = RR * 2 * ROWS * 256;                                                                           \
+    if (!attr_set) {                                                                                                    \
+      if (LDSB > 65536 &&                                                                                               \
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tn_kernel<RR, ROWS>),                                \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess)                          \
+        return CL_ELAUNCH;                                                                                              \
+      attr_set = true;                                                                                                  \
+    }                                                                                                                   \
+    hipLaunchKernelGGL((wgrad_tn_kernel<RR, ROWS>), dim3(nblocks), dim3(256), LDSB, stream, grp, zero_page);            \
   } while (0)
-  if (g_wgrad_ring == 3) WGRAD_LAUNCH(3);
-  else if (g_wgrad_ring == 6) WGRAD_LAUNCH(6);
-  else WGRAD_LAUNCH(4);
+  if (g_wgrad_rows == 64) {
+    if (g_wgrad_ring == 3) WGRAD_LAUNCH(3, 64);
+    else if (g_wgrad_ring == 4) WGRAD_LAUNCH(4, 64);
+    else WGRAD_LAUNCH(2, 64);
+  } else if (g_wgrad_ring == 3) WGRAD_LAUNCH(3, 32);
+  else if (g_wgrad_ring == 6) WGRAD_LAUNCH(6, 32);
+  else WGRAD_LAUNCH(4, 32);
 #undef WGRAD_LAUNCH
   if (nred > 0) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nred), dim3(256), 0, stream, grp);
   CL_CHECK_LAUNCH();
@@ -273,19 +288,21 @@ int launch_wgrad_tn_group(const WgradDesc* probs, int n, const void* zero_page, 
     tiles_all += (long)((d.N + 127) / 128) * ((d.K + 127) / 128);
   }
   if (tiles_all == 0) return CL_OK;
-  // uniform number of m-steps per workgroup across the group
+  // uniform number of m-steps per workgroup across the group (a step = g_wgrad_rows rows of m)
+  const int rows = g_wgrad_rows == 64 ? 64 : 32;
   long steps_all = 0;
   for (int i = 0; i < n; ++i)
-    if (probs[i].M > 0) steps_all += (long)((probs[i].N + 127) / 128) * ((probs[i].K + 127) / 128) * ((probs[i].M + 31) / 32);
+    if (probs[i].M > 0) steps_all += (long)((probs[i].N + 127) / 128) * ((probs[i].K + 127) / 128) * ((probs[i].M + rows - 1) / rows);
   long per = (steps_all + g_wgrad_blocks - 1) / g_wgrad_blocks;
-  if (per < g_wgrad_min_steps) per = g_wgrad_min_steps;
+  const long min_steps = std::max(1, g_wgrad_min_steps * 32 / rows);
+  if (per < min_steps) per = min_steps;
 
   WgradGroup grp; grp.n = 0; grp.pad = 0;
   int nblocks = 0, nred = 0; long ws_used = 0;
   for (int i = 0; i < n; ++i) {
     const WgradDesc& d = probs[i];
     if (d.M <= 0 || d.N <= 0 || d.K <= 0) continue;
-    const int tn = (d.N + 127) / 128, tk = (d.K + 127) / 128, steps = (d.M + 31) / 32;
+    const int tn = (d.N + 127) / 128, tk = (d.K + 127) / 128, steps = (d.M + rows - 1) / rows;
     int splits = (int)((steps + per - 1) / per);
     int pp = (steps + splits - 1) / splits;
     splits = (steps + pp - 1) / pp;

@@ -121,6 +121,7 @@ _DEBUG_SIGS = {
     "cl_debug_groupnorm_form": [_I, _I],
     "cl_debug_gemm_tag": [_I],
     "cl_debug_gemm_xs_rules": [_I],
+    "cl_debug_wgrad_ring": [_I],
     "cl_debug_gemm_tag_count": [],
     "cl_debug_gemm_tag_get": [_I, _P],
 }
@@ -146,6 +147,8 @@ def lib():
         if gn3 or not gn1:
             L.cl_debug_groupnorm_form(int(gn3), int(gn1))
         L.cl_debug_gemm_xs_rules(int(XS_ENABLED))
+        if os.environ.get("CTRLORA_WGRAD_RING"):                     # A/B switch: 4 = the round-1..4 ring depth
+            L.cl_debug_wgrad_ring(int(os.environ["CTRLORA_WGRAD_RING"]))
         if os.environ.get("CTRLORA_GEMM_TUNED", "1") != "0":
             load_gemm_table(os.environ.get("CTRLORA_GEMM_TABLE", GEMM_TABLE_PATH))
             if XS_ENABLED:      # round 5: signatures the x-stationary kernel (csrc/gemm_xs.hip, configuration 34) won

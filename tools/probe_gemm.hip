@@ -380,6 +380,48 @@ static void wgrad_suite(bool timeit) {
   }
 }
 
+// round 5: the nine tap problems of one 3x3 conv's weight gradient + the block's LoRA problems as ONE grouped launch (what a
+// pre-training backward stage flushes), for every (rows per step, ring depth) form of wgrad_tn_kernel
+static void wgrad_tap_group(int B, int H, int C, int O) {
+  const int M = B * H * H;
+  Buf DY, X; DY.init((size_t)M * O, CL_BF16); X.init((size_t)M * C, CL_BF16);
+  float* dW; HIPCHK(hipMalloc(&dW, (size_t)O * 9 * C * 4)); HIPCHK(hipMemset(dW, 0, (size_t)O * 9 * C * 4));
+  WgradDesc d[9];
+  for (int t = 0; t < 9; ++t) {
+    d[t] = WgradDesc{}; d[t].dy = DY.d; d[t].lddy = O; d[t].x = X.d; d[t].ldx = C; d[t].dW = dW + (size_t)t * C; d[t].lddw = 9 * C;
+    d[t].M = M; d[t].N = O; d[t].K = C; d[t].alpha = 1.f; d[t].tap = t; d[t].Hin = H; d[t].Win = H; d[t].Hout = H; d[t].Wout = H;
+    d[t].stride = 1; d[t].pad = 1;
+  }
+  std::vector<float> ref;
+  const int forms[][2] = {{32, 4}, {32, 3}, {64, 2}, {64, 3}, {64, 4}};
+  for (auto& f : forms) {
+    g_wgrad_rows = f[0]; g_wgrad_ring = f[1];
+    HIPCHK(hipMemset(dW, 0, (size_t)O * 9 * C * 4));
+    int rc = launch_wgrad_tn_group(d, 9, g_zero, 0);
+    HIPCHK(hipDeviceSynchronize());
+    if (rc) { printf("[FAIL] tap group rows %d ring %d rc=%d\n", f[0], f[1], rc); g_fail++; continue; }
+    std::vector<float> out((size_t)O * 9 * C);
+    HIPCHK(hipMemcpy(out.data(), dW, out.size() * 4, hipMemcpyDeviceToHost));
+    double num = 0, den = 0;
+    if (ref.empty()) ref = out;       // the 32-row / 4-slot form is the product's (tests/test_gpu_parity_r3.py checks it against fp64)
+    for (size_t i = 0; i < out.size(); ++i) { const double dd = out[i] - ref[i]; num += dd * dd; den += (double)ref[i] * ref[i]; }
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    float best = 1e9f;
+    for (int rep = 0; rep < 3; ++rep) {
+      HIPCHK(hipEventRecord(e0, 0));
+      for (int i = 0; i < 10; ++i) launch_wgrad_tn_group(d, 9, g_zero, 0);
+      HIPCHK(hipEventRecord(e1, 0)); HIPCHK(hipEventSynchronize(e1));
+      float ms; HIPCHK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms / 10);
+    }
+    const double fl = 2.0 * M * O * 9.0 * C;
+    printf("[TIME] conv dW %dx%dx%d %d->%d, 9 taps: rows %2d ring %d  %8.1f us  %7.1f TF/s   vs 32/4 form rel_l2 %.2e%s\n", B, H, H, C, O,
+           f[0], f[1], best * 1e3, fl / best * 1e-9, std::sqrt(num / (den + 1e-30)), std::sqrt(num / (den + 1e-30)) > 1e-5 ? "  <-- FAIL" : "");
+    if (std::sqrt(num / (den + 1e-30)) > 1e-5) g_fail++;
+  }
+  g_wgrad_rows = 32; g_wgrad_ring = 4;
+  hipFree(dW); hipFree(DY.d); hipFree(X.d);
+}
+
 static void correctness_suite(const char* tag) {
   printf("---- correctness: %s\n", tag);
   case_linear("linear bf16 300x200x96 plain", CL_BF16, 300, 200, 96, 0, false, false, false, 0, 1.f, 0.f, true, 1);
@@ -529,6 +571,31 @@ int main(int argc, char** argv) {
       g_probe_act = 0;
     }
     return 0;
+  }
+  if (argc > 1 && !strcmp(argv[1], "--wgrad5")) {   // 64-row steps vs 32-row steps
+    const int forms[][2] = {{32, 4}, {32, 3}, {64, 2}};
+    for (auto& f : forms) {
+      const int rows = f[0];
+      g_wgrad_rows = rows; g_wgrad_ring = f[1];
+      printf("---- rows per step %d, ring %d\n", rows, f[1]);
+      case_wgrad("wgrad 300x200x136", 300, 200, 136, 1.0f);
+      case_wgrad("wgrad 616x320x128 alpha 0.5", 616, 320, 128, 0.5f);
+      case_wgrad("wgrad M=8 1280x128", 8, 1280, 128, 1.0f);
+      case_wgrad("wgrad 4096x128x320", 4096, 128, 320, 1.0f);
+      case_wgrad("wgrad 1000x8x40 (tiny)", 1000, 8, 40, 1.0f);
+      case_wgrad("wgrad 32768x320x128 (dB @64^2)", 32768, 320, 128, 1.0f, true);
+      case_wgrad("wgrad 32768x128x320 (dA @64^2)", 32768, 128, 320, 1.0f, true);
+      case_wgrad("wgrad 32768x2560x128 (dB GEGLU)", 32768, 2560, 128, 1.0f, true);
+      case_wgrad("wgrad 32768x320x320 (zero conv)", 32768, 320, 320, 1.0f, true);
+      case_wgrad("wgrad 512x1280x1280 (zero conv 8^2)", 512, 1280, 1280, 1.0f, true);
+    }
+    g_wgrad_rows = 32; g_wgrad_ring = 4;
+    wgrad_tap_group(8, 64, 320, 320);
+    wgrad_tap_group(8, 32, 640, 640);
+    wgrad_tap_group(8, 16, 1280, 1280);
+    wgrad_tap_group(8, 8, 1280, 1280);
+    printf("%s\n", g_fail ? "WGRAD PROBE: FAILURES" : "WGRAD PROBE: all pass");
+    return g_fail ? 1 : 0;
   }
   if (argc > 1 && !strcmp(argv[1], "--xs")) {   // x-stationary kernel: correctness on ragged / grouped cases, then the production shapes
     case_xs("xs 300x320x320 bias", 300, 320, 320, 0, true, 1, 1.f, 0, 0);
