@@ -301,7 +301,12 @@ __global__ __launch_bounds__(256, MINW) void gemm_xs_kernel(GemmParams p, int cp
     constexpr int S = decltype(SLOT)::value;
     // This wave's DMA of chunk c (issued in iteration c - D, after that iteration's residual loads) has landed when at most the
     // operations issued AFTER it are outstanding: the stores of iteration c - D, and everything of iterations c - D + 1 .. c - 1.
+    // (In the first D - 1 iterations the DMAs of chunks c + 1 .. D - 1 -- issued by the prologue, right behind DMA(c) -- are
+    // among them: found by tests/test_xs_vmcnt_model.py, which replays this arithmetic; without the term iteration 0 of a
+    // 3-slot ring waited for chunk 1 as well.)
     int allow = 0;
+#pragma unroll
+    for (int j = 1; j < D; ++j) allow += (c + j < D && c + j < nch) ? DPC : 0;
 #pragma unroll
     for (int k = D; k >= 1; --k) {
       const int i = c - k;
