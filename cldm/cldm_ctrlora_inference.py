@@ -8,7 +8,7 @@ import torch.nn as nn
 from cldm.cldm import ControlLDM, ControlNet
 from cldm.cldm_ctrlora_finetune import swap_linears
 from cldm.ddim_hacked import DDIMSampler
-from cldm.lora import LoRACompatibleLinear, LoRALinearLayer
+from cldm.lora import LoRALinearLayer
 from cldm.switchable import SwitchableConv2d, SwitchableGroupNorm, SwitchableLayerNorm
 
 

@@ -18,7 +18,7 @@ Reference modules restated (behaviour, not code):
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, Optional, Tuple
 
 import torch
 

@@ -16,7 +16,7 @@ import torch
 from .. import hip
 from .blocks import Ctx
 from .nets import ControlNetE, NetCfg, UNetE
-from .packing import TrainableSet, rup
+from .packing import rup
 
 
 class CtrLoRAEngine:

@@ -11,7 +11,7 @@
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence
+from typing import List, Sequence
 
 import torch
 

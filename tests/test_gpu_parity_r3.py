@@ -16,12 +16,11 @@
 Reference lines: cldm/ddim_hacked.py:181-231, cldm/cldm_ctrlora_inference.py:156-178, cldm/lora.py:285-318,
 cldm/cldm_ctrlora_pretrain.py:95-111,174-182.  The oracle is the checker only.
 """
-import os
 
 import pytest
 import torch
 
-from tests.util import GOLDEN, rel_l2
+from tests.util import rel_l2
 from tests.test_gpu_bench_shapes import BF16_EPS, _bf, _need_gpu, _netcfg, _record
 
 pytestmark = pytest.mark.gpu

@@ -17,7 +17,6 @@ Reference: scripts/train_ctrlora_finetune.py:63-129, cldm/logger.py:12-126, scri
 cldm/cldm_ctrlora_pretrain.py:95-111."""
 import glob
 import importlib.util
-import json
 import os
 import sys
 import time

@@ -9,8 +9,6 @@ order, per wave, for every form that ships (ring depth 2 / 3; plain, residual, G
   * the residual wait inside an iteration covers the residual loads and nothing newer than them but this iteration's DMA;
   * every block is stored exactly once, its residual loaded exactly once before it.
 No GPU."""
-import itertools
-
 import pytest
 
 DPC_OF = {20: 5, 28: 7, 40: 10, 48: 12}          # DMA instructions per wave and chunk (K / 64)
