@@ -102,3 +102,46 @@ def test_measured_gemm_table_is_well_formed_and_registers():
     assert hip.load_gemm_table("") == 0 == L.cl_gemm_tune_size()          # A/B switch: built-in rules only
     assert L.cl_gemm_tune_set(0, 0, 64, 64, 64, 0, 0, 99, 0) != 0           # unknown configuration refused
     hip.load_gemm_table(hip.GEMM_TABLE_PATH)
+
+
+def test_ctypes_structs_have_the_layout_the_c_compiler_gives_the_header(tmp_path):
+    """cl_gemm_params / cl_wgrad_desc are passed BY POINTER / as a host array across the boundary: the ctypes mirrors in
+    ctrlora_amd/hip.py must agree with the header on every field's name, offset and on the total size -- checked against gcc's
+    own offsetof over include/ctrlora_hip.h (the header is plain C; a field renamed on one side only fails to compile here)."""
+    import shutil
+    import subprocess
+    from ctrlora_amd import hip
+    if shutil.which("gcc") is None:
+        pytest.skip("needs gcc")
+    pairs = [("cl_gemm_params", hip.GemmParams), ("cl_wgrad_desc", hip.WgradDesc)]
+    lines = ["#include <stddef.h>", "#include <stdio.h>", '#include "ctrlora_hip.h"', "int main(void) {"]
+    for cname, cls in pairs:
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu %zu\\n", offsetof({cname}, {fname}), sizeof((({cname}*)0)->{fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines) + "\n")
+    exe = tmp_path / "layout"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
+    got = {}
+    for ln in out:
+        w = ln.split()
+        if len(w) == 3 and w[1] == "size":
+            got[(w[0], None)] = int(w[2])
+        elif len(w) == 4:
+            got[(w[0], w[1])] = (int(w[2]), int(w[3]))
+    for cname, cls in pairs:
+        assert got[(cname, None)] == ctypes.sizeof(cls), (cname, got[(cname, None)], ctypes.sizeof(cls))
+        for fname, ftype in cls._fields_:
+            f = getattr(cls, fname)
+            assert got[(cname, fname)] == (f.offset, ctypes.sizeof(ftype)), (cname, fname, got[(cname, fname)], f.offset)
+    # and the header has no field the mirror lacks: same field COUNT per struct
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "ctrlora_hip.h")).read(), flags=re.S)
+    for cname, cls in pairs:
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, flags=re.S).group(1)
+        nfields = sum(len(decl.split(",")) for decl in body.split(";") if decl.strip())
+        assert nfields == len(cls._fields_), (cname, nfields, len(cls._fields_))
