@@ -43,6 +43,7 @@
 #include <vector>
 #include <utility>
 #include "mma.h"
+#include "gemm_epi.h"
 
 namespace cl {
 
@@ -95,59 +96,6 @@ static int tag_for(const GemmParams& p, int dtype) {
 
 template <int N> __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-struct EpiArgs {
-  const float* bias; const void* rowbias; long ldrb; int rows_per_batch;
-  const void* residual; long ldr; float alpha, beta; int act;
-  void* C; long ldc; int out_f32; int atomic; int M, N; int alpha_n;
-};
-
-// apply the epilogue to 8 consecutive columns of one row and store
-template <typename T>
-__device__ __forceinline__ void epilogue8(const EpiArgs& e, float v[8], int grow, int gcol) {
-  if (e.bias) {
-    const float4 b0 = *reinterpret_cast<const float4*>(e.bias + gcol);
-    const float4 b1 = *reinterpret_cast<const float4*>(e.bias + gcol + 4);
-    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-    v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-  }
-  if (e.rowbias) {
-    float rb[8];
-    load8(reinterpret_cast<const T*>(e.rowbias) + (long)(grow / e.rows_per_batch) * e.ldrb + gcol, rb);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] += rb[i];
-  }
-  if (e.act == ACT_SILU) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = silu_f(v[i]);
-  }
-  const float al = (e.alpha_n > 0 && gcol >= e.alpha_n) ? 1.0f : e.alpha;     // (8 columns never straddle alpha_n)
-#pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] *= al;
-  if (e.residual) {
-    float rs[8];
-    load8(reinterpret_cast<const T*>(e.residual) + (long)grow * e.ldr + gcol, rs);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] += e.beta * rs[i];
-  }
-  if (e.atomic) {
-    float* dst = reinterpret_cast<float*>(e.C) + (long)grow * e.ldc + gcol;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) atomicAdd(dst + i, v[i]);
-  } else if (e.out_f32) {
-    store8(reinterpret_cast<float*>(e.C) + (long)grow * e.ldc + gcol, v);
-  } else {
-    store8(reinterpret_cast<T*>(e.C) + (long)grow * e.ldc + gcol, v);
-  }
-}
-
-__device__ __forceinline__ EpiArgs epi_of(const GemmParams& p) {
-  EpiArgs e;
-  e.bias = p.bias; e.rowbias = p.rowbias; e.ldrb = p.ldrb; e.rows_per_batch = p.rows_per_batch;
-  e.residual = p.residual; e.ldr = p.ldr; e.alpha = p.alpha; e.beta = p.beta; e.act = p.act;
-  e.C = p.C; e.ldc = p.ldc; e.out_f32 = p.out_f32; e.atomic = p.atomic; e.M = p.M; e.N = p.N; e.alpha_n = p.alpha_n;
-  return e;
 }
 
 // Accumulator tile -> memory: each wave stages 32 (or 16) x WN fp32 through LDS so that residual
@@ -1091,6 +1039,16 @@ static int pick_splitk(GemmParams& p, long tiles, int steps, int want, int min_s
   return p.splitk;
 }
 
+// the same choice and the reduce launch for kernels in other translation units (gemm_w4.hip)
+int gemm_pick_splitk(GemmParams& p, long tiles, int steps, int want, int min_steps, float** slab, hipStream_t stream) {
+  return pick_splitk(p, tiles, steps, want, min_steps, slab, stream);
+}
+void gemm_launch_splitk_reduce_bf16(const GemmParams& p, const float* slab, hipStream_t stream) {
+  const long total = (long)p.M * (p.N / 8);
+  int rg = (int)((total + 255) / 256); if (rg > 4096) rg = 4096;
+  hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(rg), dim3(256), 0, stream, p, slab, p.splitk);
+}
+
 static int device_cus() {
   static int n = 0;
   if (!n) {
@@ -1176,7 +1134,7 @@ struct TuneKey {
 static std::map<TuneKey, std::pair<int, int>> g_tune;
 
 int gemm_tune_set(int dtype, int mode, int M, int N, int K1, int K2, int geglu, int cfg, int splitk) {
-  if (cfg < 0 || cfg > 36 || splitk < 0 || splitk > 64) return CL_EINVAL;
+  if (cfg < 0 || cfg > 41 || splitk < 0 || splitk > 64) return CL_EINVAL;
   g_tune[TuneKey{{dtype, mode, M, N, K1, K2, geglu ? 1 : 0}}] = std::make_pair(cfg, splitk);
   return CL_OK;
 }
@@ -1202,7 +1160,7 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
 
 template <typename T>
 static int launch_t_cfg(const GemmParams& p, hipStream_t stream, int cfg) {
-  if (p.act == ACT_GEGLU && cfg != 2 && cfg != 12 && cfg != 8 && cfg != 10 && cfg != 14 && cfg != 16 && cfg != 18 && cfg != 20 && cfg != 23 && cfg != 25 && cfg != 27 && cfg != 29) cfg = -2;   // needs a 2 x 80-column wave pair
+  if (p.act == ACT_GEGLU && cfg != 2 && cfg != 12 && cfg != 8 && cfg != 10 && cfg != 14 && cfg != 16 && cfg != 18 && cfg != 20 && cfg != 23 && cfg != 25 && cfg != 27 && cfg != 29 && !(cfg == 40 && sizeof(T) == 2)) cfg = -2;   // needs a 2 x 80-column wave pair (40: in-register pairing)
   if constexpr (sizeof(T) == 2) {
     // No table entry and no forced configuration: the x-stationary kernel by RULE where the measured table took it at the
     // benchmarked batch sizes (profiles/r05_gemm_xs/autotune_xs.out) -- other batch sizes (pre-training at the reference's
@@ -1251,6 +1209,8 @@ static int launch_t_cfg(const GemmParams& p, hipStream_t stream, int cfg) {
         case 0: case 24: return 64;
         case 1: case 6: case 7: case 22: return 128;
         case 2: case 3: case 4: case 5: case 23: return 160;
+        case 40: return lines ? 160 : 128;
+        case 41: return 128;
         case 31: case 32: case 35: case 36: return (lines && p.N % 80 == 0) ? 80 : 128;
         case 33: return (lines && p.N % 320 == 0) ? 320 : 128;
         case 34: return 32;    // x-stationary kernel: 32-column chunks (its own launcher re-checks the groups)
@@ -1361,6 +1321,13 @@ static int launch_t_cfg(const GemmParams& p, hipStream_t stream, int cfg) {
         if (rc != CL_EINVAL) return rc;
       }
       t_force_sk = 0;
+      return launch_t_cfg<T>(p, stream, -1);
+    }
+    case 40: case 41: {   // loader / consumer kernel (gemm_w4.hip): 256 x 160 / 256 x 128 tiles, 4 MFMA waves + 4 DMA waves
+      if constexpr (sizeof(T) == 2) {
+        const int rc = launch_gemm_w4(p, stream, cfg == 40 ? 160 : 128);
+        if (rc != CL_EINVAL) return rc;
+      }
       return launch_t_cfg<T>(p, stream, -1);
     }
     // small-M tiles of the generic kernel (8x8 / 16x16 levels, text-context projections): offered to the tuner

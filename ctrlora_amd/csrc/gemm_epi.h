@@ -1,0 +1,62 @@
+// Epilogue shared by the tile kernels (gemm.hip) and the loader / consumer kernel (gemm_w4.hip): bias, time-embedding
+// row-bias (openaimodel.py:272), SiLU, alpha / alpha_n, beta * residual (openaimodel.py:274, cldm/cldm.py:41), fp32 / bf16 /
+// atomic store -- applied to 8 consecutive columns of one output row.
+#pragma once
+#include "gemm.h"
+
+namespace cl {
+
+struct EpiArgs {
+  const float* bias; const void* rowbias; long ldrb; int rows_per_batch;
+  const void* residual; long ldr; float alpha, beta; int act;
+  void* C; long ldc; int out_f32; int atomic; int M, N; int alpha_n;
+};
+
+// apply the epilogue to 8 consecutive columns of one row and store
+template <typename T>
+__device__ __forceinline__ void epilogue8(const EpiArgs& e, float v[8], int grow, int gcol) {
+  if (e.bias) {
+    const float4 b0 = *reinterpret_cast<const float4*>(e.bias + gcol);
+    const float4 b1 = *reinterpret_cast<const float4*>(e.bias + gcol + 4);
+    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+    v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+  }
+  if (e.rowbias) {
+    float rb[8];
+    load8(reinterpret_cast<const T*>(e.rowbias) + (long)(grow / e.rows_per_batch) * e.ldrb + gcol, rb);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += rb[i];
+  }
+  if (e.act == ACT_SILU) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = silu_f(v[i]);
+  }
+  const float al = (e.alpha_n > 0 && gcol >= e.alpha_n) ? 1.0f : e.alpha;     // (8 columns never straddle alpha_n)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] *= al;
+  if (e.residual) {
+    float rs[8];
+    load8(reinterpret_cast<const T*>(e.residual) + (long)grow * e.ldr + gcol, rs);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += e.beta * rs[i];
+  }
+  if (e.atomic) {
+    float* dst = reinterpret_cast<float*>(e.C) + (long)grow * e.ldc + gcol;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(dst + i, v[i]);
+  } else if (e.out_f32) {
+    store8(reinterpret_cast<float*>(e.C) + (long)grow * e.ldc + gcol, v);
+  } else {
+    store8(reinterpret_cast<T*>(e.C) + (long)grow * e.ldc + gcol, v);
+  }
+}
+
+__device__ __forceinline__ EpiArgs epi_of(const GemmParams& p) {
+  EpiArgs e;
+  e.bias = p.bias; e.rowbias = p.rowbias; e.ldrb = p.ldrb; e.rows_per_batch = p.rows_per_batch;
+  e.residual = p.residual; e.ldr = p.ldr; e.alpha = p.alpha; e.beta = p.beta; e.act = p.act;
+  e.C = p.C; e.ldc = p.ldc; e.out_f32 = p.out_f32; e.atomic = p.atomic; e.M = p.M; e.N = p.N; e.alpha_n = p.alpha_n;
+  return e;
+}
+
+}  // namespace cl

@@ -7,10 +7,11 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value"
 C=ctrlora_amd/csrc
 for p in "$@"; do
   case $p in
-    gemm) hipcc $FLAGS tools/probe_gemm.hip $C/gemm.hip $C/gemm_xs.hip $C/wgrad.hip -o build/probe_gemm ;;
-    gemm_t) hipcc $FLAGS -DFL_TIMING tools/probe_gemm.hip $C/gemm.hip $C/gemm_xs.hip $C/wgrad.hip -o build/probe_gemm_t ;;
-    attn) hipcc $FLAGS tools/probe_attn.hip $C/gemm.hip $C/gemm_xs.hip $C/attention_fwd.hip $C/attention_bwd.hip $C/attention_tr.hip $C/elementwise.hip -o build/probe_attn ;;
-    attn_bwd) hipcc $FLAGS tools/probe_attn_bwd.hip $C/gemm.hip $C/gemm_xs.hip $C/attention_fwd.hip $C/attention_bwd.hip $C/attention_tr.hip $C/elementwise.hip -o build/probe_attn_bwd ;;
+    gemm) hipcc $FLAGS tools/probe_gemm.hip $C/gemm.hip $C/gemm_xs.hip $C/gemm_w4.hip $C/wgrad.hip -o build/probe_gemm ;;
+    gemm_w4) hipcc $FLAGS -DW4_PROBE tools/probe_gemm.hip $C/gemm.hip $C/gemm_xs.hip $C/gemm_w4.hip $C/wgrad.hip -o build/probe_gemm_w4 ;;
+    gemm_t) hipcc $FLAGS -DFL_TIMING tools/probe_gemm.hip $C/gemm.hip $C/gemm_xs.hip $C/gemm_w4.hip $C/wgrad.hip -o build/probe_gemm_t ;;
+    attn) hipcc $FLAGS tools/probe_attn.hip $C/gemm.hip $C/gemm_xs.hip $C/gemm_w4.hip $C/attention_fwd.hip $C/attention_bwd.hip $C/attention_tr.hip $C/elementwise.hip -o build/probe_attn ;;
+    attn_bwd) hipcc $FLAGS tools/probe_attn_bwd.hip $C/gemm.hip $C/gemm_xs.hip $C/gemm_w4.hip $C/attention_fwd.hip $C/attention_bwd.hip $C/attention_tr.hip $C/elementwise.hip -o build/probe_attn_bwd ;;
     stream_gemm) hipcc $FLAGS tools/probe_stream_gemm.hip -o build/probe_stream_gemm ;;
     attn_bwd_abl)   # the product library with ONE ingredient of the d_head-40 fold backward kernels removed (attention_tr.hip: ATTN_BWD_ABL)
       python -m ctrlora_amd.build > /dev/null

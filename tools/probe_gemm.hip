@@ -460,6 +460,116 @@ static void correctness_suite(const char* tag) {
   case_conv("conv3x3 s1 f32 1x9x7x16->24", CL_F32, GEMM_CONV_S1, 1, 9, 7, 16, 24);
 }
 
+
+// ---------------- loader / consumer kernel (configurations 40 / 41, gemm_w4.hip) ----------------
+#ifdef W4_PROBE
+namespace cl { void w4_abl_set(int v); void w4_sched_set(int v); void w4_timing_set(unsigned long long* buf); }
+#endif
+// interleaved A/B of tile configurations on ONE set of operands: median / min of `rounds` timed batches each, the outputs compared with
+// configuration cfgs[0]'s (different summation order: rel-L2 at the bf16 rounding level), and every configuration's repeat launches
+// compared BITWISE (an LDS-ring race shows up as a run-to-run difference long before it shows up in an error norm)
+static void ab_case(const char* name, int mode, int M, int N, int K1, int B, int H, int W, int K2, const int* cfgs, int ncfg, int rounds = 5,
+                    bool resid = false, bool rowb_silu = false) {
+  const int dtype = CL_BF16;
+  Buf A, Wt, A2, W2, R, RB;
+  const int taps = mode == GEMM_LINEAR ? 1 : 9;
+  A.init(mode == GEMM_LINEAR ? (size_t)M * K1 : (size_t)B * H * W * K1, dtype);
+  Wt.init((size_t)N * taps * K1, dtype, 0.05f);
+  if (K2) { A2.init((size_t)M * K2, dtype); W2.init((size_t)N * K2, dtype, 0.05f); }
+  if (resid) R.init((size_t)M * N, dtype);
+  const int rpb = mode == GEMM_LINEAR ? 4096 : H * W;
+  if (rowb_silu) RB.init((size_t)((M + rpb - 1) / rpb) * N, dtype);
+  std::vector<float> hb(N); for (auto& v : hb) v = frand();
+  float* dbias; HIPCHK(hipMalloc(&dbias, N * 4)); HIPCHK(hipMemcpy(dbias, hb.data(), N * 4, hipMemcpyHostToDevice));
+  GemmParams p{}; p.A1 = A.d; p.lda1 = K1; p.K1 = K1; p.W1 = Wt.d; p.ldw1 = taps * K1; p.M = M; p.N = N; p.mode = mode;
+  if (K2) { p.A2 = A2.d; p.lda2 = K2; p.K2 = K2; p.W2 = W2.d; p.ldw2 = K2; }
+  p.B = B; p.Hin = H; p.Win = W; p.Hout = H; p.Wout = W; p.zero_page = g_zero; p.alpha = 1.f; p.ldc = N; p.splitk = 1; p.bias = dbias;
+  if (resid) { p.residual = R.d; p.ldr = N; p.beta = 1.f; }
+  if (rowb_silu) { p.rowbias = RB.d; p.ldrb = N; p.rows_per_batch = rpb; p.act = ACT_SILU; }
+  std::vector<void*> C(ncfg);
+  std::vector<std::vector<uint16_t>> h(ncfg, std::vector<uint16_t>((size_t)M * N)), h2(1, std::vector<uint16_t>((size_t)M * N));
+  std::vector<std::vector<float>> t(ncfg);
+  std::vector<int> rcs(ncfg, 0);
+  hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  for (int c = 0; c < ncfg; ++c) { HIPCHK(hipMalloc(&C[c], (size_t)M * N * 2)); HIPCHK(hipMemset(C[c], 0, (size_t)M * N * 2)); }
+  const int iters = 10;
+  for (int r = 0; r < rounds + 1; ++r)
+    for (int c = 0; c < ncfg; ++c) {
+      g_gemm_force_cfg = cfgs[c]; p.C = C[c];
+      HIPCHK(hipEventRecord(e0, 0));
+      for (int i = 0; i < iters; ++i) rcs[c] |= launch_gemm(p, dtype, 0);
+      HIPCHK(hipEventRecord(e1, 0)); HIPCHK(hipEventSynchronize(e1));
+      float ms; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+      if (r > 0) t[c].push_back(ms / iters * 1e3f);      // round 0 = warm-up (clock ramp, first-touch)
+    }
+  g_gemm_force_cfg = -1;
+  const double fl = 2.0 * M * N * ((double)taps * K1 + K2);
+  for (int c = 0; c < ncfg; ++c) HIPCHK(hipMemcpy(h[c].data(), C[c], h[c].size() * 2, hipMemcpyDeviceToHost));
+  for (int c = 0; c < ncfg; ++c) {
+    // bitwise repeat: three more single launches into a scrubbed buffer
+    size_t rep_diff = 0;
+    for (int k = 0; k < 3; ++k) {
+      HIPCHK(hipMemset(C[c], 0xff, (size_t)M * N * 2));
+      g_gemm_force_cfg = cfgs[c]; p.C = C[c];
+      launch_gemm(p, dtype, 0); HIPCHK(hipDeviceSynchronize());
+      HIPCHK(hipMemcpy(h2[0].data(), C[c], h2[0].size() * 2, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < h2[0].size(); ++i) rep_diff += h2[0][i] != h[c][i];
+    }
+    g_gemm_force_cfg = -1;
+    double num = 0, den = 0; size_t nz = 0;
+    for (size_t i = 0; i < h[c].size(); ++i) {
+      const double a = h_bf2f(h[c][i]), b = h_bf2f(h[0][i]); num += (a - b) * (a - b); den += b * b; nz += h[c][i] != 0;
+    }
+    std::sort(t[c].begin(), t[c].end());
+    const float med = t[c][t[c].size() / 2], mn = t[c][0];
+    const double rel = std::sqrt(num / (den + 1e-30));
+    const bool ok = rcs[c] == 0 && rep_diff == 0 && rel < 4e-3 && nz > h[c].size() / 2;
+    printf("[%s] %-40s cfg %2d: median %8.1f us (%7.1f TF/s)  min %8.1f us  | vs cfg %2d rel_l2 %.2e | repeat diffs %zu\n", ok ? "PASS" : "FAIL",
+           name, cfgs[c], med, fl / med * 1e-6, mn, cfgs[0], rel, rep_diff);
+    if (!ok) g_fail++;
+  }
+  for (int c = 0; c < ncfg; ++c) hipFree(C[c]);
+  hipFree(A.d); hipFree(Wt.d); hipFree(dbias); if (K2) { hipFree(A2.d); hipFree(W2.d); } if (resid) hipFree(R.d); if (rowb_silu) hipFree(RB.d);
+}
+
+// one big conv against the CPU double reference on sampled output elements (full tensors are too slow on the host)
+static void conv_sampled(const char* name, int cfg, int B, int H, int W, int C, int N, int nsamp) {
+  const int M = B * H * W;
+  Buf X, Wt, Cb; std::vector<float> hb(N);
+  X.init((size_t)M * C, CL_BF16); Wt.init((size_t)N * 9 * C, CL_BF16, 0.05f);
+  for (auto& v : hb) v = frand();
+  float* dbias; HIPCHK(hipMalloc(&dbias, N * 4)); HIPCHK(hipMemcpy(dbias, hb.data(), N * 4, hipMemcpyHostToDevice));
+  Cb.init((size_t)M * N, CL_F32, 1.0f, true);
+  GemmParams p{}; p.A1 = X.d; p.lda1 = C; p.K1 = C; p.W1 = Wt.d; p.ldw1 = 9 * C; p.M = M; p.N = N; p.mode = GEMM_CONV_S1;
+  p.B = B; p.Hin = H; p.Win = W; p.Hout = H; p.Wout = W; p.zero_page = g_zero; p.bias = dbias;
+  p.alpha = 1.f; p.C = Cb.d; p.ldc = N; p.out_f32 = 1; p.splitk = 1;
+  g_gemm_force_cfg = cfg;
+  int rc = launch_gemm(p, CL_BF16, 0);
+  g_gemm_force_cfg = -1;
+  HIPCHK(hipDeviceSynchronize());
+  if (rc) { printf("[FAIL] %s rc=%d\n", name, rc); g_fail++; return; }
+  Cb.download(CL_F32);
+  double num = 0, den = 0;
+  for (int sidx = 0; sidx < nsamp; ++sidx) {
+    rng_state = rng_state * 1664525u + 1013904223u; const int m = (int)((rng_state >> 4) % (unsigned)M);
+    rng_state = rng_state * 1664525u + 1013904223u; const int n = (int)((rng_state >> 4) % (unsigned)N);
+    // corners and edges first: they exercise the tap mask
+    const int mm = sidx < 8 ? ((sidx & 1) ? M - 1 - (sidx >> 1) * (W - 1) : (sidx >> 1) * (W - 1)) : m;
+    const int ox = mm % W, oy = (mm / W) % H, b = mm / (W * H);
+    double sacc = hb[n];
+    for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) {
+      const int iy = oy + ky - 1, ix = ox + kx - 1;
+      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+      const float* xp = &X.h[(((size_t)b * H + iy) * W + ix) * C];
+      const float* wp = &Wt.h[((size_t)n * 9 + ky * 3 + kx) * C];
+      for (int c = 0; c < C; ++c) sacc += (double)xp[c] * wp[c];
+    }
+    const double d = Cb.h[(size_t)mm * N + n] - sacc; num += d * d; den += sacc * sacc;
+  }
+  report(name, num, den, 2e-5);
+  hipFree(X.d); hipFree(Wt.d); hipFree(Cb.d); hipFree(dbias);
+}
+
 #ifdef FL_TIMING
 namespace cl { void fl_timing_set(unsigned long long* buf); }
 #endif
@@ -657,6 +767,93 @@ int main(int argc, char** argv) {
     time_case("tile GEGLU 8192x5120x640", CL_BF16, GEMM_LINEAR, 8192, 5120, 640, 0, 0, 0);
     g_probe_act = 0;
     printf("%s\n", g_fail ? "XS PROBE: FAILURES" : "XS PROBE: all pass");
+    return g_fail ? 1 : 0;
+  }
+  if (argc > 1 && !strcmp(argv[1], "--w4")) {   // loader / consumer kernel: correctness, then interleaved A/B against the ping-pong tiles
+    const bool quick = argc > 2 && !strcmp(argv[2], "quick");
+    const bool abl_only = argc > 2 && !strcmp(argv[2], "abl");
+    if (abl_only) goto w4_ablations;
+    {
+    const int cf[] = {40, 41};
+    for (int c : cf) { char tag[32]; snprintf(tag, 32, "forced cfg %d", c); g_gemm_force_cfg = c; correctness_suite(tag); }
+    g_gemm_force_cfg = -1;
+    conv_sampled("conv 320->320 @64^2 B2 sampled vs fp64, cfg 40", 40, 2, 64, 64, 320, 320, 4000);
+    conv_sampled("conv 128->128 @96x80 B1 sampled vs fp64, cfg 41", 41, 1, 96, 80, 128, 128, 4000);
+    conv_sampled("conv 640->320 ragged 3x33x31 sampled, cfg 40", 40, 3, 33, 31, 640, 320, 4000);
+    const int ab[] = {16, 40}, ab128[] = {17, 41};
+    ab_case("conv 320->320 @64^2 B8", GEMM_CONV_S1, 8 * 64 * 64, 320, 320, 8, 64, 64, 0, ab, 2, 7);
+    ab_case("conv 320->320 @64^2 B8 rowbias+silu", GEMM_CONV_S1, 8 * 64 * 64, 320, 320, 8, 64, 64, 0, ab, 2, 3, false, true);
+    ab_case("conv 320->320 @64^2 B32 (DDIM)", GEMM_CONV_S1, 32 * 64 * 64, 320, 320, 32, 64, 64, 0, ab, 2, 3);
+    ab_case("conv 960->320 @64^2 B8", GEMM_CONV_S1, 8 * 64 * 64, 320, 960, 8, 64, 64, 0, ab, 2, 3);
+    ab_case("conv 640->320 @64^2 B8 + residual", GEMM_CONV_S1, 8 * 64 * 64, 320, 640, 8, 64, 64, 0, ab, 2, 3, true);
+    ab_case("conv 640->640 @32^2 B8", GEMM_CONV_S1, 8 * 32 * 32, 640, 640, 8, 32, 32, 0, ab, 2, 3);
+    ab_case("conv 1280->1280 @16^2 B8", GEMM_CONV_S1, 8 * 16 * 16, 1280, 1280, 8, 16, 16, 0, ab, 2, 3);
+    ab_case("conv 2560->1280 @16^2 B8", GEMM_CONV_S1, 8 * 16 * 16, 1280, 2560, 8, 16, 16, 0, ab, 2, 3);
+    ab_case("conv 1280->1280 @8^2 B8 (split-K)", GEMM_CONV_S1, 8 * 8 * 8, 1280, 1280, 8, 8, 8, 0, ab, 2, 3);
+    ab_case("conv 128->128 @256^2 B4 (VAE)", GEMM_CONV_S1, 4 * 256 * 256, 128, 128, 4, 256, 256, 0, ab128, 2, 3);
+    ab_case("conv 256->256 @128^2 B4 (VAE)", GEMM_CONV_S1, 4 * 128 * 128, 256, 256, 4, 128, 128, 0, ab128, 2, 3);
+    ab_case("gemm 4096^3", GEMM_LINEAR, 4096, 4096, 4096, 0, 0, 0, 0, ab128, 2, 3);
+    ab_case("gemm 32768x320x1280 (FF out)", GEMM_LINEAR, 32768, 320, 1280, 0, 0, 0, 0, ab, 2, 3);
+    ab_case("gemm 32768x320x1280+128 (FF out, LoRA)", GEMM_LINEAR, 32768, 320, 1280, 0, 0, 0, 128, ab, 2, 3, true);
+    ab_case("gemm 8192x640x2560 (FF out 32^2)", GEMM_LINEAR, 8192, 640, 2560, 0, 0, 0, 0, ab, 2, 3);
+    if (!quick) {
+      ab_case("gemm 32768x320x320", GEMM_LINEAR, 32768, 320, 320, 0, 0, 0, 0, ab, 2, 3);
+      ab_case("gemm 32768x2560x320", GEMM_LINEAR, 32768, 2560, 320, 0, 0, 0, 0, ab, 2, 3);
+      ab_case("gemm 2048x1280x1280", GEMM_LINEAR, 2048, 1280, 1280, 0, 0, 0, 0, ab, 2, 3);
+      ab_case("gemm 8192x640x640", GEMM_LINEAR, 8192, 640, 640, 0, 0, 0, 0, ab, 2, 3);
+    }
+    }
+w4_ablations:
+#ifdef W4_PROBE
+    const int only40[] = {40};
+    {
+      printf("---- read schedule: 0 = two reads per gap + lgkmcnt(0) per k-step, 1 = counted waits (production)\n");
+      for (int rep = 0; rep < 2; ++rep)
+        for (int sc = 0; sc < 2; ++sc) {
+          cl::w4_sched_set(sc);
+          char nm[64]; snprintf(nm, 64, "conv 320->320 @64^2 B8  sched %d", sc);
+          ab_case(nm, GEMM_CONV_S1, 8 * 64 * 64, 320, 320, 8, 64, 64, 0, only40, 1, 5);
+        }
+      cl::w4_sched_set(1);
+    }
+    const int abls[] = {0, 1, 2, 3, 4, 5, 6, 7, 13, 21, 37, 33};
+    const char* an[] = {"full", "no fragment reads", "no DMA", "no reads, no DMA", "no stores", "no reads + no stores", "no DMA + no stores",
+                        "skeleton: MFMA + barrier only", "W-tile DMA only (no X DMA, no reads, no stores)", "X-tile DMA only (no W DMA, no reads, no stores)", "DMA + barriers only (no MFMA, no reads, no stores)", "DMA + reads, no MFMA"};
+    for (int ai = 0; ai < 12; ++ai) {
+      cl::w4_abl_set(abls[ai]);
+      printf("---- ablation %d: %s (results wrong by construction; FAIL lines below are expected)\n", abls[ai], an[ai]);
+      const int keep = g_fail;
+      ab_case("conv 320->320 @64^2 B8", GEMM_CONV_S1, 8 * 64 * 64, 320, 320, 8, 64, 64, 0, only40, 1, 3);
+      ab_case("conv 320->320 @64^2 B32", GEMM_CONV_S1, 32 * 64 * 64, 320, 320, 32, 64, 64, 0, only40, 1, 3);
+      g_fail = keep;
+    }
+    cl::w4_abl_set(0);
+    {   // s_memtime stamps of every tile: entry | stage 0 landed | main loop done | stores retired
+      const int M = 8 * 64 * 64, N = 320, K1 = 320;
+      Buf A, Wt, Cb; A.init((size_t)M * K1, CL_BF16); Wt.init((size_t)N * 9 * K1, CL_BF16, 0.05f); Cb.init((size_t)M * N, CL_BF16, 1.f, true);
+      GemmParams p{}; p.A1 = A.d; p.lda1 = K1; p.K1 = K1; p.W1 = Wt.d; p.ldw1 = 9 * K1; p.M = M; p.N = N; p.mode = GEMM_CONV_S1;
+      p.B = 8; p.Hin = 64; p.Win = 64; p.Hout = 64; p.Wout = 64; p.zero_page = g_zero; p.alpha = 1.f; p.C = Cb.d; p.ldc = N; p.splitk = 1;
+      const long nv = 256;
+      unsigned long long* tb; HIPCHK(hipMalloc(&tb, nv * 32)); HIPCHK(hipMemset(tb, 0, nv * 32));
+      g_gemm_force_cfg = 40;
+      for (int i = 0; i < 3; ++i) launch_gemm(p, CL_BF16, 0);
+      HIPCHK(hipDeviceSynchronize());
+      cl::w4_timing_set(tb);
+      launch_gemm(p, CL_BF16, 0); HIPCHK(hipDeviceSynchronize());
+      cl::w4_timing_set(nullptr);
+      g_gemm_force_cfg = -1;
+      std::vector<unsigned long long> tt(nv * 4);
+      HIPCHK(hipMemcpy(tt.data(), tb, nv * 32, hipMemcpyDeviceToHost));
+      double ph[3] = {0, 0, 0}; unsigned long long tmin = ~0ull, tmax = 0;
+      for (long i = 0; i < nv; ++i) {
+        for (int k = 0; k < 3; ++k) ph[k] += (double)(tt[i * 4 + k + 1] - tt[i * 4 + k]);
+        tmin = std::min(tmin, tt[i * 4]); tmax = std::max(tmax, tt[i * 4 + 3]);
+      }
+      printf("[TIMING] cfg 40 conv 320->320 @64^2 B8: %ld tiles, span %.0f ticks; per tile: entry -> stage 0 landed %.0f | main loop (45 stages) %.0f | "
+             "epilogue to stores retired %.0f  [s_memtime ticks]\n", nv, (double)(tmax - tmin), ph[0] / nv, ph[1] / nv, ph[2] / nv);
+    }
+#endif
+    printf("probe_gemm --w4: %s (%d failures)\n", g_fail ? "FAILED" : "ALL PASS", g_fail);
     return g_fail ? 1 : 0;
   }
   if (argc > 1 && !strcmp(argv[1], "--stagger")) {   // two workgroups per CU, the second one held back once
