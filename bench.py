@@ -743,7 +743,11 @@ def dist_dry_run(args, world, rank, local):
         dist.barrier()
     sync()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    per_rank = [float(dt) / args.steps * 1e3]
     if multi:
+        allt = [torch.zeros_like(dt) for _ in range(dist.get_world_size())]
+        dist.all_gather(allt, dt)
+        per_rank = [float(x) / args.steps * 1e3 for x in allt]
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     want = world * (world + 1) / 2 if multi else float(rank + 1)
     ok = bool(torch.all(bucket == want))
@@ -754,6 +758,7 @@ def dist_dry_run(args, world, rank, local):
         print(json.dumps({"metric": "launch-path dry run (no model): 4 MB all-reduce per step", "value": round(args.steps / float(dt), 3),
                           "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(float(dt) / args.steps * 1e3, 3), "dry_run": True,
+                          "world": (dist.get_world_size() if multi else 1), "ms_per_step_by_rank": [round(v, 3) for v in per_rank],
                           "backend": (dist.get_backend() if multi else "none"), "device": device.type,
                           "allreduce_sum_correct_on_every_rank": bool(int(okt))}))
     if multi:

@@ -143,9 +143,11 @@ class _PretrainDP:
     def note_used(self, task):
         if task not in self.used:
             self.used.append(task)
-        if self.enabled and self.inner.world_size > 1 and self.inner._mask_pre is None and not self._mask_sent:
+        if self.enabled and self.inner.world_size > 1:
             # final micro-step of the optimizer step, called at the START of its forward (apply_model /
-            # engine_train_step): the used-bank mask travels while the step computes (BankedGradAllReduce.prefetch_mask)
+            # engine_train_step): the used-bank mask travels while the step computes (BankedGradAllReduce.prefetch_mask).
+            # Idempotent for an unchanged set; a set that changed since an un-consumed prefetch (a forward without its backward
+            # pass) supersedes it there -- on every rank alike
             self.inner.prefetch_mask(self.used)
             self._mask_sent = True
 

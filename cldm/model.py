@@ -35,12 +35,17 @@ def load_state_dict(ckpt_path, location="cpu"):
 def create_model(config_path):
     """cldm/model.py:23-28.  The parameters come out with torch's default distributions, drawn the fast way
     (ctrlora_amd/fastinit.py: a checkpoint overwrites them in every script anyway, and eight ranks constructing the model with
-    per-layer kaiming_uniform_ calls spend minutes of shared host cores)."""
+    per-layer kaiming_uniform_ calls spend minutes of shared host cores).  CTRLORA_FAST_INIT=0 keeps torch's own per-layer
+    draws (as bench.build_model does)."""
+    import os
     from ctrlora_amd.fastinit import fill_default_init, skip_default_init
     with open(config_path) as fh:
         tree = yaml.safe_load(fh)
-    with skip_default_init():
+    if os.environ.get("CTRLORA_FAST_INIT", "1") == "0":
         net = instantiate_from_config(tree["model"])
-    fill_default_init(net, seed=int(torch.initial_seed() % (1 << 30)))
+    else:
+        with skip_default_init():
+            net = instantiate_from_config(tree["model"])
+        fill_default_init(net, seed=int(torch.initial_seed() % (1 << 30)))
     print(f"[cldm.model] built {type(net).__name__} from {config_path}")
     return net.cpu()

@@ -3,33 +3,52 @@
 //   out[M,N] = epilogue( A1[M,K1].W1[N,K1]^T  (+ A2[M,K2].W2[N,K2]^T) )          linear, or implicit 3x3 conv over NHWC
 //
 // Which products: the ResBlock / Downsample / Upsample 3x3 convolutions (ldm/modules/diffusionmodules/openaimodel.py:108-118,
-// 150,203,229) and the deep-K linears (attention.py:59-76 FeedForward out, 163-170 projections at K >= 1280) -- everything the
-// 256 x 160 ping-pong tile kernel (gemm_fl_kernel, gemm.hip) served at 42-44 % of the matrix peak.  What limited that kernel was
-// its synchronisation skeleton: eight waves, four s_barrier-delimited sections per 128-byte stage (two waves of a SIMD swap
-// the "load" and "multiply" roles at every barrier), 20-MFMA sections of v_mfma_f32_16x16x32_bf16, 9 ds_read_b128 per 20 MFMAs.
+// 150,203,229) and the deep-K linears (attention.py:59-76 FeedForward out, 163-170 projections at K >= 1280) -- what the
+// 256 x 160 ping-pong tile kernel (gemm_fl_kernel, gemm.hip) serves at 42-44 % of the matrix peak.
 //
-// Structure here: the two roles are two KINDS of wave, for the whole tile.
+// What bounds such a product on this chip (profiles/r06_w4/, tools/probe_simd.hip): POWER.  A bare stream of
+// v_mfma_f32_32x32x16_bf16 on uniform random operands clocks down to 1.68 GHz = 1.75 PF/s (2.14 PF/s on constant operands); the
+// same FLOPs as v_mfma_f32_16x16x32_bf16 hold 1.88 GHz = 1.94 PF/s (a quarter of the accumulator traffic per FLOP); and every
+// KB moved beside the MFMAs comes out of the clock: +1 ds_read_b128 per 32-cycle MFMA slot -8.5 %, +1 LDS-DMA (1 KiB) per four
+// slots -7.5 %.  Costs ADD -- measured on the first form of this kernel (one 32x32x16 wave per SIMD, 64 x 160 per wave): MFMA
+// alone 29.5 us, + fragment reads +10, + DMA +17, + stores +11 = 64 us at 1.56 GHz against the ping-pong kernel's 55 at 2.08.
+// So the levers are joules, not issue slots: the cheaper MFMA shape, fewer DMA bytes per FLOP, no stall that is not hidden.
+//
+// Structure: two KINDS of wave, for the whole tile.
 //   * waves 0-3, the CONSUMERS, one per SIMD: each owns 64 rows x BN columns of the 256 x BN tile and issues nothing but
-//     v_mfma_f32_32x32x16_bf16 (inline asm, accumulators in the accumulation registers) and the ds_read_b128 of the next k-step's
-//     fragments, two reads per MFMA gap: 2 + BN/32 reads per 2 BN/32 MFMAs of 32 cycles each (BN 160: 7 reads per 320 matrix
-//     cycles, 35 % of the LDS read bandwidth; the 16x16x32 form needs 9 per 320).  The product is formed TRANSPOSED
-//     (D^T[n x m] = W[n x k] . X^T[k x m]: W is the A operand), so a lane ends up with 4 consecutive output columns of ONE row
-//     per 8-column group; v_permlane32_swap pairs the half-waves' groups and every lane stores 8 consecutive columns (16 / 32
-//     bytes) straight from registers -- no LDS staging, no barrier in the epilogue;
-//   * waves 4-7, the LOADERS, one per SIMD: all address generation (linear / stride-1 conv with a 9-bit tap mask / generic
-//     conv) and every global_load_lds_dwordx4 (8 rows x 128 B per instruction, XOR-swizzled on the source side exactly as in
-//     gemm_fl_kernel: the 32-row fragment reads are bank-conflict-free).  A loader's LDS-DMA issue (tens of cycles each) and its
-//     VALU run beside the consumer's MFMA stream on the same SIMD instead of inside it;
-//   * ONE s_barrier per stage.  Ring of 3 stages (156 KB).  B(s) = "stage s has landed and nobody reads stage s-2 any more":
-//       loader   ... DMA(s+1) | vmcnt: own DMA(s) landed | B(s) | DMA(s+2) -> slot of stage s-1 | vmcnt | B(s+1) ...
-//       consumer ... k-steps 0..2 of stage s-1 | lgkmcnt(0): last reads of stage s-1 retired | B(s) | k-step 3 of stage s-1 with
-//                    the reads of stage s, k-step 0 | k-steps 0..2 of stage s | B(s+1) ...
-//     RAW: every loader's counted vmcnt for stage s precedes B(s); the first read of stage s is issued after it.
-//     WAR: the slot of stage s-1 is refilled (DMA(s+2)) after B(s), which every consumer passes with lgkmcnt(0) after its last
-//          read of stage s-1 (issued in k-step 2 of that stage).
-//     A loader sits in B(s+1) about one stage ahead of the consumers: a DMA has two stages (~2500 cycles) to land.
-// All waves of a workgroup share one register allocation: 512 threads = two waves per SIMD = 256 registers, of which the
-// consumer holds 160 accumulators + 56 fragment registers + 8 addresses, the loader ~50 addresses.
+//     v_mfma_f32_16x16x32_bf16 (inline asm) and ds_read_b128.  Per 128-byte stage and wave: 2 NW groups of four MFMAs
+//     (NW = BN / 16; group k multiplies W fragment k by the four X fragments of its k-half), W fragments through a ring of
+//     R = NW / 2 register quads (the read of W[k + R] goes out behind group k), X fragments double-buffered per k-half; every
+//     read has >= R groups (320 cycles) to land and is waited for with a COUNTED lgkmcnt (LDS returns in order; the counts come
+//     from a constexpr replay of the issue order, w4_sched).  The product is formed TRANSPOSED (D^T[n x m] = W[n x k] . X^T[k x m])
+//     so that a lane holds 4 consecutive output columns of one row; v_permlane16_swap pairs neighbouring 16-column blocks and
+//     every lane stores 8 consecutive columns, a wave-instruction whole 64-byte row segments, straight from registers;
+//   * waves 4-7, the LOADERS, one per SIMD: all address generation and every global_load_lds_dwordx4 (8 rows x 128 B per
+//     instruction, XOR-swizzled on the SOURCE side: the fragment reads are bank-conflict-free).
+//   * a 3-slot LDS ring and TWO barriers per stage, neither of which makes anybody wait for a read:
+//       consumer  stage s:  group 0 | B_war(s-1) | groups 1 .. GB | B_raw(s+1) | groups GB+1 .. (first reads of stage s+1)
+//       loader    ... B_war(s-1) | DMA(s+2) -> slot of stage s-1 | vmcnt: own DMA(s+1) landed | B_raw(s+1) ...
+//     RAW: every loader's counted vmcnt for stage s+1 precedes B_raw(s+1); the first read of stage s+1 follows it.
+//     WAR: the slot of stage s-1 is refilled after B_war(s-1), which a consumer passes behind group 0 of stage s -- that group
+//          waited for W[0] of stage s, a read issued after every read of stage s-1 (in-order return: they have all retired).
+//     A DMA has ~1.7 stages to land -- about what an LDS-DMA round trip takes under load (~2000-2500 cycles for HBM / Infinity-Cache
+//     data, less for the L2-resident weights), and LDS cannot hold a fourth slot: the chain is just-in-time by construction.
+//     (Tried: LDS mailboxes -- ds_add counters polled through the consumers' in-order read queue -- instead of barriers, so that
+//     one wave's LDS jitter is not everybody's stall.  Correct, and slower: the polls' round trips add straight onto the chain,
+//     DMA + synchronisation alone 1263 -> 1650 cycles per stage, profiles/r06_w4/probe_w4_v3_lds_mailboxes_instead_of_barriers.log.)
+//   * HALO mode (stride-1 3x3 convolutions whose 256-row tile lies inside one image, H W % 256 == 0, W <= 64): the X operand is
+//     not re-fetched per tap.  Per 64-channel chunk the loaders bring the tile's input pixels ONCE, with their one-pixel halo,
+//     as an LDS image of (R + 2) x (W + 1) + 1 pixel rows of 128 bytes (one zero column between image rows serves as right AND left
+//     padding; zero rows above / below the image: no masks anywhere);
+//     the nine taps of the chunk are nine stages whose X fragment rows are the same image read at a wave-uniform row offset
+//     (ky (W + 1) + kx), and only the 20 KB weight tile streams per stage.  K is walked chunk-major (chunk, tap) instead of
+//     tap-major.  LDS-DMA instructions per stage and SIMD: 13 -> 6.4; two image buffers (the next chunk's lands under this one's
+//     nine stages, its pieces riding on taps 2 .. 8: the loaders run two stages ahead, and the buffer they fill was read until the
+//     previous chunk's last tap) + the 3-slot weight ring = 158 KB.  The loaders SPECIALISE: waves 4-5 stream nothing but weight
+//     tiles (L2-resident: every CU of the grid reads the same 1.8 MB), waves 6-7 nothing but image pieces (HBM / Infinity Cache) --
+//     vmcnt retires in order, and a weight tile must not wait behind an image piece nobody needs before the next chunk.
+// All waves of a workgroup share one register allocation: 512 threads = two waves per SIMD = 256 registers; with accumulation
+// registers in use hipcc splits them 128 | 128, so 128 accumulators live in "a" registers, 32 in "v" beside 52 fragment registers.
 #include <type_traits>
 #include "gemm.h"
 #include "gemm_epi.h"
@@ -37,55 +56,83 @@
 namespace cl {
 namespace {
 
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
-
 template <int I, int N, typename F> __device__ __forceinline__ void w4_for(F&& f) {
   if constexpr (I < N) { f(std::integral_constant<int, I>{}); w4_for<I + 1, N>(f); }
 }
 template <int OFF> __device__ __forceinline__ void w4_rd128(u32x4_t& v, uint32_t addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
 }
-// c += a . b; every operand placement is explicit: fragments "v", accumulators "a" -- except the fifth 32-column block's, which
-// live in architectural registers ("v"): with accumulation registers in use hipcc (ROCm 7.2) splits a 256-register budget
-// 128 | 128, so 160 accumulators cannot all be "a" (268 spills), while 128 "a" + 32 "v" + 56 fragment registers fit.
-// (The compiler pads nothing around an asm MFMA: the stream below never reads an accumulator, and the epilogue drains first.)
-template <bool AG> __device__ __forceinline__ void w4_mfma(f32x16_t& c, const u32x4_t& a, const u32x4_t& b) {
-  if constexpr (AG) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+// c += a . b (the compiler pads nothing around an asm MFMA: the stream never reads an accumulator, the epilogue drains first)
+template <bool AG> __device__ __forceinline__ void w4_mfma(f32x4_t& c, const u32x4_t& a, const u32x4_t& b) {
+  if constexpr (AG) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 template <int N> __device__ __forceinline__ void w4_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void w4_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-// wait states around the asm MFMAs that the compiler does not know about: after the v_accvgpr_write of the zero fill (SHORT),
-// and 16 passes after the last MFMA before anything else reads its result
-template <bool SHORT, bool AG> __device__ __forceinline__ void w4_pad(f32x16_t& a, f32x16_t& b) {
-  if constexpr (SHORT) { if constexpr (AG) asm volatile("s_nop 7" : "+a"(a), "+a"(b)); else asm volatile("s_nop 7" : "+v"(a), "+v"(b)); }
-  else { if constexpr (AG) asm volatile("s_nop 15\n\ts_nop 15" : "+a"(a), "+a"(b)); else asm volatile("s_nop 15\n\ts_nop 15" : "+v"(a), "+v"(b)); }
+// s_waitcnt vmcnt(n) for a run-time n (the count is an instruction immediate)
+__device__ __forceinline__ void w4_vm_rt(int n) {
+  switch (n) {
+#define VMW(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    VMW(0) VMW(1) VMW(2) VMW(3) VMW(4) VMW(5) VMW(6) VMW(7) VMW(8) VMW(9) VMW(10) VMW(11) VMW(12) VMW(13) VMW(14) VMW(15) VMW(16)
+    VMW(17) VMW(18) VMW(19) VMW(20) VMW(21) VMW(22) VMW(23) VMW(24) VMW(25) VMW(26) VMW(27) VMW(28) VMW(29) VMW(30) VMW(31) VMW(32)
+#undef VMW
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+}
+template <int N> __device__ __forceinline__ void w4_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+// wait states around the asm MFMAs: behind the v_accvgpr_write of the zero fill (SHORT), and before anything reads a result
+template <bool SHORT, bool AG> __device__ __forceinline__ void w4_pad(f32x4_t& a, f32x4_t& b, f32x4_t& c, f32x4_t& d) {
+  if constexpr (SHORT) {
+    if constexpr (AG) asm volatile("s_nop 7" : "+a"(a), "+a"(b), "+a"(c), "+a"(d)); else asm volatile("s_nop 7" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  } else {
+    if constexpr (AG) asm volatile("s_nop 15" : "+a"(a), "+a"(b), "+a"(c), "+a"(d)); else asm volatile("s_nop 15" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  }
 }
 
-enum { W4_LINEAR = 0, W4_CONV_S1 = 1, W4_CONV_ANY = 2 };
+enum { W4_LINEAR = 0, W4_CONV_S1 = 1, W4_CONV_ANY = 2, W4_CONV_HALO = 3 };
 
-// Issue plans of the fragment reads: the gap (= behind MFMA g) that read position ps goes out in, per k-step kind.
-//   kind 0 (k-steps 0, 1)  W0 X0 | X1 | W1 | - | W2 | - | W3 ...      kind 1 (k-step 2)  two per gap from gap 0
-//   kind 2 (k-step 3)      kind 0 pushed back by one gap              kinds 3 / 4 (SCHED 0)  RPG per gap from gap 1 / 0
-template <int NF, int RPG = 2> constexpr int w4_gap_of(int kind, int ps) {
-  if (kind == 1) return ps / 2;
-  if (kind == 3) return 1 + ps / RPG;
-  if (kind == 4) return ps / RPG;
-  const int g = ps <= 1 ? 0 : (ps == 2 ? 1 : 2 * (ps - 2));
-  return kind == 2 ? (g == 0 ? 1 : (g < 4 ? g + 1 : g)) : g;
-}
-// reads of plan `kind` that are issued before MFMA m (i.e. in gaps < m)
-template <int NF> constexpr int w4_issued_before(int kind, int m) {
+// ---- the consumers' LDS issue order, replayed at compile time.  Per stage: groups g = 0 .. G2-1 (G2 = 2 NW); behind group g go out
+//   W[g + R]                 (fragment index continues into the next stage: g + R >= G2 reads stage s+1, k-half 0)
+//   X(k-half 1, i = g)       for g < 4
+//   X(next stage, k-half 0)  two behind group GB + 1, two behind GB + 2          (GB = G2 - R - 1 carries B_raw)
+// Group g needs W[g] (+ the four X of its k-half at g = 0 and g = NW); LDS returns in order, so it may run when at most the
+// reads issued BEHIND the last one it needs are outstanding.
+template <int NW> struct W4Sched { int allow[2 * NW]; };
+template <int NW> constexpr W4Sched<NW> w4_sched() {
+  constexpr int G2 = 2 * NW, R = NW / 2, GB = G2 - R - 1;
+  int seq[3 * (G2 * 4)] = {};          // > 0: a read id, < 0: group marker -(1000 S + g) - 1
   int n = 0;
-  for (int ps = 0; ps < 2 + NF; ++ps) n += w4_gap_of<NF>(kind, ps) < m ? 1 : 0;
-  return n;
+  for (int S = 0; S < 3; ++S)
+    for (int g = 0; g < G2; ++g) {
+      seq[n++] = -(1000 * S + g) - 1;
+      const int k = g + R;
+      seq[n++] = k < G2 ? 1000 * S + k + 1 : 1000 * (S + 1) + (k - G2) + 1;                 // W id: 1000 S + k + 1
+      if (g < 4) seq[n++] = 1000 * S + 200 + g + 1;                                          // X(k-half 1, g)
+      if (g == GB + 1) { seq[n++] = 1000 * (S + 1) + 100 + 0 + 1; seq[n++] = 1000 * (S + 1) + 100 + 1 + 1; }
+      if (g == GB + 2) { seq[n++] = 1000 * (S + 1) + 100 + 2 + 1; seq[n++] = 1000 * (S + 1) + 100 + 3 + 1; }
+    }
+  W4Sched<NW> r{};
+  for (int g = 0; g < G2; ++g) {       // stage S = 1: its first reads went out in stage 0's tail (the steady state)
+    int pg = -1, last = -1;
+    for (int i = 0; i < n; ++i) {
+      if (seq[i] == -(1000 + g) - 1) pg = i;
+      bool need = seq[i] == 1000 + g + 1;
+      if (g == 0) for (int x = 0; x < 4; ++x) need = need || seq[i] == 1000 + 100 + x + 1;
+      if (g == NW) for (int x = 0; x < 4; ++x) need = need || seq[i] == 1000 + 200 + x + 1;
+      if (need && pg < 0) last = i;     // (needed reads sit before the group marker)
+    }
+    int cnt = 0;
+    for (int i = last + 1; i < pg; ++i) cnt += seq[i] > 0 ? 1 : 0;
+    r.allow[g] = cnt > 15 ? 15 : cnt;
+  }
+  return r;
 }
+template <int NW, int g> constexpr int w4_allow() { return w4_sched<NW>().allow[g]; }
 
 // ABL (template parameter; non-zero instances exist in probe builds only, tools/probe_gemm.hip -DW4_PROBE): bit 0 = consumers skip
-// their fragment reads, bit 1 = loaders skip their DMA, bit 2 = no stores -- wrong results by construction, they price the ingredients
+// their fragment reads, bit 1 = loaders skip their DMA, bit 2 = no stores, bit 5 = no MFMAs -- wrong results by construction
 #define W4_ABL(bit) ((ABL & (bit)) != 0)
 #ifdef W4_PROBE
-int g_w4_abl_host = 0, g_w4_sched_host = 1;
+int g_w4_abl_host = 0, g_w4_halo_host = 1;
 // wave 0 of every workgroup stores s_memtime at four points of its tile: entry | stage 0 landed | main loop done | stores retired
 __device__ unsigned long long* g_w4_timing = nullptr;
 #define W4_STAMP(i) do { if (g_w4_timing && threadIdx.x == 0) g_w4_timing[(long)blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -94,21 +141,29 @@ __device__ unsigned long long* g_w4_timing = nullptr;
 #endif
 
 constexpr int W4_BM = 256, W4_NC = 4, W4_NL = 4, W4_R = 3;
+constexpr int W4_HROWS = 392;                     // HALO: pixel rows of one image buffer (>= (R + 2) (W + 1) + 1, a multiple of 8)
+constexpr int W4_XJI = 25;                        // HALO: image DMA instructions per image loader and chunk (2 x 25 >= 392 / 8)
+// HALO: an image loader's pieces [lo, hi) of the next chunk ride on the stage with tap t: taps 2 .. 8 carry 4 4 4 4 4 4 1
+__host__ __device__ constexpr int w4_pieces_lo(int t) { return t < 2 ? 0 : 4 * (t - 2); }
+__host__ __device__ constexpr int w4_pieces_hi(int t) { return t < 2 ? 0 : (4 * (t - 2) + 4 > W4_XJI ? W4_XJI : 4 * (t - 2) + 4); }
 
-// NF: 32-column fragment blocks per tile row (BN = 32 NF: 5 -> 160, 4 -> 128).  RPG: fragment reads per MFMA gap.
-template <int NF, int MODE, int SCHED, int ABL = 0>
+// NW: 16-column fragment blocks per tile row (BN = 16 NW: 10 -> 160, 8 -> 128).
+template <int NW, int MODE, int ABL = 0>
 __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParams p, int tiles_m, int tiles_n,
                                                                       float* __restrict__ slab) {
   typedef bf16_t T;
-  constexpr int BN = 32 * NF;
+  constexpr bool HALO = MODE == W4_CONV_HALO;
+  constexpr int BN = 16 * NW, G2 = 2 * NW, R = NW / 2, GB = G2 - R - 1;
   constexpr int XI = W4_BM / 8, WI = BN / 8;            // DMA instructions (8 rows x 128 B) per stage: X rows, W rows
   constexpr int XJ = XI / W4_NL, WJ = WI / W4_NL;       // ... per loader wave
-  constexpr int G = XJ + WJ;
-  constexpr int GA = W4_ABL(2) ? 0 : (W4_ABL(8) ? 0 : XJ) + (W4_ABL(16) ? 0 : WJ);   // (G in every product build)
-  constexpr int SLOT = (XI + WI) * 1024;
-  constexpr int RPG = 2;
-  constexpr int NFR = 2 + NF;                           // fragments per k-step and consumer: X0 X1 W0 .. W(NF-1)
-  static_assert(WI % W4_NL == 0, "every loader issues the same number of DMA instructions (counted vmcnt)");
+  constexpr int G = HALO ? WJ : XJ + WJ;                // per loader and stage (HALO: + the image pieces riding on the stage)
+  constexpr int GA = W4_ABL(2) ? 0 : G;
+  constexpr int XBUF = W4_HROWS * 128;                  // HALO: one image buffer
+  constexpr int SLOT = HALO ? WI * 1024 : (XI + WI) * 1024;
+  constexpr int RING0 = HALO ? 2 * XBUF : 0;            // byte offset of the ring
+  constexpr int WOFF = HALO ? 0 : XI * 1024;            // W rows inside a slot
+  static_assert(WI % W4_NL == 0 && G2 % R == 0 && NW % 2 == 0, "uniform DMA counts; the W ring is periodic per stage");
+  static_assert(RING0 + W4_R * SLOT <= 160 * 1024, "LDS");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -126,7 +181,7 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
   }
   const int m0 = (pid / tiles_n) * W4_BM, n0 = (pid % tiles_n) * BN;
 
-  const int cpt = p.K1 / 64;  // stages per tap
+  const int cpt = p.K1 / 64;  // 64-channel chunks (= stages per tap)
   const int ks1 = (MODE == W4_LINEAR ? 1 : 9) * cpt;
   const int ks2 = (MODE == W4_LINEAR) ? p.K2 / 64 : 0;
   int kbeg = 0, kend = ks1 + ks2;
@@ -136,11 +191,122 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
     kend = min(kend, kbeg + per);
   }
   const int total = kend - kbeg;                            // >= 1 (launcher)
+  // HALO: stage index k = 9 chunk + tap; the tile's pixels are rows [py0, py0 + 256 / W) of image pb, all W columns
+  const int Wp = HALO ? p.Win + 1 : 0;                      // pixel rows per image row of the LDS image (W pixels + one zero column)
+  const int cc0 = HALO ? kbeg / 9 : 0, tap0 = HALO ? kbeg - cc0 * 9 : 0;
 
   if (wave >= W4_NC) {
     // =================================================================================== loader
     const int lw = wave - W4_NC;
     const int lrow = lane >> 3, lslot = lane & 7;
+    const char* zpage = (const char*)p.zero_page + lslot * 16;
+    if constexpr (HALO) {
+      // ---- HALO: waves 4-5 stream the weight tiles, waves 6-7 the image pieces (see the top)
+      if (lw < 2) {
+        constexpr int WJ2 = WI / 2;                           // weight DMA instructions per stage and weight loader
+        const char* pw[WJ2];
+#pragma unroll
+        for (int j = 0; j < WJ2; ++j) {
+          const int inst = j * 2 + lw;
+          const int chunk = (lslot ^ (((inst & 1) << 2) | (lrow >> 1))) * 16;
+          int n = n0 + inst * 8 + lrow;
+          n = min(n, p.N - 1);
+          pw[j] = (const char*)p.W1 + ((long)n * p.ldw1) * sizeof(T) + chunk;      // + (tap C + 64 chunk) 2 per stage
+        }
+        int tap = tap0, cc = cc0;
+        auto issue_w = [&](int slot) {
+          char* Ws = smem + RING0 + slot * SLOT;
+          const long koff = ((long)tap * p.K1 + (long)cc * 64) * sizeof(T);        // this stage's 64 K columns of W
+          if constexpr (!W4_ABL(2)) {
+#pragma unroll
+            for (int j = 0; j < WJ2; ++j) glds16(pw[j] + koff, Ws + (j * 2 + lw) * 1024);
+          }
+          if (++tap == 9) { tap = 0; ++cc; }
+        };
+        constexpr int GW = W4_ABL(2) ? 0 : WJ2;
+        issue_w(0);
+        if (total > 1) { issue_w(1); w4_vm<GW>(); } else { w4_vm<0>(); }
+        __builtin_amdgcn_s_barrier();                         // B_raw(0)
+        __builtin_amdgcn_sched_barrier(0);
+        int slot2 = 2;
+        for (int s = 0; s < total; ++s) {
+          __builtin_amdgcn_s_barrier();                       // B_war(s-1): the slot of stage s-1 is free
+          __builtin_amdgcn_sched_barrier(0);
+          if (s + 2 < total) { issue_w(slot2); w4_vm<GW>(); } else { w4_vm<0>(); }
+          __builtin_amdgcn_s_barrier();                       // B_raw(s+1)
+          __builtin_amdgcn_sched_barrier(0);
+          slot2 = (slot2 == W4_R - 1) ? 0 : slot2 + 1;
+        }
+        return;
+      }
+      // image loader il = 0 / 1: pieces il, il + 2, ... of every image (W4_XJI each; past the image: the last piece again)
+      const int il = lw - 2;
+      const int hw = p.Hin * p.Win;
+      const int pb = m0 / hw, py0 = (m0 - pb * hw) / p.Win, rows = W4_BM / p.Win;
+      const int nrow = (rows + 2) * Wp + 1;
+      const int ninst = (nrow + 7) / 8;
+      // piece j of this loader = image rows 8 (2 j + il) + lrow: (hy, hx) walk on by 16 rows per piece (W + 1 >= 17: one wrap at most).
+      // The FIRST image is brought by the consumer waves (they idle until stage 0 has landed): pointers start at chunk cc0 + 1.
+      const char* pa[W4_XJI];
+      {
+        int hr = il * 8 + lrow;
+        int hy = hr / Wp, hx = hr - hy * Wp;
+#pragma unroll
+        for (int j = 0; j < W4_XJI; ++j) {
+          const int inst = j * 2 + il;
+          const int chunk = (lslot ^ (((inst & 1) << 2) | (lrow >> 1))) * 16;
+          const int y = py0 - 1 + hy, x = hx - 1;        // (hx = 0: the zero column)
+          const bool ok = hr < nrow && (unsigned)y < (unsigned)p.Hin && (unsigned)x < (unsigned)p.Win;
+          pa[j] = ok ? (const char*)p.A1 + ((((long)pb * p.Hin + y) * p.Win + x) * p.lda1) * sizeof(T) + chunk + (long)(cc0 + 1) * 128
+                     : zpage + (long)(cc0 + 1) * 128;
+          hr += 16; hx += 16;
+          if (hx >= Wp) { hx -= Wp; ++hy; }
+        }
+      }
+      // pieces [lo, hi) of the NEXT image into buffer `buf` (pieces past the image do not exist: this loader only ever waits for
+      // everything); a piece's pointer then moves on a chunk
+      auto issue_image = [&](int buf, int lo, int hi) {
+        char* Xb = smem + buf * XBUF;
+#pragma unroll
+        for (int j = 0; j < W4_XJI; ++j)
+          if (j >= lo && j < hi) {
+            const int inst = j * 2 + il;
+            if constexpr (!W4_ABL(2)) { if (inst < ninst) glds16(pa[j], Xb + inst * 1024); }
+            pa[j] += 128;
+          }
+      };
+      // The pieces of chunk c+1 ride on the steps that issue taps 2 .. 8 of chunk c (the loaders run two stages ahead; the buffer
+      // was read until chunk c-1's last tap); the first step of a split-K range also carries what the taps before it would have
+      // (nothing has been read yet).  They must have landed at the B_raw of chunk c+1's first stage: the step that issues tap 1 of
+      // chunk c+1 (two stages ahead) waits for everything.
+      int tap = tap0, cc = cc0, ibuf = 0;
+      bool first = true;
+      auto step = [&]() {           // the step that (on the weight side) issues the stage (cc, tap)
+        if (cc + 1 < cpt) {
+          const int lo = first ? 0 : w4_pieces_lo(tap), hi = w4_pieces_hi(tap);
+          if (hi > lo) issue_image(ibuf ^ 1, lo, hi);
+        }
+        first = false;
+        if (++tap == 9) { tap = 0; ++cc; ibuf ^= 1; }
+      };
+      step();
+      if (total > 1) step();
+      w4_vm_rt(0);                                            // (prologue: everything, the next image's first pieces included)
+      __builtin_amdgcn_s_barrier();                           // B_raw(0)
+      __builtin_amdgcn_sched_barrier(0);
+      for (int s = 0; s < total; ++s) {
+        __builtin_amdgcn_s_barrier();                         // B_war(s-1)
+        __builtin_amdgcn_sched_barrier(0);
+        // stage s+1 is read after B_raw(s+1): if it is a chunk's first stage its image must be complete (tap == 1 here <=> the
+        // stage issued by this step, s+2, has tap 1 <=> stage s+1 has tap 0)
+        const bool chunk_start_next = tap == 1;
+        if (s + 2 < total) step();
+        if (chunk_start_next) w4_vm<0>();
+        __builtin_amdgcn_s_barrier();                         // B_raw(s+1)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      return;
+    } else {
     const char* pa[XJ];            // LINEAR: running pointer.  CONV: centre pixel (S1) / base (ANY)
     const char* a2[XJ];
     uint32_t vmask[XJ];            // CONV_S1: bit t = tap t reads inside the image
@@ -189,9 +355,8 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
                   ? w2[j] + (long)(kbeg - ks1) * 128
                   : (const char*)p.W1 + ((long)n * p.ldw1) * sizeof(T) + chunk + (long)kbeg * 128;
     }
-    const char* zpage = (const char*)p.zero_page + lslot * 16;
 
-    // wave-uniform walk over (tap, channel chunk) for the conv modes
+    // wave-uniform walk over (tap, channel chunk)
     int kt_next = kbeg;
     int tap = (MODE == W4_LINEAR) ? 0 : kbeg / cpt;
     int cc = (MODE == W4_LINEAR) ? 0 : kbeg - tap * cpt;
@@ -206,10 +371,9 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
       for (int j = 0; j < XJ; ++j)   // a split-K workgroup may start in the middle of a tap
         cur[j] = ((vmask[j] >> tap) & 1u) ? pa[j] + tapoff + (long)cc * 128 : zpage + (long)cc * 128;
     }
-
     auto issue = [&](int slot) {
-      char* Xs = smem + slot * SLOT;
-      char* Ws = Xs + XI * 1024;
+      char* Xs = smem + RING0 + slot * SLOT;
+      char* Ws = Xs + WOFF;
       if constexpr (W4_ABL(2)) { ++kt_next; return; }
       if constexpr (MODE == W4_LINEAR) {
         if (ks2 && kt_next == ks1) {   // switch to the second K segment (LoRA up-projection)
@@ -219,7 +383,7 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
           for (int j = 0; j < WJ; ++j) pw[j] = w2[j];
         }
 #pragma unroll
-        for (int j = 0; j < XJ; ++j) { if constexpr (!W4_ABL(8)) glds16(pa[j], Xs + (j * W4_NL + lw) * 1024); pa[j] += 128; }
+        for (int j = 0; j < XJ; ++j) { glds16(pa[j], Xs + (j * W4_NL + lw) * 1024); pa[j] += 128; }
       } else if constexpr (MODE == W4_CONV_S1) {
         // cur[j] walks the channel chunks of the current tap (+128 B per stage); lanes whose tap falls outside the image walk
         // the zero page instead (at least (K1 / 64 + 1) * 128 bytes long); the select against the 9-bit mask happens only when
@@ -229,7 +393,7 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
           for (int j = 0; j < XJ; ++j) cur[j] = ((vmask[j] >> tap) & 1u) ? pa[j] + tapoff : zpage;
         }
 #pragma unroll
-        for (int j = 0; j < XJ; ++j) { if constexpr (!W4_ABL(8)) glds16(cur[j], Xs + (j * W4_NL + lw) * 1024); cur[j] += 128; }
+        for (int j = 0; j < XJ; ++j) { glds16(cur[j], Xs + (j * W4_NL + lw) * 1024); cur[j] += 128; }
         const bool wrap = cc + 1 == cpt;
         cc = wrap ? 0 : cc + 1;
         tap += wrap ? 1 : 0;
@@ -259,174 +423,237 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
         if (++cc == cpt) { cc = 0; ++tap; }
       }
 #pragma unroll
-      for (int j = 0; j < WJ; ++j) { if constexpr (!W4_ABL(16)) glds16(pw[j], Ws + (j * W4_NL + lw) * 1024); pw[j] += 128; }
+      for (int j = 0; j < WJ; ++j) { glds16(pw[j], Ws + (j * W4_NL + lw) * 1024); pw[j] += 128; }
       ++kt_next;
     };
 
     issue(0);
     if (total > 1) { issue(1); w4_vm<GA>(); } else { w4_vm<0>(); }
-    __builtin_amdgcn_s_barrier();                             // B(0)
+    __builtin_amdgcn_s_barrier();                             // B_raw(0)
     __builtin_amdgcn_sched_barrier(0);
     int slot2 = 2;
-    for (int s = 0; s < total; ++s) {                         // (B(total) only balances the consumers' uniform stage body)
+    for (int s = 0; s < total; ++s) {
+      __builtin_amdgcn_s_barrier();                           // B_war(s-1): the slot of stage s-1 is free
+      __builtin_amdgcn_sched_barrier(0);
       if (s + 2 < total) { issue(slot2); w4_vm<GA>(); } else { w4_vm<0>(); }
-      __builtin_amdgcn_s_barrier();                           // B(s+1)
+      __builtin_amdgcn_s_barrier();                           // B_raw(s+1)
       __builtin_amdgcn_sched_barrier(0);
       slot2 = (slot2 == W4_R - 1) ? 0 : slot2 + 1;
     }
     return;
+    }
   }
 
   // ===================================================================================== consumer
-  const int l31 = lane & 31, hi = lane >> 5;
+  const int lr = lane & 15, lg = lane >> 4;
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  // fragment (rows 32 b + l31 of a tile, k-step j of the stage: logical 16-byte chunk 2 j + hi) -> slot (2 j) ^ (hi ^ swz(l31))
-  uint32_t xa[4], wa[4];
+  // fragment (16 rows, k-half h of the stage: logical 16-byte chunk lg + 4 h) -> slot (lg ^ swz(row)) ^ 4 h; swz(row) = (row >> 1) & 7
+  uint32_t wa[2], xa[HALO ? 4 : 2];
+  uint32_t xh0[4];                              // HALO: centre-tap image row of this lane's pixel, per X fragment
+  const int wsh = HALO ? 31 - __builtin_clz(p.Win) : 0;
   {
-    const int t = hi ^ ((l31 >> 1) & 7);
+    const uint32_t fo = lr * 128 + ((lg ^ ((lr >> 1) & 7)) * 16);
+    wa[0] = lds0 + RING0 + WOFF + fo; wa[1] = wa[0] ^ 64u;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      xa[j] = lds0 + (wave * 64 + l31) * 128 + (((2 * j) ^ t) * 16);
-      wa[j] = lds0 + XI * 1024 + l31 * 128 + (((2 * j) ^ t) * 16);
+    for (int i = 0; i < 4; ++i) xh0[i] = 0;
+    if constexpr (!HALO) { xa[0] = lds0 + (wave * 64) * 128 + fo; xa[1] = xa[0] ^ 64u; }
+    else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int px = wave * 64 + 16 * i + lr;                        // tile-local pixel: image row px / W, column px % W
+        const int yl = px >> wsh, xl = px & (p.Win - 1);               // (W is a power of two: w4_halo_ok)
+        xh0[i] = (yl + 1) * Wp + xl + 1;
+      }
     }
   }
-  f32x16_t acc[NF][2];
+  int ctap = tap0, cbuf = 0;                    // HALO: tap / image buffer of the stage whose X addresses are in xa
+  auto halo_addr = [&](int tp, int buf) {
+    if constexpr (HALO) {
+      const int ky = (tp * 11) >> 5, kx = tp - 3 * ky;
+      const int toff = (ky - 1) * Wp + (kx - 1);
 #pragma unroll
-  for (int f = 0; f < NF; ++f)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[f][i][r] = 0.f;
-  u32x4_t F[2][NFR];
-
-  // Fragment reads are issued in the order the MFMAs need them -- position 0 1 2 3 4 .. = W0 X0 X1 W1 W2 .. (MFMA m multiplies
-  // W[m / 2] by X[m % 2]) -- and LDS returns in order, so "fragment at position q has landed" is lgkmcnt(reads issued after it).
-  auto read_pos = [&](auto Bc, auto Jc, auto Pc) {
-    constexpr int b = decltype(Bc)::value, j = decltype(Jc)::value, ps = decltype(Pc)::value;
-    constexpr int q = ps == 0 ? 2 : (ps <= 2 ? ps - 1 : ps);         // index into F[b]: X0 X1 W0 W1 ..
-    if constexpr (W4_ABL(1)) return;
-    else if constexpr (q < 2) w4_rd128<q * 4096>(F[b][q], xa[j]);
-    else w4_rd128<(q - 2) * 4096>(F[b][q], wa[j]);
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t h = xh0[i] + toff;
+        xa[i] = lds0 + buf * XBUF + h * 128 + ((lg ^ ((h >> 1) & 7)) * 16);
+      }
+    }
   };
+  halo_addr(ctap, cbuf);
+
+  f32x4_t acc[NW][4];
+#pragma unroll
+  for (int f = 0; f < NW; ++f)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[f][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  u32x4_t Xf[2][4], Wr[R];
+
+  auto read_w = [&](auto Kc) {                  // W fragment k (0 .. G2-1 of the stage whose addresses are in wa) -> ring slot k % R
+    constexpr int k = decltype(Kc)::value;
+    if constexpr (W4_ABL(1)) return;
+    else w4_rd128<(k % NW) * 2048>(Wr[k % R], wa[k / NW]);
+  };
+  auto read_x = [&](auto Hc, auto Ic) {         // X fragment i of k-half h
+    constexpr int h = decltype(Hc)::value, i = decltype(Ic)::value;
+    if constexpr (W4_ABL(1)) return;
+    else if constexpr (HALO) {
+      if constexpr (h == 0) w4_rd128<0>(Xf[0][i], xa[i]);
+      else { const uint32_t a1 = xa[i] ^ 64u; w4_rd128<0>(Xf[1][i], a1); }
+    } else {
+      w4_rd128<i * 2048>(Xf[h][i], xa[h]);
+    }
+  };
+  using H0 = std::integral_constant<int, 0>;
+  using H1 = std::integral_constant<int, 1>;
 
   W4_STAMP(0);
-  __builtin_amdgcn_s_barrier();                               // B(0): stage 0 has landed
+  if constexpr (HALO) {
+    // the FIRST image: the four consumer waves have nothing to do until stage 0 has landed and bring it themselves (pieces
+    // wave, wave + 4, ...: 13 each cover the 49) -- the image loaders start with the next chunk's
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const char* zpage = (const char*)p.zero_page + lslot * 16;
+    const int hw = p.Hin * p.Win;
+    const int pb = m0 / hw, py0 = (m0 - pb * hw) >> wsh, rows = W4_BM >> wsh;
+    const int nrow = (rows + 2) * Wp + 1, ninst = (nrow + 7) / 8;
+    int hr = wave * 8 + lrow;
+    int hy = hr / Wp, hx = hr - hy * Wp;
+#pragma unroll
+    for (int j = 0; j < 13; ++j) {
+      const int inst = j * 4 + wave;
+      const int chunk = (lslot ^ (((inst & 1) << 2) | (lrow >> 1))) * 16;
+      const int y = py0 - 1 + hy, x = hx - 1;
+      const bool ok = hr < nrow && (unsigned)y < (unsigned)p.Hin && (unsigned)x < (unsigned)p.Win;
+      const char* src = ok ? (const char*)p.A1 + ((((long)pb * p.Hin + y) * p.Win + x) * p.lda1) * sizeof(T) + chunk + (long)cc0 * 128
+                           : zpage + (long)cc0 * 128;
+      if constexpr (!W4_ABL(2)) { if (inst < ninst) glds16(src, smem + inst * 1024); }
+      hr += 32; hx += 32;
+      if (hx >= Wp) { hx -= Wp; ++hy; }
+      if (hx >= Wp) { hx -= Wp; ++hy; }
+    }
+    w4_vm<0>();
+  }
+  __builtin_amdgcn_s_barrier();                               // B_raw(0): stage 0 (and the first image) has landed
   __builtin_amdgcn_sched_barrier(0);
   W4_STAMP(1);
-  w4_for<0, NFR>([&](auto Pc) { read_pos(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, Pc); });
+  // the first reads, in the order the steady state issues them at the end of a stage (the counts of w4_sched assume it)
+  w4_for<0, R>([&](auto Kc) {
+    constexpr int k = decltype(Kc)::value;
+    read_w(Kc);
+    if constexpr (k == 0) { read_x(H0{}, std::integral_constant<int, 0>{}); read_x(H0{}, std::integral_constant<int, 1>{}); }
+    if constexpr (k == 1) { read_x(H0{}, std::integral_constant<int, 2>{}); read_x(H0{}, std::integral_constant<int, 3>{}); }
+  });
   // (the accumulators were just written by v_accvgpr_write: wait states before the first MFMA reads them as SrcC)
-  w4_for<0, NF>([&](auto Fc) { constexpr int f = decltype(Fc)::value; w4_pad<true, (f < 4)>(acc[f][0], acc[f][1]); });
-  w4_lgkm0();
+  w4_for<0, NW>([&](auto Fc) { constexpr int f = decltype(Fc)::value; w4_pad<true, (f < 8)>(acc[f][0], acc[f][1], acc[f][2], acc[f][3]); });
   __builtin_amdgcn_sched_barrier(0);
 
-  int slot = 0;
-  // One stage = four k-steps of 2 NF MFMAs.  k-step j multiplies the fragments in F[j & 1] while the reads of the next k-step fill
-  // F[(j + 1) & 1]; k-step 3 opens with B(s+1) and then reads k-step 0 of stage s+1.  The body is the same for EVERY stage: the last
-  // one passes a balancing barrier and reads a stale slot into registers nobody uses.
-  // Issue plans (gap g = behind MFMA g) per k-step kind, SCHED 1:
-  //   j = 0, 1   W0 X0 | X1 | W1 | - | W2 | - | W3 | - | W4     one k-step (~320 cycles) between a read and its MFMA
-  //   j = 2      W0 X0 | X1 W1 | W2 W3 | W4                      early: they must have retired at B(s+1) (WAR on the slot)
-  //   j = 3      - | W0 X0 | X1 | W1 | W2 | - | W3 | - | W4      gap 0 moves the eight read addresses to the next slot
-  // and the wait in front of MFMA m allows (reads issued behind the fragment it needs) outstanding.  SCHED 0: RPG reads per gap
-  // from gap 0 (1 in k-step 3) and lgkmcnt(0) at the end of every k-step.
-  auto stage = [&]() {
-    w4_for<0, 4>([&](auto Jc) {
-      constexpr int j = decltype(Jc)::value, cb = j & 1, nb = cb ^ 1, jn = (j + 1) & 3;
-      constexpr int KIND = (SCHED == 0) ? (j == 3 ? 3 : 4) : (j < 2 ? 0 : (j == 2 ? 1 : 2));       // plan of THIS k-step's reads
-      if constexpr (j == 3) {
-        if constexpr (SCHED != 0) w4_lgkm0();                 // this stage's last reads (issued early in k-step 2) have retired
-        __builtin_amdgcn_s_barrier();                         // B(s+1)
+  // (slot / tap bookkeeping is done by the caller and passed BY VALUE: loop-carried integers captured by reference and updated inside
+  // the unrolled body ended up in scratch memory)
+  auto stage = [&](int slot, int ntap, int nbuf) {
+    w4_for<0, G2>([&](auto Gc) {
+      constexpr int g = decltype(Gc)::value, h = g / NW, f = g % NW;
+      if constexpr (!W4_ABL(1)) w4_lgkm<w4_allow<NW, g>()>();
+      w4_for<0, 4>([&](auto Ic) {
+        constexpr int i = decltype(Ic)::value;
+        if constexpr (!W4_ABL(32)) w4_mfma<(f < 8)>(acc[f][i], Wr[g % R], Xf[h][i]);
+      });
+      if constexpr (g == 0) {
+        __builtin_amdgcn_s_barrier();                         // B_war(s-1)
         __builtin_amdgcn_sched_barrier(0);
       }
-      w4_for<0, 2 * NF>([&](auto Mc) {
-        constexpr int m = decltype(Mc)::value;
-        if constexpr (SCHED != 0 && j != 3 && (m < 2 || (m & 1) == 0)) {
-          // fragments at positions <= need(m) have landed when at most the reads behind them are outstanding
-          constexpr int need = m == 0 ? 1 : (m == 1 ? 2 : (m >> 1) + 2);
-          constexpr int allow = (NFR - 1 - need) + w4_issued_before<NF>(KIND, m);
-          asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(allow) : "memory");
-        }
-        if constexpr (!W4_ABL(32)) w4_mfma<((m >> 1) < 4)>(acc[m >> 1][m & 1], F[cb][2 + (m >> 1)], F[cb][m & 1]);
-        if constexpr (j == 3 && m == 0) {
-          __builtin_amdgcn_sched_barrier(0);
-          const int d = (slot == W4_R - 1) ? -(W4_R - 1) * SLOT : SLOT;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) { xa[k] += d; wa[k] += d; }
-          slot = (slot == W4_R - 1) ? 0 : slot + 1;
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        w4_for<0, NFR>([&](auto Pc) {
-          if constexpr (w4_gap_of<NF, RPG>(KIND, decltype(Pc)::value) == m)
-            read_pos(std::integral_constant<int, nb>{}, std::integral_constant<int, jn>{}, Pc);
-        });
-      });
-      if constexpr (SCHED == 0) w4_lgkm0();                   // the next k-step's fragments (for j = 2: this stage's last reads)
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (g + R < G2) read_w(std::integral_constant<int, g + R>{});
+      if constexpr (g == GB) {
+        // every read of this stage is out: move to the next slot (and, HALO, to the next tap / image) -- the reads below
+        // belong to stage s+1 and follow B_raw(s+1)
+        __builtin_amdgcn_sched_barrier(0);
+        const int d = (slot == W4_R - 1) ? -(W4_R - 1) * SLOT : SLOT;
+        wa[0] += d; wa[1] += d;
+        if constexpr (!HALO) { xa[0] += d; xa[1] += d; }
+        else halo_addr(ntap, nbuf);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                         // B_raw(s+1)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (g + R >= G2) read_w(std::integral_constant<int, g + R - G2>{});
+      if constexpr (g < 4) read_x(H1{}, std::integral_constant<int, g>{});
+      if constexpr (g == GB + 1) { read_x(H0{}, std::integral_constant<int, 0>{}); read_x(H0{}, std::integral_constant<int, 1>{}); }
+      if constexpr (g == GB + 2) { read_x(H0{}, std::integral_constant<int, 2>{}); read_x(H0{}, std::integral_constant<int, 3>{}); }
     });
   };
-  for (int s = 0; s < total; ++s) stage();
-  w4_lgkm0();                                                 // (the stale reads of the last k-step: nothing may be in flight past here)
+  {
+    int slot = 0;                                             // slot of the stage being read
+    for (int s = 0; s < total; ++s) {
+      const bool twrap = ctap == 8;
+      const int ntap = twrap ? 0 : ctap + 1, nbuf = twrap ? (cbuf ^ 1) : cbuf;
+      stage(slot, ntap, nbuf);
+      slot = slot == W4_R - 1 ? 0 : slot + 1; ctap = ntap; cbuf = nbuf;
+    }
+  }
+  w4_lgkm<0>();                                               // (the stale reads behind the last stage: nothing in flight past here)
   __builtin_amdgcn_sched_barrier(0);
   W4_STAMP(2);
 
-  // ---- epilogue: the MFMA results may be read 16 passes after the last issue; nothing padded that for an asm MFMA
-  w4_for<0, NF>([&](auto Fc) { constexpr int f = decltype(Fc)::value; w4_pad<false, (f < 4)>(acc[f][0], acc[f][1]); });
-  if (W4_ABL(4) || p.act == 77) return;                       // act 77: timing probe only (skip the stores)
+  // ---- epilogue: an MFMA result may be read 8 passes after its issue; nothing padded that for an asm MFMA
+  w4_for<0, NW>([&](auto Fc) { constexpr int f = decltype(Fc)::value; w4_pad<false, (f < 8)>(acc[f][0], acc[f][1], acc[f][2], acc[f][3]); });
+  if (W4_ABL(4) || p.act == 77) { W4_STAMP(3); return; }      // act 77: timing probe only (skip the stores)
   const EpiArgs e = epi_of(p);
-  const int row_w = m0 + wave * 64 + l31;
-  // 8 consecutive columns 16 b + 8 hi .. + 7 of the tile (b = 2 f + q) from two 4-column groups of either half-wave:
-  // v_permlane32_swap hands lanes 0-31 the partner's group 2 q, lanes 32-63 the partner's group 2 q + 1
-  auto cols8 = [&](auto Fc, auto Ic, auto Qc, float (&v)[8]) {
-    constexpr int f = decltype(Fc)::value, i = decltype(Ic)::value, q = decltype(Qc)::value;
+  const int row_w = m0 + wave * 64 + lr;
+  // Lane (m = lr, lane row lg) holds columns 4 lg + r of every 16-column block.  v_permlane16_swap of blocks (fa, fb): lane rows
+  // 0 / 2 end up with columns 0-7 / 8-15 of block fa, lane rows 1 / 3 with those of block fb -- 8 consecutive columns per lane
+  auto cols8 = [&](auto Fa, auto Fb, auto Ic, float (&v)[8]) {
+    constexpr int fa = decltype(Fa)::value, fb = decltype(Fb)::value, i = decltype(Ic)::value;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[f][i][8 * q + k]), __float_as_uint(acc[f][i][8 * q + 4 + k]),
-                                                       false, false);
-      v[k] = __uint_as_float(sw[0]); v[4 + k] = __uint_as_float(sw[1]);
+    for (int r = 0; r < 4; ++r) {
+      const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[fa][i][r]), __float_as_uint(acc[fb][i][r]), false, false);
+      v[r] = __uint_as_float(sw[0]); v[4 + r] = __uint_as_float(sw[1]);
     }
   };
   if (p.act == ACT_GEGLU && !slab) {
-    // value columns [0, 80) of the tile pair with gate columns [80, 160): 8-column block b with block b + 5, same lane
-    if constexpr (NF == 5) {
-      w4_for<0, 2>([&](auto Ic) {
+    // value columns [0, 80) of the tile pair with gate columns [80, 160): block f with block f + 5, SAME lane and register --
+    // the products are formed in the accumulator layout, then blocks (0,1) (2,3) leave as 16-byte stores and block 4 as 8-byte ones
+    if constexpr (NW == 10) {
+      w4_for<0, 4>([&](auto Ic) {
         constexpr int i = decltype(Ic)::value;
-        const int grow = row_w + 32 * i;
-        w4_for<0, 5>([&](auto Bc) {
-          constexpr int b = decltype(Bc)::value, gb = b + 5;
-          float v[8], g[8];
-          cols8(std::integral_constant<int, b / 2>{}, Ic, std::integral_constant<int, b % 2>{}, v);
-          cols8(std::integral_constant<int, gb / 2>{}, Ic, std::integral_constant<int, gb % 2>{}, g);
-          const int c0 = 16 * b + 8 * hi;
+        const int grow = row_w + 16 * i;
+        w4_for<0, 5>([&](auto Fc) {
+          constexpr int f = decltype(Fc)::value;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c = 16 * f + 4 * lg + r;
+            const float bv = e.bias ? e.bias[n0 + c] : 0.f, bg = e.bias ? e.bias[n0 + 80 + c] : 0.f;
+            acc[f][i][r] = (acc[f][i][r] + bv) * gelu_f(acc[f + 5][i][r] + bg);
+          }
+        });
+        w4_for<0, 2>([&](auto Qc) {
+          constexpr int q = decltype(Qc)::value;
+          float v[8];
+          cols8(std::integral_constant<int, 2 * q>{}, std::integral_constant<int, 2 * q + 1>{}, Ic, v);
+          const int c0 = 32 * q + 16 * (lg & 1) + 8 * (lg >> 1);
           if (grow < p.M) {
-            if (e.bias) {
-#pragma unroll
-              for (int k = 0; k < 8; ++k) { v[k] += e.bias[n0 + c0 + k]; g[k] += e.bias[n0 + 80 + c0 + k]; }
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] *= gelu_f(g[k]);
             if (p.out_f32) store8(reinterpret_cast<float*>(e.C) + (long)grow * e.ldc + n0 / 2 + c0, v);
             else store8(reinterpret_cast<T*>(e.C) + (long)grow * e.ldc + n0 / 2 + c0, v);
           }
         });
+        if (grow < p.M) {
+          float v4[4] = {acc[4][i][0], acc[4][i][1], acc[4][i][2], acc[4][i][3]};
+          const int c0 = 64 + 4 * lg;
+          if (p.out_f32) store4(reinterpret_cast<float*>(e.C) + (long)grow * e.ldc + n0 / 2 + c0, v4);
+          else store4(reinterpret_cast<T*>(e.C) + (long)grow * e.ldc + n0 / 2 + c0, v4);
+        }
       });
     }
     return;
   }
-  w4_for<0, 2>([&](auto Ic) {
+  w4_for<0, 4>([&](auto Ic) {
     constexpr int i = decltype(Ic)::value;
-    const int grow = row_w + 32 * i;
-    w4_for<0, NF>([&](auto Fc) {
-      constexpr int f = decltype(Fc)::value;
-      w4_for<0, 2>([&](auto Qc) {
-        constexpr int q = decltype(Qc)::value;
-        float v[8];
-        cols8(Fc, Ic, Qc, v);
-        const int gcol = n0 + 32 * f + 16 * q + 8 * hi;
-        if (grow < p.M && gcol < p.N) {
-          if (slab) store8(slab + ((long)zsplit * p.M + grow) * p.N + gcol, v);    // split-K partial: raw accumulators
-          else epilogue8<T>(e, v, grow, gcol);
-        }
-      });
+    const int grow = row_w + 16 * i;
+    w4_for<0, NW / 2>([&](auto Qc) {
+      constexpr int q = decltype(Qc)::value;
+      float v[8];
+      cols8(std::integral_constant<int, 2 * q>{}, std::integral_constant<int, 2 * q + 1>{}, Ic, v);
+      const int gcol = n0 + 32 * q + 16 * (lg & 1) + 8 * (lg >> 1);
+      if (grow < p.M && gcol < p.N) {
+        if (slab) store8(slab + ((long)zsplit * p.M + grow) * p.N + gcol, v);    // split-K partial: raw accumulators
+        else epilogue8<T>(e, v, grow, gcol);
+      }
     });
   });
 #ifdef W4_PROBE
@@ -435,10 +662,11 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
 #endif
 }
 
-template <int NF, int MODE, int ABL = 0, int SCHED = 1>
+template <int NW, int MODE, int ABL = 0>
 int launch_w4_mode(const GemmParams& p0, hipStream_t stream) {
-  constexpr int BN = 32 * NF, SMEM = W4_R * (W4_BM / 8 + BN / 8) * 1024;
-  auto kern = &gemm_w4_kernel<NF, MODE, SCHED, ABL>;
+  constexpr int BN = 16 * NW;
+  constexpr int SMEM = MODE == W4_CONV_HALO ? 2 * W4_HROWS * 128 + W4_R * (BN / 8) * 1024 : W4_R * (W4_BM / 8 + BN / 8) * 1024;
+  auto kern = &gemm_w4_kernel<NW, MODE, ABL>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
@@ -460,32 +688,40 @@ int launch_w4_mode(const GemmParams& p0, hipStream_t stream) {
   return CL_OK;
 }
 
-template <int NF>
-int launch_w4_nf(const GemmParams& p, hipStream_t stream) {
-  if (p.mode == GEMM_LINEAR) return launch_w4_mode<NF, W4_LINEAR>(p, stream);
+// the halo-resident form covers a stride-1 conv whose every 256-row tile lies inside one image and whose image buffer fits
+bool w4_halo_ok(const GemmParams& p) {
+  if (p.mode != GEMM_CONV_S1 || p.Hin != p.Hout || p.Win != p.Wout) return false;
+  if (p.Win > 64 || p.Win < 16 || (p.Win & (p.Win - 1)) || ((long)p.Hin * p.Win) % W4_BM || p.M % W4_BM) return false;
+  return (W4_BM / p.Win + 2) * (p.Win + 2) <= W4_HROWS;
+}
+
+template <int NW>
+int launch_w4_nw(const GemmParams& p, hipStream_t stream) {
+  if (p.mode == GEMM_LINEAR) return launch_w4_mode<NW, W4_LINEAR>(p, stream);
   if (p.K2) return CL_EINVAL;   // a second K segment exists for linear operands only
 #ifdef W4_PROBE
-  if constexpr (NF == 5) {
-    if (p.mode == GEMM_CONV_S1) {
-      if (g_w4_sched_host == 0) return launch_w4_mode<NF, W4_CONV_S1, 0, 0>(p, stream);
+  if constexpr (NW == 10) {
+    if (p.mode == GEMM_CONV_S1 && g_w4_abl_host) {
+      const bool halo = g_w4_halo_host && w4_halo_ok(p);
       switch (g_w4_abl_host) {
-#define W4_CASE(a) case a: return launch_w4_mode<NF, W4_CONV_S1, a>(p, stream);
-        W4_CASE(1) W4_CASE(2) W4_CASE(3) W4_CASE(4) W4_CASE(5) W4_CASE(6) W4_CASE(7) W4_CASE(13) W4_CASE(21) W4_CASE(37) W4_CASE(33)
+#define W4_CASE(a) case a: return halo ? launch_w4_mode<NW, W4_CONV_HALO, a>(p, stream) : launch_w4_mode<NW, W4_CONV_S1, a>(p, stream);
+        W4_CASE(1) W4_CASE(2) W4_CASE(3) W4_CASE(4) W4_CASE(5) W4_CASE(6) W4_CASE(7) W4_CASE(37)
 #undef W4_CASE
         default: break;
       }
     }
   }
+  if (p.mode == GEMM_CONV_S1 && !g_w4_halo_host) return launch_w4_mode<NW, W4_CONV_S1>(p, stream);
 #endif
-  if (p.mode == GEMM_CONV_S1) return launch_w4_mode<NF, W4_CONV_S1>(p, stream);
-  return launch_w4_mode<NF, W4_CONV_ANY>(p, stream);
+  if (p.mode == GEMM_CONV_S1) return w4_halo_ok(p) ? launch_w4_mode<NW, W4_CONV_HALO>(p, stream) : launch_w4_mode<NW, W4_CONV_S1>(p, stream);
+  return launch_w4_mode<NW, W4_CONV_ANY>(p, stream);
 }
 
 }  // namespace
 
 #ifdef W4_PROBE
 void w4_abl_set(int v) { g_w4_abl_host = v; }
-void w4_sched_set(int v) { g_w4_sched_host = v; }
+void w4_halo_set(int v) { g_w4_halo_host = v; }
 void w4_timing_set(unsigned long long* buf) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_w4_timing), &buf, sizeof(buf)); }
 #endif
 
@@ -494,8 +730,8 @@ int launch_gemm_w4(const GemmParams& p, hipStream_t stream, int bn) {
   if (p.atomic || p.K1 % 64 || p.K2 % 64 || p.K1 <= 0) return CL_EINVAL;
   if (p.act == ACT_GEGLU && bn != 160) return CL_EINVAL;
   if (p.act == ACT_GEGLU_SPLIT || p.ln_gamma) return CL_EINVAL;
-  if (bn == 160) return launch_w4_nf<5>(p, stream);
-  if (bn == 128) return launch_w4_nf<4>(p, stream);
+  if (bn == 160) return launch_w4_nw<10>(p, stream);
+  if (bn == 128) return launch_w4_nw<8>(p, stream);
   return CL_EINVAL;
 }
 

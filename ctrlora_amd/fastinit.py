@@ -42,5 +42,20 @@ def fill_default_init(model: nn.Module, seed: int = 0):
                 if p is None or p.numel() == 0 or not bool(torch.isnan(p.reshape(-1)[0])):
                     continue          # explicitly initialised after construction (or drawn by a constructor that was not patched)
                 n = p.numel()
-                off = zlib.crc32(f"{name}.{pn}".encode()) % (block.numel() - n) if n < block.numel() else 0
-                p.copy_(block[off:off + n].view(p.shape)).mul_(bound)
+                flat = p.reshape(-1)
+                if n < block.numel():
+                    off = zlib.crc32(f"{name}.{pn}".encode()) % (block.numel() - n)
+                    flat.copy_(block[off:off + n])
+                else:                 # larger than the block: tile it
+                    for lo in range(0, n, block.numel()):
+                        hi = min(n, lo + block.numel())
+                        flat[lo:hi].copy_(block[:hi - lo])
+                flat.mul_(bound)
+        # Anything that READ a marked parameter while the model was being constructed (weight_norm's g, an EMA clone, one layer's
+        # weights copied into another) has baked the mark in and is not a Linear / Conv weight or bias of its own: refuse loudly
+        # instead of training on NaNs.  One isnan().any() per tensor.
+        bad = [n_ for n_, t_ in list(model.named_parameters()) + list(model.named_buffers())
+               if t_.is_floating_point() and t_.numel() and bool(torch.isnan(t_).any())]
+        if bad:
+            raise RuntimeError("fastinit: tensors still carry the 'not drawn yet' mark after fill_default_init (something read a "
+                               f"parameter during construction): {bad[:5]}{' ...' if len(bad) > 5 else ''}; set CTRLORA_FAST_INIT=0")

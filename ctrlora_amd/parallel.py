@@ -159,10 +159,16 @@ class BankedGradAllReduce:
     def reset(self):
         """Drop the hook's per-step state: wait for (and forget) every bucket already in flight, rewind the cursor.  Called at
         the start of every backward pass (an aborted backward, or `enabled` flipped off after buckets went out, must not leave
-        a stale cursor: part of the buffer would be reduced twice and part skipped in the next step)."""
+        a stale cursor: part of the buffer would be reduced twice and part skipped in the next step).
+        CONTRACT: the spans [0, cursor) that were already in flight HAVE been summed across ranks in place; after a
+        reset that interrupts a step the gradient buffer must be zeroed (optimizer.zero_grad()) before the next backward pass,
+        exactly as after an optimizer step -- the regular accumulation flow always does (exchange() drains the buckets before
+        `enabled` goes False again).  (A used-bank mask prefetched for an abandoned step is superseded by the next
+        prefetch_mask(), see there.)"""
         for w in self._pending:
             w.wait()
         self._pending = []
+        self.interrupted = bool(self._lo or self._hi)      # diagnostics: the last reset cut a step short
         self._lo = self._hi = 0
         self.launches = 0
         self.launches_before_last_stage = 0
@@ -203,7 +209,17 @@ class BankedGradAllReduce:
         if self._mask_pre is not None:
             if self._mask_pre[0] == used:
                 return
-            raise RuntimeError("the used-task set changed after its mask exchange was started; ranks would diverge")
+            # A prefetch that no exchange() consumed -- a grad-enabled forward that was not followed by a backward pass (logging,
+            # a sanity pass, a skipped step) -- is SUPERSEDED: its collective is waited for and its result dropped, then the new
+            # set goes out.  Like every collective this must happen on all ranks alike: every prefetch_mask() is paired with
+            # exactly one exchange() or one superseding prefetch_mask() on every rank.
+            stale = self._mask_pre
+            self._mask_pre = None
+            if stale[3]:
+                stale[2].synchronize()
+            else:
+                stale[2].wait()
+            self.mask_prefetch_superseded = getattr(self, "mask_prefetch_superseded", 0) + 1
         ref = self.shared[0] if self.shared else next(iter(self.banks.values()))
         mask = torch.tensor([1 if t in used else 0 for t in self.tasks], dtype=torch.int32, device=ref.device)
         work = dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group, async_op=True)

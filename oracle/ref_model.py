@@ -262,8 +262,9 @@ def ddim_step(x, e_cond, e_uncond, scale, a_t, a_prev, sigma_t, sqrt_one_minus_a
     return a_prev.sqrt() * pred_x0 + dir_xt + nz, pred_x0
 
 
-def ddim_sample(eps_fn, sched, S, x_T, scale=1.0, uncond=False, eta=0.0, noises=None):
-    """DDIMSampler.ddim_sampling loop (ddim_hacked.py:123-178).  eps_fn(x, t_long, cond: bool)."""
+def ddim_sample(eps_fn, sched, S, x_T, scale=1.0, uncond=False, eta=0.0, noises=None, keep=None):
+    """DDIMSampler.ddim_sampling loop (ddim_hacked.py:123-178).  eps_fn(x, t_long, cond: bool).  keep: an optional list that
+    receives the sample after every step (what the reference logs as intermediates['x_inter'] with log_every_t = 1)."""
     ds = make_ddim_schedule(sched, S, eta)
     img = x_T
     b = x_T.shape[0]
@@ -277,6 +278,8 @@ def ddim_sample(eps_fn, sched, S, x_T, scale=1.0, uncond=False, eta=0.0, noises=
         nz = noises[i] if noises is not None else None
         img, _ = ddim_step(img, e_c, e_u, scale, ds["alphas"][index], ds["alphas_prev"][index],
                            ds["sigmas"][index], ds["sqrt_one_minus_alphas"][index], nz)
+        if keep is not None:
+            keep.append(img)
     return img, steps
 
 

@@ -75,3 +75,21 @@ def test_two_real_ranks_through_spawn_ranks_rendezvous_allreduce_and_print_one_l
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["dry_run"] and out["steps"] == 3 and out["allreduce_sum_correct_on_every_rank"]
     assert out["backend"] in ("gloo", "nccl") and out["value"] > 0
+
+
+def test_eight_real_ranks_through_spawn_ranks_dry_run():
+    """The first 8-rank contact, without GPUs (VERDICT r5 next #8a): `python bench.py --gpus 8 --dist-dry-run` starts eight real
+    torch.distributed.run ranks (gloo here, RCCL on a GPU node), which rendezvous on 127.0.0.1, all-reduce a bucket per step inside
+    the measured region's barrier / MAX bracket, and rank 0 prints one JSON line that carries the rank count it saw."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dist-dry-run", "--steps", "3", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["world"] == 8 and out["dry_run"] and out["allreduce_sum_correct_on_every_rank"]
+    assert len(out["ms_per_step_by_rank"]) == 8 and all(v > 0 for v in out["ms_per_step_by_rank"])

@@ -232,7 +232,7 @@ def test_timestep_embedding_qsample_mse_ddim_adamw_match_oracle():
     ("tiny", torch.float32, 1e-4, 5e-4), ("tiny", torch.bfloat16, 3e-2, 1.5e-1),
     ("sd15", torch.float32, 1e-4, 5e-4),
     # (SD1.5 width in bf16 is gated at the benchmarked geometry by test_gpu_bench_shapes.py and at rank 32 by test_gpu_parity_r4.py)
-    pytest.param("sd15", torch.bfloat16, 3e-2, 1.5e-1, marks=pytest.mark.slow)])
+    ("sd15", torch.bfloat16, 3e-2, 1.5e-1)])     # (the end-to-end bf16 check of the xs / LN-prologue / RES epilogues stays in the default run)
 def test_engine_forward_backward_vs_oracle_and_reference_golden(name, dtype, tol_eps, tol_grad):
     """eps, the 13 ControlNet residuals and every trainable gradient: HIP engine vs the CPU oracle on the
     same key-addressed weights / seeded inputs, and eps / loss vs the golden vectors generated from the

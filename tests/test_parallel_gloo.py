@@ -143,6 +143,111 @@ def test_banked_grad_exchange_two_ranks_different_tasks_gloo():
     assert all(ok for _, ok in res), res
 
 
+# ------------------------------------------------------------------ eight ranks (VERDICT r5 next #8b): the production layout's size
+
+_N_REAL = 36_950_016          # ~ the 36.95 M trainable floats of the rank-128 fine-tune (148 MB: five 32 MB buckets)
+
+
+def _worker_real_layout(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ctrlora_amd.parallel import GradAllReduce
+    try:
+        n = _N_REAL
+        ex = _FakeExecutor(n, rank)
+        dp = GradAllReduce([ex], bucket_bytes=32 << 20)        # bench.py's bucket size
+        dp.enabled = True
+        # 13 backward stages in increasing offset order (middle block first ... time embedding last), uneven like the real ones
+        cuts = [0] + [int(n * f) for f in (0.11, 0.21, 0.3, 0.38, 0.47, 0.55, 0.63, 0.72, 0.8, 0.87, 0.93, 0.98)] + [n]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            ex.on_stage_done(a, b)
+        dp.on_backward_done(); dp.wait()
+        expect = torch.zeros(n)
+        for r in range(world):
+            expect += _TR(n, r).flat_grad
+        err = float((ex.tr.flat_grad - expect).abs().max())
+        q.put((rank, err, dp.launches, dp.launched_bytes))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_grad_allreduce_eight_ranks_real_layout_size_gloo():
+    """8 ranks x 36.95 M floats through GradAllReduce with bench.py's 32 MB buckets: a handful of collectives, every element exchanged
+    once, every rank ends with the sum over all eight."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_real_layout, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in range(world)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(r for r, *_ in res) == list(range(world))
+    for rank, err, launches, nbytes in res:
+        assert err < 1e-4, (rank, err)                # fp32 sums of eight N(0,1) terms in a different order
+        # (a bucket is launched when whole stages have filled >= 32 MB: 4-5 collectives for these spans)
+        assert 3 <= launches <= 6 and nbytes == _N_REAL * 4, (rank, launches, nbytes)
+
+
+_TASKS9 = ["hed", "canny", "depth", "seg", "lineart", "jpeg", "palette", "pixel", "normal"]
+
+
+def _bank_worker8(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ctrlora_amd.parallel import BankedGradAllReduce
+    try:
+        mk = lambda seed, n: torch.randn(n, generator=torch.Generator().manual_seed(seed))
+        shared = [mk(10 + rank, 3000), mk(50 + rank, 500)]
+        banks = {t: mk(1000 * (i + 1) + rank, 1200) for i, t in enumerate(_TASKS9)}
+        stale = {t: b.clone() for t, b in banks.items()}
+        ex = BankedGradAllReduce(shared, banks)
+        # the reference's per-rank task order: rank r trains task (r * 2) % 9 in this step -> 8 ranks, tasks {0,2,4,6,8,1,3,5}: task 7 idle
+        mine = _TASKS9[(rank * 2) % 9]
+        users = {}
+        for r in range(world):
+            users.setdefault(_TASKS9[(r * 2) % 9], []).append(r)
+        live = ex.exchange([mine])
+        ok = set(live) == set(users) and "pixel" not in live
+        ok &= all(torch.allclose(s, sum(mk(b + r, s.numel()) for r in range(world)), atol=1e-5) for s, b in zip(shared, (10, 50)))
+        for i, t in enumerate(_TASKS9):
+            if t in users:      # the owners' gradients summed, zeros from everybody else
+                ok &= torch.allclose(banks[t], sum(mk(1000 * (i + 1) + r, 1200) for r in users[t]), atol=1e-5)
+            else:               # idle everywhere: neither touched nor communicated
+                ok &= torch.equal(banks[t], stale[t])
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_banked_grad_exchange_eight_ranks_nine_tasks_gloo():
+    """configs[3]'s shape of the problem: 8 ranks, 9 LoRA banks, every rank on its own task -- eight banks live (one owner each,
+    zeros from the other seven ranks), one bank idle and untouched, the shared base gradients summed over all eight."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bank_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
+
+
 # ------------------------------------------------------------------ _PretrainDP: replicas stay identical (ADVICE r2 high)
 
 class _FlatSet:

@@ -8,7 +8,7 @@ C=ctrlora_amd/csrc
 for p in "$@"; do
   case $p in
     gemm) hipcc $FLAGS tools/probe_gemm.hip $C/gemm.hip $C/gemm_xs.hip $C/gemm_w4.hip $C/wgrad.hip -o build/probe_gemm ;;
-    gemm_w4) hipcc $FLAGS -DW4_PROBE tools/probe_gemm.hip $C/gemm.hip $C/gemm_xs.hip $C/gemm_w4.hip $C/wgrad.hip -o build/probe_gemm_w4 ;;
+    gemm_w4) hipcc $FLAGS -DW4_PROBE -DFL_TIMING tools/probe_gemm.hip $C/gemm.hip $C/gemm_xs.hip $C/gemm_w4.hip $C/wgrad.hip -o build/probe_gemm_w4 ;;
     gemm_t) hipcc $FLAGS -DFL_TIMING tools/probe_gemm.hip $C/gemm.hip $C/gemm_xs.hip $C/gemm_w4.hip $C/wgrad.hip -o build/probe_gemm_t ;;
     attn) hipcc $FLAGS tools/probe_attn.hip $C/gemm.hip $C/gemm_xs.hip $C/gemm_w4.hip $C/attention_fwd.hip $C/attention_bwd.hip $C/attention_tr.hip $C/elementwise.hip -o build/probe_attn ;;
     attn_bwd) hipcc $FLAGS tools/probe_attn_bwd.hip $C/gemm.hip $C/gemm_xs.hip $C/gemm_w4.hip $C/attention_fwd.hip $C/attention_bwd.hip $C/attention_tr.hip $C/elementwise.hip -o build/probe_attn_bwd ;;

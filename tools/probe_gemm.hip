@@ -463,7 +463,7 @@ static void correctness_suite(const char* tag) {
 
 // ---------------- loader / consumer kernel (configurations 40 / 41, gemm_w4.hip) ----------------
 #ifdef W4_PROBE
-namespace cl { void w4_abl_set(int v); void w4_sched_set(int v); void w4_timing_set(unsigned long long* buf); }
+namespace cl { void w4_abl_set(int v); void w4_halo_set(int v); void w4_timing_set(unsigned long long* buf); }
 #endif
 // interleaved A/B of tile configurations on ONE set of operands: median / min of `rounds` timed batches each, the outputs compared with
 // configuration cfgs[0]'s (different summation order: rel-L2 at the bf16 rounding level), and every configuration's repeat launches
@@ -569,6 +569,78 @@ static void conv_sampled(const char* name, int cfg, int B, int H, int W, int C, 
   report(name, num, den, 2e-5);
   hipFree(X.d); hipFree(Wt.d); hipFree(Cb.d); hipFree(dbias);
 }
+
+
+#ifdef W4_PROBE
+// s_memtime stamps of every tile (wave 0): entry | stage 0 landed | main loop done | stores retired, next to the wall time of the
+// same launch: cycles / wall = the clock the chip actually held
+static void w4_timing_case(const char* tag) {
+  const int M = 8 * 64 * 64, N = 320, K1 = 320;
+  Buf A, Wt, Cb; A.init((size_t)M * K1, CL_BF16); Wt.init((size_t)N * 9 * K1, CL_BF16, 0.05f); Cb.init((size_t)M * N, CL_BF16, 1.f, true);
+  GemmParams p{}; p.A1 = A.d; p.lda1 = K1; p.K1 = K1; p.W1 = Wt.d; p.ldw1 = 9 * K1; p.M = M; p.N = N; p.mode = GEMM_CONV_S1;
+  p.B = 8; p.Hin = 64; p.Win = 64; p.Hout = 64; p.Wout = 64; p.zero_page = g_zero; p.alpha = 1.f; p.C = Cb.d; p.ldc = N; p.splitk = 1;
+  const long nv = 256;
+  unsigned long long* tb; HIPCHK(hipMalloc(&tb, nv * 32)); HIPCHK(hipMemset(tb, 0, nv * 32));
+  g_gemm_force_cfg = 40;
+  for (int i = 0; i < 10; ++i) launch_gemm(p, CL_BF16, 0);
+  HIPCHK(hipDeviceSynchronize());
+  cl::w4_timing_set(tb);
+  hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  for (int i = 0; i < 5; ++i) launch_gemm(p, CL_BF16, 0);
+  HIPCHK(hipEventRecord(e0, 0));
+  for (int i = 0; i < 10; ++i) launch_gemm(p, CL_BF16, 0);
+  HIPCHK(hipEventRecord(e1, 0)); HIPCHK(hipEventSynchronize(e1));
+  float ms; HIPCHK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
+  HIPCHK(hipDeviceSynchronize());
+  cl::w4_timing_set(nullptr);
+  g_gemm_force_cfg = -1;
+  std::vector<unsigned long long> tt(nv * 4);
+  HIPCHK(hipMemcpy(tt.data(), tb, nv * 32, hipMemcpyDeviceToHost));
+  double ph[3] = {0, 0, 0};
+  for (long i = 0; i < nv; ++i)
+    for (int k = 0; k < 3; ++k) ph[k] += (double)(tt[i * 4 + k + 1] - tt[i * 4 + k]);
+  const double tot = (ph[0] + ph[1] + ph[2]) / nv;
+  printf("[TIMING] %-52s wall %6.1f us | per tile: entry -> stage 0 landed %6.0f | main loop (45 stages) %6.0f = %5.0f per stage | epilogue %6.0f | "
+         "sum %6.0f cycles -> %.2f GHz\n", tag, ms * 1e3, ph[0] / nv, ph[1] / nv, ph[1] / nv / 45, ph[2] / nv, tot, tot / (ms * 1e3) * 1e-3);
+  hipFree(tb); hipFree(A.d); hipFree(Wt.d); hipFree(Cb.d);
+}
+#endif
+
+
+#if defined(W4_PROBE) && defined(FL_TIMING)
+namespace cl { void fl_timing_set(unsigned long long* buf); }
+// the same cycles-against-wall accounting for the ping-pong tile kernel (configuration 16): stamps 0 entry | 2 first stage landed |
+// 3 main loop done | 4 epilogue issued
+static void fl_timing_case16() {
+  const int M = 8 * 64 * 64, N = 320, K1 = 320;
+  Buf A, Wt, Cb; A.init((size_t)M * K1, CL_BF16); Wt.init((size_t)N * 9 * K1, CL_BF16, 0.05f); Cb.init((size_t)M * N, CL_BF16, 1.f, true);
+  GemmParams p{}; p.A1 = A.d; p.lda1 = K1; p.K1 = K1; p.W1 = Wt.d; p.ldw1 = 9 * K1; p.M = M; p.N = N; p.mode = GEMM_CONV_S1;
+  p.B = 8; p.Hin = 64; p.Win = 64; p.Hout = 64; p.Wout = 64; p.zero_page = g_zero; p.alpha = 1.f; p.C = Cb.d; p.ldc = N; p.splitk = 1;
+  const long nv = 256;
+  unsigned long long* tb; HIPCHK(hipMalloc(&tb, nv * 64)); HIPCHK(hipMemset(tb, 0, nv * 64));
+  g_gemm_force_cfg = 16;
+  for (int i = 0; i < 10; ++i) launch_gemm(p, CL_BF16, 0);
+  HIPCHK(hipDeviceSynchronize());
+  cl::fl_timing_set(tb);
+  hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  for (int i = 0; i < 5; ++i) launch_gemm(p, CL_BF16, 0);
+  HIPCHK(hipEventRecord(e0, 0));
+  for (int i = 0; i < 10; ++i) launch_gemm(p, CL_BF16, 0);
+  HIPCHK(hipEventRecord(e1, 0)); HIPCHK(hipEventSynchronize(e1));
+  float ms; HIPCHK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
+  HIPCHK(hipDeviceSynchronize());
+  cl::fl_timing_set(nullptr);
+  g_gemm_force_cfg = -1;
+  std::vector<unsigned long long> tt(nv * 8);
+  HIPCHK(hipMemcpy(tt.data(), tb, nv * 64, hipMemcpyDeviceToHost));
+  double ph[3] = {0, 0, 0};
+  for (long i = 0; i < nv; ++i) { ph[0] += (double)(tt[i * 8 + 2] - tt[i * 8]); ph[1] += (double)(tt[i * 8 + 3] - tt[i * 8 + 2]); ph[2] += (double)(tt[i * 8 + 4] - tt[i * 8 + 3]); }
+  const double tot = (ph[0] + ph[1] + ph[2]) / nv;
+  printf("[TIMING] %-52s wall %6.1f us | per tile: entry -> stage 0 landed %6.0f | main loop (45 stages) %6.0f = %5.0f per stage | epilogue %6.0f | "
+         "sum %6.0f cycles -> %.2f GHz\n", "cfg 16 (ping-pong tiles, stamps cost ~1 %)", ms * 1e3, ph[0] / nv, ph[1] / nv, ph[1] / nv / 45, ph[2] / nv, tot, tot / (ms * 1e3) * 1e-3);
+  hipFree(tb); hipFree(A.d); hipFree(Wt.d); hipFree(Cb.d);
+}
+#endif
 
 #ifdef FL_TIMING
 namespace cl { void fl_timing_set(unsigned long long* buf); }
@@ -780,6 +852,10 @@ int main(int argc, char** argv) {
     conv_sampled("conv 320->320 @64^2 B2 sampled vs fp64, cfg 40", 40, 2, 64, 64, 320, 320, 4000);
     conv_sampled("conv 128->128 @96x80 B1 sampled vs fp64, cfg 41", 41, 1, 96, 80, 128, 128, 4000);
     conv_sampled("conv 640->320 ragged 3x33x31 sampled, cfg 40", 40, 3, 33, 31, 640, 320, 4000);
+    conv_sampled("conv 640->640 @32^2 B2 sampled (halo), cfg 40", 40, 2, 32, 32, 640, 640, 4000);
+    conv_sampled("conv 1280->320 @16^2 B4 sampled (halo, split-K), cfg 40", 40, 4, 16, 16, 1280, 320, 4000);
+    conv_sampled("conv 64->160 @64^2 B1 sampled (halo, one chunk), cfg 40", 40, 1, 64, 64, 64, 160, 4000);
+    conv_sampled("conv 128->128 @32^2 B3 sampled (halo), cfg 41", 41, 3, 32, 32, 128, 128, 4000);
     const int ab[] = {16, 40}, ab128[] = {17, 41};
     ab_case("conv 320->320 @64^2 B8", GEMM_CONV_S1, 8 * 64 * 64, 320, 320, 8, 64, 64, 0, ab, 2, 7);
     ab_case("conv 320->320 @64^2 B8 rowbias+silu", GEMM_CONV_S1, 8 * 64 * 64, 320, 320, 8, 64, 64, 0, ab, 2, 3, false, true);
@@ -807,51 +883,33 @@ w4_ablations:
 #ifdef W4_PROBE
     const int only40[] = {40};
     {
-      printf("---- read schedule: 0 = two reads per gap + lgkmcnt(0) per k-step, 1 = counted waits (production)\n");
+      printf("---- conv S1 under cfg 40: halo-resident image (1) vs per-tap DMA (0)\n");
       for (int rep = 0; rep < 2; ++rep)
-        for (int sc = 0; sc < 2; ++sc) {
-          cl::w4_sched_set(sc);
-          char nm[64]; snprintf(nm, 64, "conv 320->320 @64^2 B8  sched %d", sc);
+        for (int hm = 0; hm < 2; ++hm) {
+          cl::w4_halo_set(hm);
+          char nm[64]; snprintf(nm, 64, "conv 320->320 @64^2 B8  halo %d", hm);
           ab_case(nm, GEMM_CONV_S1, 8 * 64 * 64, 320, 320, 8, 64, 64, 0, only40, 1, 5);
         }
-      cl::w4_sched_set(1);
+      cl::w4_halo_set(1);
     }
-    const int abls[] = {0, 1, 2, 3, 4, 5, 6, 7, 13, 21, 37, 33};
+    const int abls[] = {0, 1, 2, 3, 4, 5, 6, 7, 37};
     const char* an[] = {"full", "no fragment reads", "no DMA", "no reads, no DMA", "no stores", "no reads + no stores", "no DMA + no stores",
-                        "skeleton: MFMA + barrier only", "W-tile DMA only (no X DMA, no reads, no stores)", "X-tile DMA only (no W DMA, no reads, no stores)", "DMA + barriers only (no MFMA, no reads, no stores)", "DMA + reads, no MFMA"};
-    for (int ai = 0; ai < 12; ++ai) {
+                        "skeleton: MFMA + barrier only", "DMA + barriers only (no MFMA, no reads, no stores)"};
+    for (int ai = 0; ai < 9; ++ai) {
       cl::w4_abl_set(abls[ai]);
       printf("---- ablation %d: %s (results wrong by construction; FAIL lines below are expected)\n", abls[ai], an[ai]);
       const int keep = g_fail;
       ab_case("conv 320->320 @64^2 B8", GEMM_CONV_S1, 8 * 64 * 64, 320, 320, 8, 64, 64, 0, only40, 1, 3);
-      ab_case("conv 320->320 @64^2 B32", GEMM_CONV_S1, 32 * 64 * 64, 320, 320, 32, 64, 64, 0, only40, 1, 3);
+      w4_timing_case(an[ai]);
       g_fail = keep;
     }
     cl::w4_abl_set(0);
-    {   // s_memtime stamps of every tile: entry | stage 0 landed | main loop done | stores retired
-      const int M = 8 * 64 * 64, N = 320, K1 = 320;
-      Buf A, Wt, Cb; A.init((size_t)M * K1, CL_BF16); Wt.init((size_t)N * 9 * K1, CL_BF16, 0.05f); Cb.init((size_t)M * N, CL_BF16, 1.f, true);
-      GemmParams p{}; p.A1 = A.d; p.lda1 = K1; p.K1 = K1; p.W1 = Wt.d; p.ldw1 = 9 * K1; p.M = M; p.N = N; p.mode = GEMM_CONV_S1;
-      p.B = 8; p.Hin = 64; p.Win = 64; p.Hout = 64; p.Wout = 64; p.zero_page = g_zero; p.alpha = 1.f; p.C = Cb.d; p.ldc = N; p.splitk = 1;
-      const long nv = 256;
-      unsigned long long* tb; HIPCHK(hipMalloc(&tb, nv * 32)); HIPCHK(hipMemset(tb, 0, nv * 32));
-      g_gemm_force_cfg = 40;
-      for (int i = 0; i < 3; ++i) launch_gemm(p, CL_BF16, 0);
-      HIPCHK(hipDeviceSynchronize());
-      cl::w4_timing_set(tb);
-      launch_gemm(p, CL_BF16, 0); HIPCHK(hipDeviceSynchronize());
-      cl::w4_timing_set(nullptr);
-      g_gemm_force_cfg = -1;
-      std::vector<unsigned long long> tt(nv * 4);
-      HIPCHK(hipMemcpy(tt.data(), tb, nv * 32, hipMemcpyDeviceToHost));
-      double ph[3] = {0, 0, 0}; unsigned long long tmin = ~0ull, tmax = 0;
-      for (long i = 0; i < nv; ++i) {
-        for (int k = 0; k < 3; ++k) ph[k] += (double)(tt[i * 4 + k + 1] - tt[i * 4 + k]);
-        tmin = std::min(tmin, tt[i * 4]); tmax = std::max(tmax, tt[i * 4 + 3]);
-      }
-      printf("[TIMING] cfg 40 conv 320->320 @64^2 B8: %ld tiles, span %.0f ticks; per tile: entry -> stage 0 landed %.0f | main loop (45 stages) %.0f | "
-             "epilogue to stores retired %.0f  [s_memtime ticks]\n", nv, (double)(tmax - tmin), ph[0] / nv, ph[1] / nv, ph[2] / nv);
-    }
+    w4_timing_case("full");
+#if defined(W4_PROBE) && defined(FL_TIMING)
+    fl_timing_case16();
+    w4_timing_case("full (again)");
+    fl_timing_case16();
+#endif
 #endif
     printf("probe_gemm --w4: %s (%d failures)\n", g_fail ? "FAILED" : "ALL PASS", g_fail);
     return g_fail ? 1 : 0;
