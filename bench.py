@@ -40,13 +40,32 @@ STOCK_BF16_IMAGES_PER_S = 42.3   # profiles/r02_compare_precision.json: stock ke
 def stock_reference():
     """(images/s, source) of the reference's modules on PyTorch-ROCm's own kernels under bf16 autocast, B = 8, one MI355X: the
     newest tests/tools/compare_stock.py result under profiles/ (re-measured in round 5), else the round-2 figure."""
-    for name in ("r05_compare_precision.json", "r02_compare_precision.json"):
+    for name in ("r06_compare_precision.json", "r05_compare_precision.json", "r02_compare_precision.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return float(json.load(f)["stock_bf16_autocast"]["images_per_s"]), "profiles/" + name
         except Exception:
             continue
     return STOCK_BF16_IMAGES_PER_S, "profiles/r02_compare_precision.json"
+def src_hash(rel):
+    """sha256 (first 12 hex digits) of a source file of this tree: static measurement artefacts under profiles/ record the hash of
+    the kernel source they were measured on, and the bench marks them `stale` when the source has changed since (VERDICT r5 #9)."""
+    import hashlib
+    try:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:12]
+    except OSError:
+        return None
+
+
+def provenance(meta, rel="ctrlora_amd/csrc/gemm.hip"):
+    """{"measured_at_commit", "source_sha256", "stale"} for a static artefact whose JSON carries the first two."""
+    have = src_hash(rel)
+    was = (meta or {}).get("source_sha256")
+    return dict(measured_at_commit=(meta or {}).get("measured_at_commit"), source=rel, source_sha256_then=was, source_sha256_now=have,
+                stale=bool(was is None or have is None or was != have))
+
+
 PEAK_HBM_TBS = 8.0          # TB/s, MI355X_MICROARCH.md
 PEAK_BF16_TFLOPS = 2500.0
 
@@ -120,22 +139,30 @@ def conv_kernel_probe(device, dtype, iters=30):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * B * H * H * C * 9 * C
-    traffic = None
+    traffic, tmeta = None, None
     try:
         with open(os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")) as f:
-            traffic = json.load(f)["hbm_bytes_per_launch"]
+            tmeta = json.load(f)
+            traffic = tmeta["hbm_bytes_per_launch"]
     except Exception:
         pass
     return dict(kernel="gemm_fl_kernel<bf16,256x160,8 waves> conv3x3 320->320 @64x64 B8 (60.4 GFLOP/launch)",
                 ms=round(ms, 4), achieved=round(flops / ms * 1e-9, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                frac=round(flops / ms * 1e-9 / PEAK_BF16_TFLOPS, 4), traffic=traffic)
+                frac=round(flops / ms * 1e-9 / PEAK_BF16_TFLOPS, 4), traffic=traffic, traffic_provenance=provenance(tmeta))
 
 
 def dominant_kernel_rocprof():
     """The same launch INSIDE the replayed training step, from this round's rocprofv3 kernel trace joined with the launch tags
     (tools/prof_shapes.py -> profiles/r05_final/train_shapes_in_step.txt): static here, published beside the live HIP-event figure
     because hot isolated launches run ~8 % faster than the launch does in the step."""
-    path = os.path.join(ROOT, "profiles", "r05_final", "train_shapes_in_step.txt")
+    path = next((q for q in (os.path.join(ROOT, "profiles", r, "train_shapes_in_step.txt") for r in ("r06_final", "r05_final"))
+                 if os.path.exists(q)), "")
+    meta = None
+    try:
+        with open(os.path.join(os.path.dirname(path), "provenance.json")) as f:
+            meta = json.load(f)
+    except Exception:
+        pass
     try:
         us = n = 0.0
         for ln in open(path):
@@ -147,7 +174,7 @@ def dominant_kernel_rocprof():
             return None
         avg = us / n
         return dict(us_per_launch=round(avg, 2), launches_per_step=int(n), tflops=round(60.4e3 / avg, 1),
-                    frac=round(60.4e3 / avg / PEAK_BF16_TFLOPS, 4), source="profiles/r05_final/train_shapes_in_step.txt (static)")
+                    frac=round(60.4e3 / avg / PEAK_BF16_TFLOPS, 4), source=os.path.relpath(path, ROOT) + " (static)", **provenance(meta))
     except Exception:
         return None
 
@@ -264,6 +291,8 @@ def family_census(model, opt, data, reps=10):
             us = e0.elapsed_time(e1) * 1e3 / reps
             if fam == "hbm":
                 ent.append(us)
+            if fam == "attention":
+                ent.append(us)
             tot_us += us * cnt; tot_fl += fl * cnt; n += cnt
             t_mfma = fl / (PEAK_BF16_TFLOPS * 1e6)                      # us at the dense bf16 MFMA peak
             t_hbm = (ent[3] / (PEAK_HBM_TBS * 1e6)) if len(ent) > 3 else 0.0   # us at the HBM peak
@@ -295,6 +324,16 @@ def family_census(model, opt, data, reps=10):
             out[fam] = dict(achieved=round(tf, 1), frac=round(tf / PEAK_BF16_TFLOPS, 4), unit="TFLOP/s",
                             ms_per_step=round(tot_us * 1e-3, 2), launches_per_step=n, unique_shapes=len(tab),
                             gflop_per_step=round(tot_fl * 1e-9, 1))
+            if fam == "attention":
+                # the north_star's ">= 50 % MFMA on the attention kernel" as one field per kernel: USEFUL (algorithmic) FLOPs of a
+                # signature / its launch time / the dense bf16 peak.  "fwd" = attn_fwd40_kernel at d_head 40; "bwd" = the
+                # attn_bwd_dq + attn_bwd_dkv pair of one hip.attention_bwd call (their split is in profiles/*/train_kernel_stats)
+                out[fam]["per_signature"] = [
+                    dict(kind=k[0], B=k[1], H=k[2], N=k[3], Nkv=k[4], d_head=k[5], calls=e[0], us=round(e[3], 1),
+                         useful_tflops=round(e[1] / e[3] * 1e-6, 1), useful_frac=round(e[1] / e[3] * 1e-6 / PEAK_BF16_TFLOPS, 4))
+                    for k, e in sorted(tab.items(), key=lambda kv: -kv[1][3] * kv[1][0]) if len(e) > 3]
+                dom = [r for r in out[fam]["per_signature"] if r["N"] == r["Nkv"] == 4096]
+                out[fam]["useful_frac"] = {r["kind"] + ("" if r["kind"] == "fwd" else "_dq_dkv_pair"): r["useful_frac"] for r in dom}
             if fam == "gemm":
                 # every launch against ITS OWN roofline, max(FLOPs / MFMA peak, algorithmic bytes / HBM peak): the K = 320
                 # products of the 64x64 level are below the machine balance (160 FLOP/B against 312) and HBM-bound
@@ -964,7 +1003,15 @@ def main():
             # context, not credit: the reference's own modules on PyTorch-ROCm eager kernels, bf16 autocast, same workload and
             # GPU model (tests/tools/compare_stock.py -> profiles/r02_compare_precision.json); not re-measured in this run
             stock_ips, stock_src = stock_reference()
+            try:
+                with open(os.path.join(ROOT, stock_src)) as f:
+                    smeta = json.load(f)
+            except Exception:
+                smeta = None
             out["vs_stock"] = {"value": round(ips / stock_ips, 2), "stock_images_per_s": stock_ips,
+                               "provenance": dict(measured_at_commit=(smeta or {}).get("measured_at_commit"),
+                                                  stale=not bool((smeta or {}).get("measured_at_commit")),
+                                                  note="the comparator runs PyTorch-ROCm's kernels, not this tree's: stale = no commit recorded"),
                                "kind": f"static: {stock_src} (reference modules, torch.autocast(bf16), PyTorch-ROCm eager, B=8, "
                                        "1x MI355X; tests/tools/compare_stock.py)"}
         achieved = tf_img * ips / world          # per-GPU TFLOP/s
@@ -986,8 +1033,10 @@ def main():
                                 "launches between HIP events; the step as a whole is roofline.whole_step, the time-weighted "
                                 "contraction family roofline.family -- since round 4 (rounds 1-3 reported the family figure here)",
                         rocprof=dominant_kernel_rocprof(),
-                        traffic_kind="rocprofv3 TCC passes on this launch, FETCH_SIZE (x2: gfx950 correction) + WRITE_SIZE, re-measured in "
-                                     "round 4 (profiles/dominant_kernel_traffic.json); static in this run")
+                        traffic_provenance=dk.get("traffic_provenance"),
+                        traffic_kind="rocprofv3 TCC passes on this launch, FETCH_SIZE (x2: gfx950 correction) + WRITE_SIZE "
+                                     "(profiles/dominant_kernel_traffic.json names the commit and the kernel-source hash it was taken on; "
+                                     "`traffic_provenance.stale` = csrc/gemm.hip has changed since); static in this run")
             gf = fam.get("gemm")
             if gf:
                 roof["family"] = dict(gf, kernel="gemm_fl / gemm kernel family (implicit-GEMM 3x3 conv + linear + LoRA-fused linear), "

@@ -65,10 +65,11 @@ int launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);
 // x-stationary streaming product (gemm_xs.hip, bf16, launch configuration 34): CL_EINVAL when the product is not one it covers.
 // nsplit: column runs per group (0 = the launcher's rule).
 int launch_gemm_xs(const GemmParams& p, hipStream_t stream, int nsplit);
-// loader / consumer tile kernel (gemm_w4.hip, bf16, launch configurations 40 / 41 = 256 x 160 / 256 x 128 tiles): four consumer
+// loader / consumer tile kernel (gemm_w4.hip, bf16, launch configurations 40 / 41 = 256 x 160 / 256 x 128 tiles; 47 / 48 = their
+// persistent forms): four consumer
 // waves (one per SIMD) run nothing but the MFMA stream and its fragment reads, four loader waves issue every LDS-DMA.
 // CL_EINVAL when the product is not one it covers (K segments not whole 128-byte lines, fp32 atomics).
-int launch_gemm_w4(const GemmParams& p, hipStream_t stream, int bn);
+int launch_gemm_w4(const GemmParams& p, hipStream_t stream, int bn, int persist);   // persist: one workgroup per CU walks the tiles
 int gemm_pick_splitk(GemmParams& p, long tiles, int steps, int want, int min_steps, float** slab, hipStream_t stream);
 void gemm_launch_splitk_reduce_bf16(const GemmParams& p, const float* slab, hipStream_t stream);
 // Device scratch for the deterministic split-K path (fp32 partial slabs).  Owned by the host;

@@ -1134,7 +1134,7 @@ struct TuneKey {
 static std::map<TuneKey, std::pair<int, int>> g_tune;
 
 int gemm_tune_set(int dtype, int mode, int M, int N, int K1, int K2, int geglu, int cfg, int splitk) {
-  if (cfg < 0 || cfg > 41 || splitk < 0 || splitk > 64) return CL_EINVAL;
+  if (cfg < 0 || cfg > 48 || splitk < 0 || splitk > 64) return CL_EINVAL;
   g_tune[TuneKey{{dtype, mode, M, N, K1, K2, geglu ? 1 : 0}}] = std::make_pair(cfg, splitk);
   return CL_OK;
 }
@@ -1160,7 +1160,7 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
 
 template <typename T>
 static int launch_t_cfg(const GemmParams& p, hipStream_t stream, int cfg) {
-  if (p.act == ACT_GEGLU && cfg != 2 && cfg != 12 && cfg != 8 && cfg != 10 && cfg != 14 && cfg != 16 && cfg != 18 && cfg != 20 && cfg != 23 && cfg != 25 && cfg != 27 && cfg != 29 && !(cfg == 40 && sizeof(T) == 2)) cfg = -2;   // needs a 2 x 80-column wave pair (40: in-register pairing)
+  if (p.act == ACT_GEGLU && cfg != 2 && cfg != 12 && cfg != 8 && cfg != 10 && cfg != 14 && cfg != 16 && cfg != 18 && cfg != 20 && cfg != 23 && cfg != 25 && cfg != 27 && cfg != 29 && cfg != 44 && !((cfg == 40 || cfg == 47) && sizeof(T) == 2)) cfg = -2;   // needs a 2 x 80-column wave pair (40: in-register pairing)
   if constexpr (sizeof(T) == 2) {
     // No table entry and no forced configuration: the x-stationary kernel by RULE where the measured table took it at the
     // benchmarked batch sizes (profiles/r05_gemm_xs/autotune_xs.out) -- other batch sizes (pre-training at the reference's
@@ -1206,11 +1206,14 @@ static int launch_t_cfg(const GemmParams& p, hipStream_t stream, int cfg) {
     const bool lines = p.K1 % kps == 0 && p.K2 % kps == 0;
     auto bn_of = [&](int c) {
       switch (c) {
-        case 0: case 24: return 64;
+        case 0: case 24: case 42: case 45: return 64;
+        case 43: return 128;
+        case 44: return 160;
+        case 46: return 128;
         case 1: case 6: case 7: case 22: return 128;
         case 2: case 3: case 4: case 5: case 23: return 160;
-        case 40: return lines ? 160 : 128;
-        case 41: return 128;
+        case 40: case 47: return lines ? 160 : 128;
+        case 41: case 48: return 128;
         case 31: case 32: case 35: case 36: return (lines && p.N % 80 == 0) ? 80 : 128;
         case 33: return (lines && p.N % 320 == 0) ? 320 : 128;
         case 34: return 32;    // x-stationary kernel: 32-column chunks (its own launcher re-checks the groups)
@@ -1323,13 +1326,22 @@ static int launch_t_cfg(const GemmParams& p, hipStream_t stream, int cfg) {
       t_force_sk = 0;
       return launch_t_cfg<T>(p, stream, -1);
     }
-    case 40: case 41: {   // loader / consumer kernel (gemm_w4.hip): 256 x 160 / 256 x 128 tiles, 4 MFMA waves + 4 DMA waves
+    case 40: case 41: case 47: case 48: {   // loader / consumer kernel (gemm_w4.hip): 256 x 160 / 256 x 128 tiles, 4 MFMA waves + 4 DMA
+      // waves; 47 / 48: persistent (one workgroup per CU walks the tiles: the next tile's loads and this tile's stores overlap)
       if constexpr (sizeof(T) == 2) {
-        const int rc = launch_gemm_w4(p, stream, cfg == 40 ? 160 : 128);
+        const int rc = launch_gemm_w4(p, stream, (cfg == 40 || cfg == 47) ? 160 : 128, cfg >= 47);
         if (rc != CL_EINVAL) return rc;
       }
       return launch_t_cfg<T>(p, stream, -1);
     }
+    // Round 6: the same small tiles with an 8-slot ring (7 substeps of LDS-DMA in flight instead of 3).  The short-K / small-M
+    // launches run a near-constant ~1 us per pipeline step whatever their size: an LDS-DMA round trip under load is ~2000 cycles
+    // (profiles/r06_w4/), and a step can only be as short as round trip / (slots - 1).  Offered to the tuner.
+    case 42: return launch_cfg<T, 64, 64, 2, 2, 1, 8>(p, stream);
+    case 43: return launch_cfg<T, 64, 128, 2, 2, 1, 8>(p, stream);
+    case 44: return launch_cfg<T, 64, 160, 2, 2, 1, 8>(p, stream);
+    case 45: return launch_cfg<T, 128, 64, 2, 2, 1, 8>(p, stream);
+    case 46: return launch_cfg<T, 128, 128, 2, 2, 2, 8>(p, stream);
     // small-M tiles of the generic kernel (8x8 / 16x16 levels, text-context projections): offered to the tuner
     case 22: return launch_cfg<T, 64, 128, 2, 2, 1, 4>(p, stream);
     case 23: return launch_cfg<T, 64, 160, 2, 2, 1, 4>(p, stream);

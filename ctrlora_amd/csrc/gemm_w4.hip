@@ -150,7 +150,7 @@ __host__ __device__ constexpr int w4_pieces_hi(int t) { return t < 2 ? 0 : (4 * 
 // NW: 16-column fragment blocks per tile row (BN = 16 NW: 10 -> 160, 8 -> 128).
 template <int NW, int MODE, int ABL = 0>
 __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParams p, int tiles_m, int tiles_n,
-                                                                      float* __restrict__ slab) {
+                                                                      float* __restrict__ slab, int nvirt, int ngrid) {
   typedef bf16_t T;
   constexpr bool HALO = MODE == W4_CONV_HALO;
   constexpr int BN = 16 * NW, G2 = 2 * NW, R = NW / 2, GB = G2 - R - 1;
@@ -169,28 +169,36 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  // ---- XCD-aware tile id (as gemm_fl_kernel): XCD x (= workgroup id mod 8) owns a contiguous range of tiles
+  // ---- A workgroup walks the virtual tile ids blockIdx.x, blockIdx.x + ngrid, ... < nvirt (ngrid < nvirt: the PERSISTENT form,
+  // ngrid a multiple of 8 so that a workgroup's tiles stay on its XCD; ngrid == nvirt: one tile each).  XCD-aware tile id (as
+  // gemm_fl_kernel): XCD x (= id mod 8) owns a contiguous range of tiles.  All the stages of all its tiles are ONE sequence for the
+  // ring protocol: the loaders run straight into the next tile while the consumers store the finished one, and those stores
+  // (straight from registers, asynchronous) drain under the next tile's MFMAs.
+  if ((int)blockIdx.x >= ngrid) return;                     // launch-tag workgroups (debug_hooks.h)
   const int nt = tiles_m * tiles_n;
-  if ((int)blockIdx.x >= nt * max(p.splitk, 1)) return;     // launch-tag workgroups (debug_hooks.h)
-  int pid = blockIdx.x;
-  const int zsplit = pid / nt;
-  pid -= zsplit * nt;
-  {
-    const int q = nt >> 3, r = nt & 7, xcd = pid & 7, idx = pid >> 3;
-    pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int m0 = (pid / tiles_n) * W4_BM, n0 = (pid % tiles_n) * BN;
-
   const int cpt = p.K1 / 64;  // 64-channel chunks (= stages per tap)
   const int ks1 = (MODE == W4_LINEAR ? 1 : 9) * cpt;
   const int ks2 = (MODE == W4_LINEAR) ? p.K2 / 64 : 0;
-  int kbeg = 0, kend = ks1 + ks2;
-  if (p.splitk > 1) {
-    const int per = (kend + p.splitk - 1) / p.splitk;
-    kbeg = zsplit * per;
-    kend = min(kend, kbeg + per);
-  }
-  const int total = kend - kbeg;                            // >= 1 (launcher)
+  struct Tile { int m0, n0, zsplit, kbeg, total; };
+  const int splitk = p.splitk, tn_ = tiles_n;
+  auto decode = [=](int v) __attribute__((always_inline)) -> Tile {                          // (by VALUE throughout: nothing here may end up address-taken)
+    int pid = v;
+    const int zs = pid / nt;
+    pid -= zs * nt;
+    {
+      const int q = nt >> 3, r = nt & 7, xcd = pid & 7, idx = pid >> 3;
+      pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int kb = 0, ke = ks1 + ks2;
+    if (splitk > 1) {
+      const int per = (ke + splitk - 1) / splitk;
+      kb = zs * per;
+      ke = min(ke, kb + per);
+    }
+    return Tile{(pid / tn_) * W4_BM, (pid % tn_) * BN, zs, kb, ke - kb};      // total >= 1 (launcher)
+  };
+  const Tile t0 = decode((int)blockIdx.x);                  // the first tile (HALO: the only one)
+  const int m0 = t0.m0, n0 = t0.n0, kbeg = t0.kbeg, total = t0.total;
   // HALO: stage index k = 9 chunk + tap; the tile's pixels are rows [py0, py0 + 256 / W) of image pb, all W columns
   const int Wp = HALO ? p.Win + 1 : 0;                      // pixel rows per image row of the LDS image (W pixels + one zero column)
   const int cc0 = HALO ? kbeg / 9 : 0, tap0 = HALO ? kbeg - cc0 * 9 : 0;
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
           pw[j] = (const char*)p.W1 + ((long)n * p.ldw1) * sizeof(T) + chunk;      // + (tap C + 64 chunk) 2 per stage
         }
         int tap = tap0, cc = cc0;
-        auto issue_w = [&](int slot) {
+        auto issue_w = [&](int slot) __attribute__((always_inline)) {
           char* Ws = smem + RING0 + slot * SLOT;
           const long koff = ((long)tap * p.K1 + (long)cc * 64) * sizeof(T);        // this stage's 64 K columns of W
           if constexpr (!W4_ABL(2)) {
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
       }
       // pieces [lo, hi) of the NEXT image into buffer `buf` (pieces past the image do not exist: this loader only ever waits for
       // everything); a piece's pointer then moves on a chunk
-      auto issue_image = [&](int buf, int lo, int hi) {
+      auto issue_image = [&](int buf, int lo, int hi) __attribute__((always_inline)) {
         char* Xb = smem + buf * XBUF;
 #pragma unroll
         for (int j = 0; j < W4_XJI; ++j)
@@ -281,7 +289,7 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
       // chunk c+1 (two stages ahead) waits for everything.
       int tap = tap0, cc = cc0, ibuf = 0;
       bool first = true;
-      auto step = [&]() {           // the step that (on the weight side) issues the stage (cc, tap)
+      auto step = [&]() __attribute__((always_inline)) {           // the step that (on the weight side) issues the stage (cc, tap)
         if (cc + 1 < cpt) {
           const int lo = first ? 0 : w4_pieces_lo(tap), hi = w4_pieces_hi(tap);
           if (hi > lo) issue_image(ibuf ^ 1, lo, hi);
@@ -311,67 +319,69 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
     const char* a2[XJ];
     uint32_t vmask[XJ];            // CONV_S1: bit t = tap t reads inside the image
     int ab[XJ], ay[XJ], ax[XJ];    // CONV_ANY: output pixel coordinates
+    const char* pw[WJ]; const char* w2[WJ];
+    const char* cur[XJ];
+    const long pixb = (long)p.lda1 * sizeof(T);
+    // wave-uniform walk over (tap, channel chunk) of the tile being issued
+    int kt_next = 0, tap = 0, cc = 0;
+    long tapoff = 0;
+    // per-lane sources of one tile
+    auto setup_tile = [&](int tm0, int tn0, int tkbeg) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < XJ; ++j) {
-      const int inst = j * W4_NL + lw;
-      const int chunk = (lslot ^ (((inst & 1) << 2) | (lrow >> 1))) * 16;
-      int r = m0 + inst * 8 + lrow;
-      r = min(r, p.M - 1);
-      a2[j] = nullptr; vmask[j] = 0; ab[j] = ay[j] = ax[j] = 0;
-      if constexpr (MODE == W4_LINEAR) {
-        const bool in2 = kbeg >= ks1;
-        a2[j] = p.A2 ? (const char*)p.A2 + ((long)r * p.lda2 + (p.a2_group_n ? (long)(n0 / p.a2_group_n) * p.K2 : 0)) * sizeof(T) + chunk
-                     : nullptr;
-        pa[j] = in2 ? a2[j] + (long)(kbeg - ks1) * 128
-                    : (const char*)p.A1 + ((long)r * p.lda1 + (p.a1_group_n ? (long)(n0 / p.a1_group_n) * p.K1 : 0)) * sizeof(T) +
-                          chunk + (long)kbeg * 128;
-      } else {
-        const int ox = r % p.Wout; const int t = r / p.Wout;
-        const int oy = t % p.Hout, ob = t / p.Hout;
-        if constexpr (MODE == W4_CONV_S1) {
-          pa[j] = (const char*)p.A1 + ((((long)ob * p.Hin + oy) * p.Win + ox) * p.lda1) * sizeof(T) + chunk;
-          uint32_t m = 0;
-#pragma unroll
-          for (int tp = 0; tp < 9; ++tp) {
-            const int vy = oy + tp / 3 - 1, vx = ox + tp % 3 - 1;
-            if (((unsigned)vy < (unsigned)p.Hin) & ((unsigned)vx < (unsigned)p.Win)) m |= 1u << tp;
-          }
-          vmask[j] = m;
+      for (int j = 0; j < XJ; ++j) {
+        const int inst = j * W4_NL + lw;
+        const int chunk = (lslot ^ (((inst & 1) << 2) | (lrow >> 1))) * 16;
+        int r = tm0 + inst * 8 + lrow;
+        r = min(r, p.M - 1);
+        a2[j] = nullptr; vmask[j] = 0; ab[j] = ay[j] = ax[j] = 0; cur[j] = nullptr;
+        if constexpr (MODE == W4_LINEAR) {
+          const bool in2 = tkbeg >= ks1;
+          a2[j] = p.A2 ? (const char*)p.A2 + ((long)r * p.lda2 + (p.a2_group_n ? (long)(tn0 / p.a2_group_n) * p.K2 : 0)) * sizeof(T) + chunk
+                       : nullptr;
+          pa[j] = in2 ? a2[j] + (long)(tkbeg - ks1) * 128
+                      : (const char*)p.A1 + ((long)r * p.lda1 + (p.a1_group_n ? (long)(tn0 / p.a1_group_n) * p.K1 : 0)) * sizeof(T) +
+                            chunk + (long)tkbeg * 128;
         } else {
-          pa[j] = (const char*)p.A1 + chunk;
-          ax[j] = ox; ay[j] = oy; ab[j] = ob;
+          const int ox = r % p.Wout; const int t = r / p.Wout;
+          const int oy = t % p.Hout, ob = t / p.Hout;
+          if constexpr (MODE == W4_CONV_S1) {
+            pa[j] = (const char*)p.A1 + ((((long)ob * p.Hin + oy) * p.Win + ox) * p.lda1) * sizeof(T) + chunk;
+            uint32_t m = 0;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+              const int vy = oy + tp / 3 - 1, vx = ox + tp % 3 - 1;
+              if (((unsigned)vy < (unsigned)p.Hin) & ((unsigned)vx < (unsigned)p.Win)) m |= 1u << tp;
+            }
+            vmask[j] = m;
+          } else {
+            pa[j] = (const char*)p.A1 + chunk;
+            ax[j] = ox; ay[j] = oy; ab[j] = ob;
+          }
         }
       }
-    }
-    const char* pw[WJ]; const char* w2[WJ];
 #pragma unroll
-    for (int j = 0; j < WJ; ++j) {
-      const int inst = j * W4_NL + lw;
-      const int chunk = (lslot ^ (((inst & 1) << 2) | (lrow >> 1))) * 16;
-      int n = n0 + inst * 8 + lrow;
-      n = min(n, p.N - 1);
-      w2[j] = (MODE == W4_LINEAR && p.W2) ? (const char*)p.W2 + ((long)n * p.ldw2) * sizeof(T) + chunk : nullptr;
-      pw[j] = (MODE == W4_LINEAR && kbeg >= ks1)
-                  ? w2[j] + (long)(kbeg - ks1) * 128
-                  : (const char*)p.W1 + ((long)n * p.ldw1) * sizeof(T) + chunk + (long)kbeg * 128;
-    }
-
-    // wave-uniform walk over (tap, channel chunk)
-    int kt_next = kbeg;
-    int tap = (MODE == W4_LINEAR) ? 0 : kbeg / cpt;
-    int cc = (MODE == W4_LINEAR) ? 0 : kbeg - tap * cpt;
-    const long pixb = (long)p.lda1 * sizeof(T);
-    long tapoff = 0;
-    const char* cur[XJ];
+      for (int j = 0; j < WJ; ++j) {
+        const int inst = j * W4_NL + lw;
+        const int chunk = (lslot ^ (((inst & 1) << 2) | (lrow >> 1))) * 16;
+        int n = tn0 + inst * 8 + lrow;
+        n = min(n, p.N - 1);
+        w2[j] = (MODE == W4_LINEAR && p.W2) ? (const char*)p.W2 + ((long)n * p.ldw2) * sizeof(T) + chunk : nullptr;
+        pw[j] = (MODE == W4_LINEAR && tkbeg >= ks1)
+                    ? w2[j] + (long)(tkbeg - ks1) * 128
+                    : (const char*)p.W1 + ((long)n * p.ldw1) * sizeof(T) + chunk + (long)tkbeg * 128;
+      }
+      kt_next = tkbeg;
+      tap = (MODE == W4_LINEAR) ? 0 : tkbeg / cpt;
+      cc = (MODE == W4_LINEAR) ? 0 : tkbeg - tap * cpt;
+      tapoff = 0;
+      if constexpr (MODE == W4_CONV_S1) {
+        tapoff = ((long)(tap / 3 - 1) * p.Win + (tap % 3 - 1)) * pixb;
 #pragma unroll
-    for (int j = 0; j < XJ; ++j) cur[j] = nullptr;
-    if constexpr (MODE == W4_CONV_S1) {
-      tapoff = ((long)(tap / 3 - 1) * p.Win + (tap % 3 - 1)) * pixb;
-#pragma unroll
-      for (int j = 0; j < XJ; ++j)   // a split-K workgroup may start in the middle of a tap
-        cur[j] = ((vmask[j] >> tap) & 1u) ? pa[j] + tapoff + (long)cc * 128 : zpage + (long)cc * 128;
-    }
-    auto issue = [&](int slot) {
+        for (int j = 0; j < XJ; ++j)   // a split-K workgroup may start in the middle of a tap
+          cur[j] = ((vmask[j] >> tap) & 1u) ? pa[j] + tapoff + (long)cc * 128 : zpage + (long)cc * 128;
+      }
+    };
+    auto issue = [&](int slot) __attribute__((always_inline)) {
       char* Xs = smem + RING0 + slot * SLOT;
       char* Ws = Xs + WOFF;
       if constexpr (W4_ABL(2)) { ++kt_next; return; }
@@ -427,17 +437,36 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
       ++kt_next;
     };
 
-    issue(0);
-    if (total > 1) { issue(1); w4_vm<GA>(); } else { w4_vm<0>(); }
+    // the stages of ALL this workgroup's tiles, in order: issue_next() moves on to the next tile when one is exhausted
+    int v = (int)blockIdx.x, left = total;
+    setup_tile(m0, n0, kbeg);
+    auto issue_next = [&](int slot) __attribute__((always_inline)) -> bool {
+      if (left == 0) {
+        v += ngrid;
+        if (v >= nvirt) return false;
+        const Tile t = decode(v);
+        setup_tile(t.m0, t.n0, t.kbeg);
+        left = t.total;
+      }
+      issue(slot);
+      --left;
+      return true;
+    };
+    issue_next(0);
+    bool nxt = issue_next(1);                                 // stage s+1 exists
+    if (nxt) w4_vm<GA>(); else w4_vm<0>();
     __builtin_amdgcn_s_barrier();                             // B_raw(0)
     __builtin_amdgcn_sched_barrier(0);
     int slot2 = 2;
-    for (int s = 0; s < total; ++s) {
+    bool curs = true;                                         // stage s exists
+    while (curs) {
       __builtin_amdgcn_s_barrier();                           // B_war(s-1): the slot of stage s-1 is free
       __builtin_amdgcn_sched_barrier(0);
-      if (s + 2 < total) { issue(slot2); w4_vm<GA>(); } else { w4_vm<0>(); }
+      const bool n2 = nxt ? issue_next(slot2) : false;
+      if (n2) w4_vm<GA>(); else w4_vm<0>();
       __builtin_amdgcn_s_barrier();                           // B_raw(s+1)
       __builtin_amdgcn_sched_barrier(0);
+      curs = nxt; nxt = n2;
       slot2 = (slot2 == W4_R - 1) ? 0 : slot2 + 1;
     }
     return;
@@ -467,7 +496,7 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
     }
   }
   int ctap = tap0, cbuf = 0;                    // HALO: tap / image buffer of the stage whose X addresses are in xa
-  auto halo_addr = [&](int tp, int buf) {
+  auto halo_addr = [&](int tp, int buf) __attribute__((always_inline)) {
     if constexpr (HALO) {
       const int ky = (tp * 11) >> 5, kx = tp - 3 * ky;
       const int toff = (ky - 1) * Wp + (kx - 1);
@@ -481,10 +510,6 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
   halo_addr(ctap, cbuf);
 
   f32x4_t acc[NW][4];
-#pragma unroll
-  for (int f = 0; f < NW; ++f)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[f][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   u32x4_t Xf[2][4], Wr[R];
 
   auto read_w = [&](auto Kc) {                  // W fragment k (0 .. G2-1 of the stage whose addresses are in wa) -> ring slot k % R
@@ -534,23 +559,35 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
   __builtin_amdgcn_s_barrier();                               // B_raw(0): stage 0 (and the first image) has landed
   __builtin_amdgcn_sched_barrier(0);
   W4_STAMP(1);
-  // the first reads, in the order the steady state issues them at the end of a stage (the counts of w4_sched assume it)
-  w4_for<0, R>([&](auto Kc) {
-    constexpr int k = decltype(Kc)::value;
-    read_w(Kc);
-    if constexpr (k == 0) { read_x(H0{}, std::integral_constant<int, 0>{}); read_x(H0{}, std::integral_constant<int, 1>{}); }
-    if constexpr (k == 1) { read_x(H0{}, std::integral_constant<int, 2>{}); read_x(H0{}, std::integral_constant<int, 3>{}); }
-  });
-  // (the accumulators were just written by v_accvgpr_write: wait states before the first MFMA reads them as SrcC)
-  w4_for<0, NW>([&](auto Fc) { constexpr int f = decltype(Fc)::value; w4_pad<true, (f < 8)>(acc[f][0], acc[f][1], acc[f][2], acc[f][3]); });
-  __builtin_amdgcn_sched_barrier(0);
+  // the first reads of a tile, in the order the steady state issues them at the end of a stage (the counts of w4_sched assume it)
+  auto first_reads = [&]() __attribute__((always_inline)) {
+    w4_for<0, R>([&](auto Kc) {
+      constexpr int k = decltype(Kc)::value;
+      read_w(Kc);
+      if constexpr (k == 0) { read_x(H0{}, std::integral_constant<int, 0>{}); read_x(H0{}, std::integral_constant<int, 1>{}); }
+      if constexpr (k == 1) { read_x(H0{}, std::integral_constant<int, 2>{}); read_x(H0{}, std::integral_constant<int, 3>{}); }
+    });
+  };
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int f = 0; f < NW; ++f)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[f][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // (the accumulators were just written by v_accvgpr_write: wait states before the first MFMA reads them as SrcC)
+    w4_for<0, NW>([&](auto Fc) { constexpr int f = decltype(Fc)::value; w4_pad<true, (f < 8)>(acc[f][0], acc[f][1], acc[f][2], acc[f][3]); });
+  };
 
-  // (slot / tap bookkeeping is done by the caller and passed BY VALUE: loop-carried integers captured by reference and updated inside
-  // the unrolled body ended up in scratch memory)
-  auto stage = [&](int slot, int ntap, int nbuf) {
+  // One stage = 2 NW groups of four MFMAs.  (slot / tap bookkeeping is done by the caller and passed BY VALUE: loop-carried
+  // integers captured by reference and updated inside the unrolled body ended up in scratch memory.)  TAIL = false is a tile's
+  // LAST stage: the reads behind group GB would be the next tile's first fragments -- they are issued after the epilogue instead
+  // (first_reads), so that no fragment register is live while compiler-scheduled code runs.
+  auto stage = [&](auto TAILc, int slot, int ntap, int nbuf) __attribute__((always_inline)) {
+    constexpr bool TAIL = decltype(TAILc)::value;
     w4_for<0, G2>([&](auto Gc) {
       constexpr int g = decltype(Gc)::value, h = g / NW, f = g % NW;
-      if constexpr (!W4_ABL(1)) w4_lgkm<w4_allow<NW, g>()>();
+      // (a tile's last stage issues nothing behind group GB: its groups there wait for what the steady state would allow minus
+      // those reads -- conservatively, everything)
+      if constexpr (!W4_ABL(1)) { if constexpr (TAIL || g <= GB) w4_lgkm<w4_allow<NW, g>()>(); else w4_lgkm<0>(); }
       w4_for<0, 4>([&](auto Ic) {
         constexpr int i = decltype(Ic)::value;
         if constexpr (!W4_ABL(32)) w4_mfma<(f < 8)>(acc[f][i], Wr[g % R], Xf[h][i]);
@@ -572,90 +609,105 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
         __builtin_amdgcn_s_barrier();                         // B_raw(s+1)
         __builtin_amdgcn_sched_barrier(0);
       }
-      if constexpr (g + R >= G2) read_w(std::integral_constant<int, g + R - G2>{});
+      if constexpr (TAIL) {
+        if constexpr (g + R >= G2) read_w(std::integral_constant<int, g + R - G2>{});
+        if constexpr (g == GB + 1) { read_x(H0{}, std::integral_constant<int, 0>{}); read_x(H0{}, std::integral_constant<int, 1>{}); }
+        if constexpr (g == GB + 2) { read_x(H0{}, std::integral_constant<int, 2>{}); read_x(H0{}, std::integral_constant<int, 3>{}); }
+      }
       if constexpr (g < 4) read_x(H1{}, std::integral_constant<int, g>{});
-      if constexpr (g == GB + 1) { read_x(H0{}, std::integral_constant<int, 0>{}); read_x(H0{}, std::integral_constant<int, 1>{}); }
-      if constexpr (g == GB + 2) { read_x(H0{}, std::integral_constant<int, 2>{}); read_x(H0{}, std::integral_constant<int, 3>{}); }
     });
   };
-  {
-    int slot = 0;                                             // slot of the stage being read
-    for (int s = 0; s < total; ++s) {
-      const bool twrap = ctap == 8;
-      const int ntap = twrap ? 0 : ctap + 1, nbuf = twrap ? (cbuf ^ 1) : cbuf;
-      stage(slot, ntap, nbuf);
-      slot = slot == W4_R - 1 ? 0 : slot + 1; ctap = ntap; cbuf = nbuf;
-    }
-  }
-  w4_lgkm<0>();                                               // (the stale reads behind the last stage: nothing in flight past here)
-  __builtin_amdgcn_sched_barrier(0);
-  W4_STAMP(2);
 
-  // ---- epilogue: an MFMA result may be read 8 passes after its issue; nothing padded that for an asm MFMA
-  w4_for<0, NW>([&](auto Fc) { constexpr int f = decltype(Fc)::value; w4_pad<false, (f < 8)>(acc[f][0], acc[f][1], acc[f][2], acc[f][3]); });
-  if (W4_ABL(4) || p.act == 77) { W4_STAMP(3); return; }      // act 77: timing probe only (skip the stores)
-  const EpiArgs e = epi_of(p);
-  const int row_w = m0 + wave * 64 + lr;
-  // Lane (m = lr, lane row lg) holds columns 4 lg + r of every 16-column block.  v_permlane16_swap of blocks (fa, fb): lane rows
-  // 0 / 2 end up with columns 0-7 / 8-15 of block fa, lane rows 1 / 3 with those of block fb -- 8 consecutive columns per lane
-  auto cols8 = [&](auto Fa, auto Fb, auto Ic, float (&v)[8]) {
-    constexpr int fa = decltype(Fa)::value, fb = decltype(Fb)::value, i = decltype(Ic)::value;
+  // ---- a finished tile: accumulators -> memory
+  auto epilogue = [&](int tm0, int tn0, int tz) __attribute__((always_inline)) {
+    // an MFMA result may be read 8 passes after its issue; nothing padded that for an asm MFMA
+    w4_for<0, NW>([&](auto Fc) { constexpr int f = decltype(Fc)::value; w4_pad<false, (f < 8)>(acc[f][0], acc[f][1], acc[f][2], acc[f][3]); });
+    if (W4_ABL(4) || p.act == 77) return;                     // act 77: timing probe only (skip the stores)
+    const EpiArgs e = epi_of(p);
+    const int row_w = tm0 + wave * 64 + lr;
+    // Lane (m = lr, lane row lg) holds columns 4 lg + r of every 16-column block.  v_permlane16_swap of blocks (fa, fb): lane rows
+    // 0 / 2 end up with columns 0-7 / 8-15 of block fa, lane rows 1 / 3 with those of block fb -- 8 consecutive columns per lane
+    auto cols8 = [&](auto Fa, auto Fb, auto Ic, float (&v)[8]) {
+      constexpr int fa = decltype(Fa)::value, fb = decltype(Fb)::value, i = decltype(Ic)::value;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[fa][i][r]), __float_as_uint(acc[fb][i][r]), false, false);
-      v[r] = __uint_as_float(sw[0]); v[4 + r] = __uint_as_float(sw[1]);
-    }
-  };
-  if (p.act == ACT_GEGLU && !slab) {
-    // value columns [0, 80) of the tile pair with gate columns [80, 160): block f with block f + 5, SAME lane and register --
-    // the products are formed in the accumulator layout, then blocks (0,1) (2,3) leave as 16-byte stores and block 4 as 8-byte ones
-    if constexpr (NW == 10) {
-      w4_for<0, 4>([&](auto Ic) {
-        constexpr int i = decltype(Ic)::value;
-        const int grow = row_w + 16 * i;
-        w4_for<0, 5>([&](auto Fc) {
-          constexpr int f = decltype(Fc)::value;
+      for (int r = 0; r < 4; ++r) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[fa][i][r]), __float_as_uint(acc[fb][i][r]), false, false);
+        v[r] = __uint_as_float(sw[0]); v[4 + r] = __uint_as_float(sw[1]);
+      }
+    };
+    if (p.act == ACT_GEGLU && !slab) {
+      // value columns [0, 80) of the tile pair with gate columns [80, 160): block f with block f + 5, SAME lane and register --
+      // the products are formed in the accumulator layout, then blocks (0,1) (2,3) leave as 16-byte stores and block 4 as 8-byte ones
+      if constexpr (NW == 10) {
+        w4_for<0, 4>([&](auto Ic) {
+          constexpr int i = decltype(Ic)::value;
+          const int grow = row_w + 16 * i;
+          w4_for<0, 5>([&](auto Fc) {
+            constexpr int f = decltype(Fc)::value;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int c = 16 * f + 4 * lg + r;
-            const float bv = e.bias ? e.bias[n0 + c] : 0.f, bg = e.bias ? e.bias[n0 + 80 + c] : 0.f;
-            acc[f][i][r] = (acc[f][i][r] + bv) * gelu_f(acc[f + 5][i][r] + bg);
-          }
-        });
-        w4_for<0, 2>([&](auto Qc) {
-          constexpr int q = decltype(Qc)::value;
-          float v[8];
-          cols8(std::integral_constant<int, 2 * q>{}, std::integral_constant<int, 2 * q + 1>{}, Ic, v);
-          const int c0 = 32 * q + 16 * (lg & 1) + 8 * (lg >> 1);
+            for (int r = 0; r < 4; ++r) {
+              const int c = 16 * f + 4 * lg + r;
+              const float bv = e.bias ? e.bias[tn0 + c] : 0.f, bg = e.bias ? e.bias[tn0 + 80 + c] : 0.f;
+              acc[f][i][r] = (acc[f][i][r] + bv) * gelu_f(acc[f + 5][i][r] + bg);
+            }
+          });
+          w4_for<0, 2>([&](auto Qc) {
+            constexpr int q = decltype(Qc)::value;
+            float v[8];
+            cols8(std::integral_constant<int, 2 * q>{}, std::integral_constant<int, 2 * q + 1>{}, Ic, v);
+            const int c0 = 32 * q + 16 * (lg & 1) + 8 * (lg >> 1);
+            if (grow < p.M) {
+              if (p.out_f32) store8(reinterpret_cast<float*>(e.C) + (long)grow * e.ldc + tn0 / 2 + c0, v);
+              else store8(reinterpret_cast<T*>(e.C) + (long)grow * e.ldc + tn0 / 2 + c0, v);
+            }
+          });
           if (grow < p.M) {
-            if (p.out_f32) store8(reinterpret_cast<float*>(e.C) + (long)grow * e.ldc + n0 / 2 + c0, v);
-            else store8(reinterpret_cast<T*>(e.C) + (long)grow * e.ldc + n0 / 2 + c0, v);
+            float v4[4] = {acc[4][i][0], acc[4][i][1], acc[4][i][2], acc[4][i][3]};
+            const int c0 = 64 + 4 * lg;
+            if (p.out_f32) store4(reinterpret_cast<float*>(e.C) + (long)grow * e.ldc + tn0 / 2 + c0, v4);
+            else store4(reinterpret_cast<T*>(e.C) + (long)grow * e.ldc + tn0 / 2 + c0, v4);
           }
         });
-        if (grow < p.M) {
-          float v4[4] = {acc[4][i][0], acc[4][i][1], acc[4][i][2], acc[4][i][3]};
-          const int c0 = 64 + 4 * lg;
-          if (p.out_f32) store4(reinterpret_cast<float*>(e.C) + (long)grow * e.ldc + n0 / 2 + c0, v4);
-          else store4(reinterpret_cast<T*>(e.C) + (long)grow * e.ldc + n0 / 2 + c0, v4);
+      }
+      return;
+    }
+    w4_for<0, 4>([&](auto Ic) {
+      constexpr int i = decltype(Ic)::value;
+      const int grow = row_w + 16 * i;
+      w4_for<0, NW / 2>([&](auto Qc) {
+        constexpr int q = decltype(Qc)::value;
+        float v[8];
+        cols8(std::integral_constant<int, 2 * q>{}, std::integral_constant<int, 2 * q + 1>{}, Ic, v);
+        const int gcol = tn0 + 32 * q + 16 * (lg & 1) + 8 * (lg >> 1);
+        if (grow < p.M && gcol < p.N) {
+          if (slab) store8(slab + ((long)tz * p.M + grow) * p.N + gcol, v);    // split-K partial: raw accumulators
+          else epilogue8<T>(e, v, grow, gcol);
         }
       });
-    }
-    return;
-  }
-  w4_for<0, 4>([&](auto Ic) {
-    constexpr int i = decltype(Ic)::value;
-    const int grow = row_w + 16 * i;
-    w4_for<0, NW / 2>([&](auto Qc) {
-      constexpr int q = decltype(Qc)::value;
-      float v[8];
-      cols8(std::integral_constant<int, 2 * q>{}, std::integral_constant<int, 2 * q + 1>{}, Ic, v);
-      const int gcol = n0 + 32 * q + 16 * (lg & 1) + 8 * (lg >> 1);
-      if (grow < p.M && gcol < p.N) {
-        if (slab) store8(slab + ((long)zsplit * p.M + grow) * p.N + gcol, v);    // split-K partial: raw accumulators
-        else epilogue8<T>(e, v, grow, gcol);
-      }
     });
-  });
+  };
+
+  // ---- the tiles of this workgroup
+  int slot = 0;                                               // ring slot of the stage being read (runs on across tiles)
+  for (int v = (int)blockIdx.x; v < nvirt; v += ngrid) {
+    const Tile t = decode(v);
+    const int tm0 = t.m0, tn0 = t.n0, tz = t.zsplit, tt = t.total;
+    zero_acc();
+    first_reads();
+    __builtin_amdgcn_sched_barrier(0);
+    auto advance = [&](auto TAILc) __attribute__((always_inline)) {
+      const bool twrap = ctap == 8;
+      const int ntap = twrap ? 0 : ctap + 1, nbuf = twrap ? (cbuf ^ 1) : cbuf;
+      stage(TAILc, slot, ntap, nbuf);
+      slot = slot == W4_R - 1 ? 0 : slot + 1; ctap = ntap; cbuf = nbuf;
+    };
+    for (int s = 0; s + 1 < tt; ++s) advance(std::true_type{});
+    advance(std::false_type{});
+    w4_lgkm<0>();                                             // (nothing of the consumers' own is in flight past here)
+    __builtin_amdgcn_sched_barrier(0);
+    if (v == (int)blockIdx.x) W4_STAMP(2);
+    epilogue(tm0, tn0, tz);
+  }
 #ifdef W4_PROBE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   W4_STAMP(3);
@@ -663,14 +715,18 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
 }
 
 template <int NW, int MODE, int ABL = 0>
-int launch_w4_mode(const GemmParams& p0, hipStream_t stream) {
+int launch_w4_mode(const GemmParams& p0, hipStream_t stream, bool persist = false) {
   constexpr int BN = 16 * NW;
   constexpr int SMEM = MODE == W4_CONV_HALO ? 2 * W4_HROWS * 128 + W4_R * (BN / 8) * 1024 : W4_R * (W4_BM / 8 + BN / 8) * 1024;
   auto kern = &gemm_w4_kernel<NW, MODE, ABL>;
   static bool attr_set = false;
+  static int cus = 256;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
       return CL_ELAUNCH;
+    int dev = 0; hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+      cus = pr.multiProcessorCount;
     attr_set = true;
   }
   if ((p0.a1_group_n && p0.a1_group_n % BN) || (p0.a2_group_n && p0.a2_group_n % BN)) return CL_EINVAL;   // a tile would straddle groups
@@ -681,8 +737,13 @@ int launch_w4_mode(const GemmParams& p0, hipStream_t stream) {
   float* slab;
   gemm_pick_splitk(p, tiles, steps, 256, 4, &slab, stream);
   const long nvirt = tiles * p.splitk;
-  gemm_tag_note(nvirt, 64 * (W4_NC + W4_NL));
-  hipLaunchKernelGGL(kern, dim3((unsigned)(nvirt + gemm_cur_tag())), dim3(64 * (W4_NC + W4_NL)), SMEM, stream, p, tm, tn, slab);
+  // persistent form: one workgroup per CU (LDS admits no second one) walks virtual ids id, id + grid, ...; a multiple of 8 so that
+  // id mod 8 -- the XCD -- is the same for every tile of a workgroup.  The halo form is one tile per workgroup (launcher's rule).
+  long grid = nvirt;
+  if (persist && MODE != W4_CONV_HALO && nvirt > cus) grid = cus - cus % 8;
+  gemm_tag_note(grid, 64 * (W4_NC + W4_NL));
+  hipLaunchKernelGGL(kern, dim3((unsigned)(grid + gemm_cur_tag())), dim3(64 * (W4_NC + W4_NL)), SMEM, stream, p, tm, tn, slab, (int)nvirt,
+                     (int)grid);
   if (slab) gemm_launch_splitk_reduce_bf16(p, slab, stream);
   CL_CHECK_LAUNCH();
   return CL_OK;
@@ -696,25 +757,27 @@ bool w4_halo_ok(const GemmParams& p) {
 }
 
 template <int NW>
-int launch_w4_nw(const GemmParams& p, hipStream_t stream) {
-  if (p.mode == GEMM_LINEAR) return launch_w4_mode<NW, W4_LINEAR>(p, stream);
+int launch_w4_nw(const GemmParams& p, hipStream_t stream, bool persist) {
+  if (p.mode == GEMM_LINEAR) return launch_w4_mode<NW, W4_LINEAR>(p, stream, persist);
   if (p.K2) return CL_EINVAL;   // a second K segment exists for linear operands only
 #ifdef W4_PROBE
   if constexpr (NW == 10) {
     if (p.mode == GEMM_CONV_S1 && g_w4_abl_host) {
-      const bool halo = g_w4_halo_host && w4_halo_ok(p);
+      const bool halo = g_w4_halo_host && w4_halo_ok(p) && !persist;
       switch (g_w4_abl_host) {
-#define W4_CASE(a) case a: return halo ? launch_w4_mode<NW, W4_CONV_HALO, a>(p, stream) : launch_w4_mode<NW, W4_CONV_S1, a>(p, stream);
+#define W4_CASE(a) case a: return halo ? launch_w4_mode<NW, W4_CONV_HALO, a>(p, stream) : launch_w4_mode<NW, W4_CONV_S1, a>(p, stream, persist);
         W4_CASE(1) W4_CASE(2) W4_CASE(3) W4_CASE(4) W4_CASE(5) W4_CASE(6) W4_CASE(7) W4_CASE(37)
 #undef W4_CASE
         default: break;
       }
     }
   }
-  if (p.mode == GEMM_CONV_S1 && !g_w4_halo_host) return launch_w4_mode<NW, W4_CONV_S1>(p, stream);
+  if (p.mode == GEMM_CONV_S1 && !g_w4_halo_host) return launch_w4_mode<NW, W4_CONV_S1>(p, stream, persist);
 #endif
-  if (p.mode == GEMM_CONV_S1) return w4_halo_ok(p) ? launch_w4_mode<NW, W4_CONV_HALO>(p, stream) : launch_w4_mode<NW, W4_CONV_S1>(p, stream);
-  return launch_w4_mode<NW, W4_CONV_ANY>(p, stream);
+  // (persistent: the per-tap form -- the halo form's image hand-over is per workgroup, not per tile)
+  if (p.mode == GEMM_CONV_S1)
+    return (w4_halo_ok(p) && !persist) ? launch_w4_mode<NW, W4_CONV_HALO>(p, stream) : launch_w4_mode<NW, W4_CONV_S1>(p, stream, persist);
+  return launch_w4_mode<NW, W4_CONV_ANY>(p, stream, persist);
 }
 
 }  // namespace
@@ -726,12 +789,12 @@ void w4_timing_set(unsigned long long* buf) { (void)hipMemcpyToSymbol(HIP_SYMBOL
 #endif
 
 // CL_EINVAL = "not a product this kernel covers" (the caller falls back to the other tile kernels)
-int launch_gemm_w4(const GemmParams& p, hipStream_t stream, int bn) {
+int launch_gemm_w4(const GemmParams& p, hipStream_t stream, int bn, int persist) {
   if (p.atomic || p.K1 % 64 || p.K2 % 64 || p.K1 <= 0) return CL_EINVAL;
   if (p.act == ACT_GEGLU && bn != 160) return CL_EINVAL;
   if (p.act == ACT_GEGLU_SPLIT || p.ln_gamma) return CL_EINVAL;
-  if (bn == 160) return launch_w4_nw<10>(p, stream);
-  if (bn == 128) return launch_w4_nw<8>(p, stream);
+  if (bn == 160) return launch_w4_nw<10>(p, stream, persist != 0);
+  if (bn == 128) return launch_w4_nw<8>(p, stream, persist != 0);
   return CL_EINVAL;
 }
 

@@ -155,16 +155,16 @@ def lib():
             if "CTRLORA_GEMM_TABLE" not in os.environ:
                 if XS_ENABLED:  # round 5: signatures the x-stationary kernel (csrc/gemm_xs.hip, configuration 34) won
                     load_gemm_table(GEMM_XS_TABLE_PATH, clear=False)
-                if W4_ENABLED and os.path.exists(GEMM_W4_TABLE_PATH):   # round 6: the loader / consumer kernel (csrc/gemm_w4.hip, 40 / 41)
-                    load_gemm_table(GEMM_W4_TABLE_PATH, clear=False)
+                if R06_ENABLED and os.path.exists(GEMM_R06_TABLE_PATH):   # round 6: the loader / consumer kernel (csrc/gemm_w4.hip,
+                    load_gemm_table(GEMM_R06_TABLE_PATH, clear=False)     # 40 / 41) and the deep-ring small tiles (42 .. 46)
     return _lib
 
 
 GEMM_TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tuned_gfx950.json")
 GEMM_XS_TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tuned_gfx950_xs.json")
-GEMM_W4_TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tuned_gfx950_w4.json")
-# A/B switch: 0 = no product goes to the loader / consumer tile kernel
-W4_ENABLED = os.environ.get("CTRLORA_GEMM_W4", "1") != "0"
+GEMM_R06_TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tuned_gfx950_r06.json")
+# A/B switch: 0 = the round-6 overlay (configurations 40 .. 46) is not loaded
+R06_ENABLED = os.environ.get("CTRLORA_GEMM_R06", "1") != "0"
 # A/B switch: 0 = no product goes to the x-stationary streaming kernel (neither through the launch table nor as the fused
 # GEGLU projection of the no-grad forwards)
 XS_ENABLED = os.environ.get("CTRLORA_GEMM_XS", "1") != "0"

@@ -44,7 +44,7 @@ def test_xs_overlay_table_layers_over_the_base_table():
     n_base = hip.load_gemm_table(hip.GEMM_TABLE_PATH)
     n_all = hip.load_gemm_table(hip.GEMM_XS_TABLE_PATH, clear=False)
     assert n_all == len({tuple(r[:7]) for r in base} | {tuple(r[:7]) for r in over}) >= n_base
-    assert L.cl_gemm_tune_set(0, 0, 64, 64, 64, 0, 0, 36, 0) == 0 and L.cl_gemm_tune_set(0, 0, 64, 64, 64, 0, 0, 37, 0) != 0
+    assert L.cl_gemm_tune_set(0, 0, 64, 64, 64, 0, 0, 48, 0) == 0 and L.cl_gemm_tune_set(0, 0, 64, 64, 64, 0, 0, 49, 0) != 0
     hip.load_gemm_table(hip.GEMM_TABLE_PATH)
     hip.load_gemm_table(hip.GEMM_XS_TABLE_PATH, clear=False)
 

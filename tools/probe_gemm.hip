@@ -846,7 +846,7 @@ int main(int argc, char** argv) {
     const bool abl_only = argc > 2 && !strcmp(argv[2], "abl");
     if (abl_only) goto w4_ablations;
     {
-    const int cf[] = {40, 41};
+    const int cf[] = {40, 41, 47, 48};
     for (int c : cf) { char tag[32]; snprintf(tag, 32, "forced cfg %d", c); g_gemm_force_cfg = c; correctness_suite(tag); }
     g_gemm_force_cfg = -1;
     conv_sampled("conv 320->320 @64^2 B2 sampled vs fp64, cfg 40", 40, 2, 64, 64, 320, 320, 4000);
@@ -856,27 +856,32 @@ int main(int argc, char** argv) {
     conv_sampled("conv 1280->320 @16^2 B4 sampled (halo, split-K), cfg 40", 40, 4, 16, 16, 1280, 320, 4000);
     conv_sampled("conv 64->160 @64^2 B1 sampled (halo, one chunk), cfg 40", 40, 1, 64, 64, 64, 160, 4000);
     conv_sampled("conv 128->128 @32^2 B3 sampled (halo), cfg 41", 41, 3, 32, 32, 128, 128, 4000);
-    const int ab[] = {16, 40}, ab128[] = {17, 41};
-    ab_case("conv 320->320 @64^2 B8", GEMM_CONV_S1, 8 * 64 * 64, 320, 320, 8, 64, 64, 0, ab, 2, 7);
-    ab_case("conv 320->320 @64^2 B8 rowbias+silu", GEMM_CONV_S1, 8 * 64 * 64, 320, 320, 8, 64, 64, 0, ab, 2, 3, false, true);
-    ab_case("conv 320->320 @64^2 B32 (DDIM)", GEMM_CONV_S1, 32 * 64 * 64, 320, 320, 32, 64, 64, 0, ab, 2, 3);
-    ab_case("conv 960->320 @64^2 B8", GEMM_CONV_S1, 8 * 64 * 64, 320, 960, 8, 64, 64, 0, ab, 2, 3);
-    ab_case("conv 640->320 @64^2 B8 + residual", GEMM_CONV_S1, 8 * 64 * 64, 320, 640, 8, 64, 64, 0, ab, 2, 3, true);
-    ab_case("conv 640->640 @32^2 B8", GEMM_CONV_S1, 8 * 32 * 32, 640, 640, 8, 32, 32, 0, ab, 2, 3);
-    ab_case("conv 1280->1280 @16^2 B8", GEMM_CONV_S1, 8 * 16 * 16, 1280, 1280, 8, 16, 16, 0, ab, 2, 3);
-    ab_case("conv 2560->1280 @16^2 B8", GEMM_CONV_S1, 8 * 16 * 16, 1280, 2560, 8, 16, 16, 0, ab, 2, 3);
-    ab_case("conv 1280->1280 @8^2 B8 (split-K)", GEMM_CONV_S1, 8 * 8 * 8, 1280, 1280, 8, 8, 8, 0, ab, 2, 3);
-    ab_case("conv 128->128 @256^2 B4 (VAE)", GEMM_CONV_S1, 4 * 256 * 256, 128, 128, 4, 256, 256, 0, ab128, 2, 3);
-    ab_case("conv 256->256 @128^2 B4 (VAE)", GEMM_CONV_S1, 4 * 128 * 128, 256, 256, 4, 128, 128, 0, ab128, 2, 3);
-    ab_case("gemm 4096^3", GEMM_LINEAR, 4096, 4096, 4096, 0, 0, 0, 0, ab128, 2, 3);
-    ab_case("gemm 32768x320x1280 (FF out)", GEMM_LINEAR, 32768, 320, 1280, 0, 0, 0, 0, ab, 2, 3);
-    ab_case("gemm 32768x320x1280+128 (FF out, LoRA)", GEMM_LINEAR, 32768, 320, 1280, 0, 0, 0, 128, ab, 2, 3, true);
-    ab_case("gemm 8192x640x2560 (FF out 32^2)", GEMM_LINEAR, 8192, 640, 2560, 0, 0, 0, 0, ab, 2, 3);
+    conv_sampled("conv 320->320 @64^2 B32 sampled, persistent cfg 47 (4 tiles per CU)", 47, 32, 64, 64, 320, 320, 6000);
+    conv_sampled("conv 128->128 @256^2 B2 sampled, persistent cfg 48", 48, 2, 256, 256, 128, 128, 6000);
+    conv_sampled("conv 640->320 ragged 5x33x31 sampled, persistent cfg 47", 47, 5, 33, 31, 640, 320, 4000);
+    const int ab[] = {16, 40, 47}, ab128[] = {17, 41, 48};
+    ab_case("conv 320->320 @64^2 B8", GEMM_CONV_S1, 8 * 64 * 64, 320, 320, 8, 64, 64, 0, ab, 3, 7);
+    ab_case("conv 320->320 @64^2 B8 rowbias+silu", GEMM_CONV_S1, 8 * 64 * 64, 320, 320, 8, 64, 64, 0, ab, 3, 3, false, true);
+    ab_case("conv 320->320 @64^2 B32 (DDIM)", GEMM_CONV_S1, 32 * 64 * 64, 320, 320, 32, 64, 64, 0, ab, 3, 3);
+    ab_case("conv 960->320 @64^2 B8", GEMM_CONV_S1, 8 * 64 * 64, 320, 960, 8, 64, 64, 0, ab, 3, 3);
+    ab_case("conv 640->320 @64^2 B8 + residual", GEMM_CONV_S1, 8 * 64 * 64, 320, 640, 8, 64, 64, 0, ab, 3, 3, true);
+    ab_case("conv 640->640 @32^2 B8", GEMM_CONV_S1, 8 * 32 * 32, 640, 640, 8, 32, 32, 0, ab, 3, 3);
+    ab_case("conv 1280->1280 @16^2 B8", GEMM_CONV_S1, 8 * 16 * 16, 1280, 1280, 8, 16, 16, 0, ab, 3, 3);
+    ab_case("conv 2560->1280 @16^2 B8", GEMM_CONV_S1, 8 * 16 * 16, 1280, 2560, 8, 16, 16, 0, ab, 3, 3);
+    ab_case("conv 1280->1280 @8^2 B8 (split-K)", GEMM_CONV_S1, 8 * 8 * 8, 1280, 1280, 8, 8, 8, 0, ab, 3, 3);
+    ab_case("conv 128->128 @256^2 B4 (VAE)", GEMM_CONV_S1, 4 * 256 * 256, 128, 128, 4, 256, 256, 0, ab128, 3, 3);
+    ab_case("conv 256->256 @128^2 B4 (VAE)", GEMM_CONV_S1, 4 * 128 * 128, 256, 256, 4, 128, 128, 0, ab128, 3, 3);
+    ab_case("gemm 4096^3", GEMM_LINEAR, 4096, 4096, 4096, 0, 0, 0, 0, ab128, 3, 3);
+    ab_case("gemm 32768x320x1280 (FF out)", GEMM_LINEAR, 32768, 320, 1280, 0, 0, 0, 0, ab, 3, 3);
+    ab_case("gemm 32768x320x1280+128 (FF out, LoRA)", GEMM_LINEAR, 32768, 320, 1280, 0, 0, 0, 128, ab, 3, 3, true);
+    ab_case("gemm 8192x640x2560 (FF out 32^2)", GEMM_LINEAR, 8192, 640, 2560, 0, 0, 0, 0, ab, 3, 3);
+    ab_case("gemm 131072x320x1280 (FF out, DDIM)", GEMM_LINEAR, 131072, 320, 1280, 0, 0, 0, 0, ab, 3, 3);
+    ab_case("conv 128->128 @512^2 B2 (VAE)", GEMM_CONV_S1, 2 * 512 * 512, 128, 128, 2, 512, 512, 0, ab128, 3, 3);
     if (!quick) {
-      ab_case("gemm 32768x320x320", GEMM_LINEAR, 32768, 320, 320, 0, 0, 0, 0, ab, 2, 3);
-      ab_case("gemm 32768x2560x320", GEMM_LINEAR, 32768, 2560, 320, 0, 0, 0, 0, ab, 2, 3);
-      ab_case("gemm 2048x1280x1280", GEMM_LINEAR, 2048, 1280, 1280, 0, 0, 0, 0, ab, 2, 3);
-      ab_case("gemm 8192x640x640", GEMM_LINEAR, 8192, 640, 640, 0, 0, 0, 0, ab, 2, 3);
+      ab_case("gemm 32768x320x320", GEMM_LINEAR, 32768, 320, 320, 0, 0, 0, 0, ab, 3, 3);
+      ab_case("gemm 32768x2560x320", GEMM_LINEAR, 32768, 2560, 320, 0, 0, 0, 0, ab, 3, 3);
+      ab_case("gemm 2048x1280x1280", GEMM_LINEAR, 2048, 1280, 1280, 0, 0, 0, 0, ab, 3, 3);
+      ab_case("gemm 8192x640x640", GEMM_LINEAR, 8192, 640, 640, 0, 0, 0, 0, ab, 3, 3);
     }
     }
 w4_ablations:
