@@ -51,6 +51,31 @@ __device__ __forceinline__ void epilogue8(const EpiArgs& e, float v[8], int grow
   }
 }
 
+// the same minus bias / row-bias (the caller has added them), for the loader / consumer kernel: the residual's 16 bytes were
+// fetched ahead (vmcnt retires in order -- a load issued behind a tile's stores would wait for them to drain), and the output
+// element offset is 32-bit (one VGPR per unit instead of a pointer pair; the launcher checks the range)
+__device__ __forceinline__ void epilogue8_tail_bf16(const EpiArgs& e, float v[8], unsigned off_c, int gcol, uint4 rs) {
+  if (e.act == ACT_SILU) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = silu_f(v[i]);
+  }
+  const float al = (e.alpha_n > 0 && gcol >= e.alpha_n) ? 1.0f : e.alpha;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] *= al;
+  if (e.residual) {
+    const uint32_t w[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] += e.beta * __uint_as_float(w[i] << 16);
+      v[2 * i + 1] += e.beta * __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  if (e.out_f32) store8(reinterpret_cast<float*>(e.C) + off_c, v);
+  else {
+    store8(reinterpret_cast<bf16_t*>(e.C) + off_c, v);
+  }
+}
+
 __device__ __forceinline__ EpiArgs epi_of(const GemmParams& p) {
   EpiArgs e;
   e.bias = p.bias; e.rowbias = p.rowbias; e.ldrb = p.ldrb; e.rows_per_batch = p.rows_per_batch;

@@ -147,6 +147,19 @@ constexpr int W4_XJI = 25;                        // HALO: image DMA instruction
 __host__ __device__ constexpr int w4_pieces_lo(int t) { return t < 2 ? 0 : 4 * (t - 2); }
 __host__ __device__ constexpr int w4_pieces_hi(int t) { return t < 2 ? 0 : (4 * (t - 2) + 4 > W4_XJI ? W4_XJI : 4 * (t - 2) + 4); }
 
+// the row-bias of a tile can sit in LDS (one row of it) iff all the tile's rows belong to one batch element
+__device__ __forceinline__ bool w4_rb_uniform(const GemmParams& p, int tm0) {
+  if (!p.rowbias) return false;
+  const int last = min(tm0 + W4_BM, p.M) - 1;
+  return tm0 / p.rows_per_batch == last / p.rows_per_batch;
+}
+// an accumulator register as a VGPR operand.  (Left to the compiler, the copies out of the AGPR half went through SCRATCH: a
+// store / reload pair per quad, and every reload's vmcnt(0) also waited for the tile's global stores to drain.)
+template <bool AG> __device__ __forceinline__ float w4_get(float a) {
+  if constexpr (AG) { float x; asm("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a)); return x; }
+  else return a;
+}
+
 // NW: 16-column fragment blocks per tile row (BN = 16 NW: 10 -> 160, 8 -> 128).
 template <int NW, int MODE, int ABL = 0>
 __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParams p, int tiles_m, int tiles_n,
@@ -162,8 +175,9 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
   constexpr int SLOT = HALO ? WI * 1024 : (XI + WI) * 1024;
   constexpr int RING0 = HALO ? 2 * XBUF : 0;            // byte offset of the ring
   constexpr int WOFF = HALO ? 0 : XI * 1024;            // W rows inside a slot
+  constexpr int EPI0 = RING0 + W4_R * SLOT;             // two 1 KB blocks (tile parity): the epilogue's bias / row-bias operands
   static_assert(WI % W4_NL == 0 && G2 % R == 0 && NW % 2 == 0, "uniform DMA counts; the W ring is periodic per stage");
-  static_assert(RING0 + W4_R * SLOT <= 160 * 1024, "LDS");
+  static_assert(EPI0 + 2048 <= 160 * 1024 && BN * 4 + BN * 2 <= 1024, "LDS");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -208,19 +222,39 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
     const int lw = wave - W4_NC;
     const int lrow = lane >> 3, lslot = lane & 7;
     const char* zpage = (const char*)p.zero_page + lslot * 16;
+    // A tile's epilogue operands -> LDS (1 KB: BN bias floats, then BN row-bias bf16 when the tile's rows share a batch element):
+    // ONE DMA instruction by loader 0, issued ahead of the tile's first stage, so that it has landed when that stage has.  The
+    // consumers' epilogue then reads LDS only: a global load there would queue behind the stores.  Lanes without a source (no
+    // bias / row-bias, columns past N) are masked off -- the epilogue reads only what was brought (linear calls have no zero page).
+    auto issue_epi = [&](int tm0, int tn0, int par) __attribute__((always_inline)) {
+      if (lw != 0 || slab) return;
+      const char* src = nullptr;
+      if (lane < BN / 4) {
+        const int c = tn0 + 4 * lane;
+        if (p.bias && c < p.N) src = (const char*)(p.bias + c);
+      } else if (lane < BN / 4 + BN / 8) {
+        const int c = tn0 + 8 * (lane - BN / 4);
+        if (w4_rb_uniform(p, tm0) && c < p.N)
+          src = (const char*)(reinterpret_cast<const T*>(p.rowbias) + (long)(tm0 / p.rows_per_batch) * p.ldrb + c);
+      }
+      if constexpr (!W4_ABL(2)) { if (src) glds16(src, smem + EPI0 + par * 1024); }
+    };
     if constexpr (HALO) {
       // ---- HALO: waves 4-5 stream the weight tiles, waves 6-7 the image pieces (see the top)
       if (lw < 2) {
         constexpr int WJ2 = WI / 2;                           // weight DMA instructions per stage and weight loader
         const char* pw[WJ2];
+        auto setup_w = [&](int tn0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < WJ2; ++j) {
-          const int inst = j * 2 + lw;
-          const int chunk = (lslot ^ (((inst & 1) << 2) | (lrow >> 1))) * 16;
-          int n = n0 + inst * 8 + lrow;
-          n = min(n, p.N - 1);
-          pw[j] = (const char*)p.W1 + ((long)n * p.ldw1) * sizeof(T) + chunk;      // + (tap C + 64 chunk) 2 per stage
-        }
+          for (int j = 0; j < WJ2; ++j) {
+            const int inst = j * 2 + lw;
+            const int chunk = (lslot ^ (((inst & 1) << 2) | (lrow >> 1))) * 16;
+            int n = tn0 + inst * 8 + lrow;
+            n = min(n, p.N - 1);
+            pw[j] = (const char*)p.W1 + ((long)n * p.ldw1) * sizeof(T) + chunk;      // + (tap C + 64 chunk) 2 per stage
+          }
+        };
+        setup_w(n0);
         int tap = tap0, cc = cc0;
         auto issue_w = [&](int slot) __attribute__((always_inline)) {
           char* Ws = smem + RING0 + slot * SLOT;
@@ -231,18 +265,39 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
           }
           if (++tap == 9) { tap = 0; ++cc; }
         };
+        // the stages of all this workgroup's tiles in order (a further tile exists in the persistent form only: whole K ranges)
+        int v = (int)blockIdx.x, left = total, tpar = 0;
+        issue_epi(m0, n0, 0);
+        auto next_w = [&](int slot) __attribute__((always_inline)) -> bool {
+          if (left == 0) {
+            v += ngrid;
+            if (v >= nvirt) return false;
+            const Tile t = decode(v);
+            setup_w(t.n0);
+            tap = 0; cc = 0; left = t.total;
+            tpar ^= 1;
+            issue_epi(t.m0, t.n0, tpar);
+          }
+          issue_w(slot);
+          --left;
+          return true;
+        };
         constexpr int GW = W4_ABL(2) ? 0 : WJ2;
-        issue_w(0);
-        if (total > 1) { issue_w(1); w4_vm<GW>(); } else { w4_vm<0>(); }
+        next_w(0);
+        bool nxt = next_w(1);
+        if (nxt) w4_vm<GW>(); else w4_vm<0>();
         __builtin_amdgcn_s_barrier();                         // B_raw(0)
         __builtin_amdgcn_sched_barrier(0);
         int slot2 = 2;
-        for (int s = 0; s < total; ++s) {
+        bool curs = true;
+        while (curs) {
           __builtin_amdgcn_s_barrier();                       // B_war(s-1): the slot of stage s-1 is free
           __builtin_amdgcn_sched_barrier(0);
-          if (s + 2 < total) { issue_w(slot2); w4_vm<GW>(); } else { w4_vm<0>(); }
+          const bool n2 = nxt ? next_w(slot2) : false;
+          if (n2) w4_vm<GW>(); else w4_vm<0>();
           __builtin_amdgcn_s_barrier();                       // B_raw(s+1)
           __builtin_amdgcn_sched_barrier(0);
+          curs = nxt; nxt = n2;
           slot2 = (slot2 == W4_R - 1) ? 0 : slot2 + 1;
         }
         return;
@@ -250,13 +305,13 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
       // image loader il = 0 / 1: pieces il, il + 2, ... of every image (W4_XJI each; past the image: the last piece again)
       const int il = lw - 2;
       const int hw = p.Hin * p.Win;
-      const int pb = m0 / hw, py0 = (m0 - pb * hw) / p.Win, rows = W4_BM / p.Win;
+      const int rows = W4_BM / p.Win;
       const int nrow = (rows + 2) * Wp + 1;
       const int ninst = (nrow + 7) / 8;
       // piece j of this loader = image rows 8 (2 j + il) + lrow: (hy, hx) walk on by 16 rows per piece (W + 1 >= 17: one wrap at most).
-      // The FIRST image is brought by the consumer waves (they idle until stage 0 has landed): pointers start at chunk cc0 + 1.
       const char* pa[W4_XJI];
-      {
+      auto set_pa = [&](int tm0, int chunk0) __attribute__((always_inline)) {     // pointers of the tile at rows tm0, 64-channel chunk chunk0
+        const int pb = tm0 / hw, py0 = (tm0 - pb * hw) / p.Win;
         int hr = il * 8 + lrow;
         int hy = hr / Wp, hx = hr - hy * Wp;
 #pragma unroll
@@ -265,12 +320,14 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
           const int chunk = (lslot ^ (((inst & 1) << 2) | (lrow >> 1))) * 16;
           const int y = py0 - 1 + hy, x = hx - 1;        // (hx = 0: the zero column)
           const bool ok = hr < nrow && (unsigned)y < (unsigned)p.Hin && (unsigned)x < (unsigned)p.Win;
-          pa[j] = ok ? (const char*)p.A1 + ((((long)pb * p.Hin + y) * p.Win + x) * p.lda1) * sizeof(T) + chunk + (long)(cc0 + 1) * 128
-                     : zpage + (long)(cc0 + 1) * 128;
+          pa[j] = ok ? (const char*)p.A1 + ((((long)pb * p.Hin + y) * p.Win + x) * p.lda1) * sizeof(T) + chunk + (long)chunk0 * 128
+                     : zpage + (long)chunk0 * 128;
           hr += 16; hx += 16;
           if (hx >= Wp) { hx -= Wp; ++hy; }
         }
-      }
+      };
+      // The FIRST image is brought by the consumer waves (they idle until stage 0 has landed): pointers start at chunk cc0 + 1.
+      set_pa(m0, cc0 + 1);
       // pieces [lo, hi) of the NEXT image into buffer `buf` (pieces past the image do not exist: this loader only ever waits for
       // everything); a piece's pointer then moves on a chunk
       auto issue_image = [&](int buf, int lo, int hi) __attribute__((always_inline)) {
@@ -283,35 +340,49 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
             pa[j] += 128;
           }
       };
-      // The pieces of chunk c+1 ride on the steps that issue taps 2 .. 8 of chunk c (the loaders run two stages ahead; the buffer
-      // was read until chunk c-1's last tap); the first step of a split-K range also carries what the taps before it would have
-      // (nothing has been read yet).  They must have landed at the B_raw of chunk c+1's first stage: the step that issues tap 1 of
-      // chunk c+1 (two stages ahead) waits for everything.
-      int tap = tap0, cc = cc0, ibuf = 0;
+      // The pieces of the next image ride on the steps that issue taps 2 .. 8 of the current chunk (the loaders run two stages
+      // ahead; the buffer was read until the previous chunk's last tap); the first step of a split-K range also carries what the
+      // taps before it would have (nothing has been read yet).  The next image is the tile's next chunk or -- persistent form,
+      // whole K ranges only -- the first chunk of the workgroup's next tile: the pointers are re-made on the step of tap 2, when
+      // every piece of the tile's own last image has gone out.  They must have landed at the B_raw of the image's first stage:
+      // the step that issues tap 1 of it (two stages ahead) waits for everything.
+      int v = (int)blockIdx.x, left = total, tap = tap0, cc = cc0, ibuf = 0;
+      int cclast = (kbeg + total - 1) / 9;
       bool first = true;
-      auto step = [&]() __attribute__((always_inline)) {           // the step that (on the weight side) issues the stage (cc, tap)
-        if (cc + 1 < cpt) {
+      auto step_next = [&]() __attribute__((always_inline)) -> bool {   // the step that (on the weight side) issues the stage (v, cc, tap)
+        if (left == 0) {
+          v += ngrid;
+          if (v >= nvirt) return false;
+          left = 9 * cpt; tap = 0; cc = 0; cclast = cpt - 1;
+        }
+        const bool more = cc < cclast, nextt = !more && v + ngrid < nvirt;
+        if (nextt && tap == 2) { const Tile t = decode(v + ngrid); set_pa(t.m0, 0); }
+        if (more || nextt) {
           const int lo = first ? 0 : w4_pieces_lo(tap), hi = w4_pieces_hi(tap);
           if (hi > lo) issue_image(ibuf ^ 1, lo, hi);
         }
         first = false;
         if (++tap == 9) { tap = 0; ++cc; ibuf ^= 1; }
+        --left;
+        return true;
       };
-      step();
-      if (total > 1) step();
+      step_next();
+      bool nxt = step_next();
       w4_vm_rt(0);                                            // (prologue: everything, the next image's first pieces included)
       __builtin_amdgcn_s_barrier();                           // B_raw(0)
       __builtin_amdgcn_sched_barrier(0);
-      for (int s = 0; s < total; ++s) {
+      bool curs = true;
+      while (curs) {
         __builtin_amdgcn_s_barrier();                         // B_war(s-1)
         __builtin_amdgcn_sched_barrier(0);
-        // stage s+1 is read after B_raw(s+1): if it is a chunk's first stage its image must be complete (tap == 1 here <=> the
-        // stage issued by this step, s+2, has tap 1 <=> stage s+1 has tap 0)
+        // stage s+1 is read after B_raw(s+1): if it is an image's first stage the image must be complete (tap == 1 here <=> the
+        // stage this step issues, s+2, has tap 1 <=> stage s+1 has tap 0)
         const bool chunk_start_next = tap == 1;
-        if (s + 2 < total) step();
+        const bool n2 = nxt ? step_next() : false;
         if (chunk_start_next) w4_vm<0>();
         __builtin_amdgcn_s_barrier();                         // B_raw(s+1)
         __builtin_amdgcn_sched_barrier(0);
+        curs = nxt; nxt = n2;
       }
       return;
     } else {
@@ -438,8 +509,9 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
     };
 
     // the stages of ALL this workgroup's tiles, in order: issue_next() moves on to the next tile when one is exhausted
-    int v = (int)blockIdx.x, left = total;
+    int v = (int)blockIdx.x, left = total, tpar = 0;
     setup_tile(m0, n0, kbeg);
+    issue_epi(m0, n0, 0);
     auto issue_next = [&](int slot) __attribute__((always_inline)) -> bool {
       if (left == 0) {
         v += ngrid;
@@ -447,6 +519,8 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
         const Tile t = decode(v);
         setup_tile(t.m0, t.n0, t.kbeg);
         left = t.total;
+        tpar ^= 1;
+        issue_epi(t.m0, t.n0, tpar);
       }
       issue(slot);
       --left;
@@ -486,15 +560,22 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
 #pragma unroll
     for (int i = 0; i < 4; ++i) xh0[i] = 0;
     if constexpr (!HALO) { xa[0] = lds0 + (wave * 64) * 128 + fo; xa[1] = xa[0] ^ 64u; }
-    else {
+  }
+  // (made again at the start of every tile, from a fresh lane id: kept across the epilogue they went to scratch, and the reload's
+  // vmcnt(0) at the next tile's start waited for the finished tile's stores)
+  auto make_xh0 = [&]() __attribute__((always_inline)) {
+    if constexpr (HALO) {
+      int l2;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(l2));
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int px = wave * 64 + 16 * i + lr;                        // tile-local pixel: image row px / W, column px % W
+        const int px = wave * 64 + 16 * i + (l2 & 15);                 // tile-local pixel: image row px / W, column px % W
         const int yl = px >> wsh, xl = px & (p.Win - 1);               // (W is a power of two: w4_halo_ok)
         xh0[i] = (yl + 1) * Wp + xl + 1;
       }
     }
-  }
+  };
+  make_xh0();
   int ctap = tap0, cbuf = 0;                    // HALO: tap / image buffer of the stage whose X addresses are in xa
   auto halo_addr = [&](int tp, int buf) __attribute__((always_inline)) {
     if constexpr (HALO) {
@@ -572,7 +653,14 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
 #pragma unroll
     for (int f = 0; f < NW; ++f)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[f][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < 4; ++i) {
+        if (f < 8) acc[f][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        else {
+          // (the VGPR quads: left to the compiler they were zeroed ONCE, parked in scratch and reloaded per tile -- a vmcnt(0))
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { float z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); acc[f][i][r] = z; }
+        }
+      }
     // (the accumulators were just written by v_accvgpr_write: wait states before the first MFMA reads them as SrcC)
     w4_for<0, NW>([&](auto Fc) { constexpr int f = decltype(Fc)::value; w4_pad<true, (f < 8)>(acc[f][0], acc[f][1], acc[f][2], acc[f][3]); });
   };
@@ -618,20 +706,32 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
     });
   };
 
-  // ---- a finished tile: accumulators -> memory
-  auto epilogue = [&](int tm0, int tn0, int tz) __attribute__((always_inline)) {
+  // ---- a finished tile: accumulators -> memory.  Nothing here may wait for a global or scratch LOAD issued behind a store: vmcnt
+  // retires in order, so such a wait drains the stores (measured: 12 us of a 59 us tile when every 8-column unit loaded its own
+  // bias and the compiler parked addresses in scratch).  Hence: bias and row-bias come from LDS (issue_epi); the residual's 16
+  // bytes per unit are fetched four units ahead; every unit re-derives its coordinates from the lane id (a handful of VALU)
+  // instead of keeping twenty units' worth of addresses alive; accumulators leave the AGPR half by explicit v_accvgpr_read.
+  auto epilogue = [&](int tm0, int tn0, int tz, int par) __attribute__((always_inline)) {
     // an MFMA result may be read 8 passes after its issue; nothing padded that for an asm MFMA
     w4_for<0, NW>([&](auto Fc) { constexpr int f = decltype(Fc)::value; w4_pad<false, (f < 8)>(acc[f][0], acc[f][1], acc[f][2], acc[f][3]); });
     if (W4_ABL(4) || p.act == 77) return;                     // act 77: timing probe only (skip the stores)
-    const EpiArgs e = epi_of(p);
-    const int row_w = tm0 + wave * 64 + lr;
-    // Lane (m = lr, lane row lg) holds columns 4 lg + r of every 16-column block.  v_permlane16_swap of blocks (fa, fb): lane rows
-    // 0 / 2 end up with columns 0-7 / 8-15 of block fa, lane rows 1 / 3 with those of block fb -- 8 consecutive columns per lane
-    auto cols8 = [&](auto Fa, auto Fb, auto Ic, float (&v)[8]) {
-      constexpr int fa = decltype(Fa)::value, fb = decltype(Fb)::value, i = decltype(Ic)::value;
+    EpiArgs e = epi_of(p);
+    const char* eb = smem + EPI0 + par * 1024;
+    const bool rb_lds = w4_rb_uniform(p, tm0);
+    const int row0 = tm0 + wave * 64;                          // (uniform)
+    const unsigned ldc_u = (unsigned)e.ldc, ldr_u = (unsigned)e.ldr, ldn_u = (unsigned)p.N;
+    // lane (m = lr, lane row lg) holds columns 4 lg + r of every 16-column block
+    auto lane_rc = [&](int& lr_, int& lg_) __attribute__((always_inline)) {
+      int l2;                                                  // (volatile: every unit makes its own -- a shared copy went to scratch)
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(l2));
+      lr_ = l2 & 15; lg_ = l2 >> 4;
+    };
+    // v_permlane16_swap of blocks (fa, fb): lane rows 0 / 2 end up with columns 0-7 / 8-15 of block fa, lane rows 1 / 3 with
+    // those of block fb -- 8 consecutive columns per lane
+    auto swap8 = [&](const float (&a)[4], const float (&b)[4], float (&v)[8]) __attribute__((always_inline)) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[fa][i][r]), __float_as_uint(acc[fb][i][r]), false, false);
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[r]), __float_as_uint(b[r]), false, false);
         v[r] = __uint_as_float(sw[0]); v[4 + r] = __uint_as_float(sw[1]);
       }
     };
@@ -641,57 +741,112 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
       if constexpr (NW == 10) {
         w4_for<0, 4>([&](auto Ic) {
           constexpr int i = decltype(Ic)::value;
-          const int grow = row_w + 16 * i;
-          w4_for<0, 5>([&](auto Fc) {
+          int lr, lg;
+          lane_rc(lr, lg);
+          const int grow = row0 + lr + 16 * i;
+          const unsigned o_c = (unsigned)grow * ldc_u + (unsigned)(tn0 / 2);
+          // the products of blocks (2 q, 2 q + 1), then block 4
+          auto prod = [&](auto Fc, float (&P)[4]) __attribute__((always_inline)) {
             constexpr int f = decltype(Fc)::value;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int c = 16 * f + 4 * lg + r;
-              const float bv = e.bias ? e.bias[tn0 + c] : 0.f, bg = e.bias ? e.bias[tn0 + 80 + c] : 0.f;
-              acc[f][i][r] = (acc[f][i][r] + bv) * gelu_f(acc[f + 5][i][r] + bg);
+            float bvv[4] = {0.f, 0.f, 0.f, 0.f}, bgg[4] = {0.f, 0.f, 0.f, 0.f};
+            if (e.bias) {
+              load4(reinterpret_cast<const float*>(eb + (16 * f + 4 * lg) * 4), bvv);
+              load4(reinterpret_cast<const float*>(eb + (80 + 16 * f + 4 * lg) * 4), bgg);
             }
-          });
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              P[r] = (w4_get<(f < 8)>(acc[f][i][r]) + bvv[r]) * gelu_f(w4_get<(f + 5 < 8)>(acc[f + 5][i][r]) + bgg[r]);
+          };
           w4_for<0, 2>([&](auto Qc) {
             constexpr int q = decltype(Qc)::value;
-            float v[8];
-            cols8(std::integral_constant<int, 2 * q>{}, std::integral_constant<int, 2 * q + 1>{}, Ic, v);
-            const int c0 = 32 * q + 16 * (lg & 1) + 8 * (lg >> 1);
+            float Pa[4], Pb[4], v[8];
+            prod(std::integral_constant<int, 2 * q>{}, Pa);
+            prod(std::integral_constant<int, 2 * q + 1>{}, Pb);
+            swap8(Pa, Pb, v);
+            const unsigned c0 = 32 * q + 16 * (lg & 1) + 8 * (lg >> 1);
             if (grow < p.M) {
-              if (p.out_f32) store8(reinterpret_cast<float*>(e.C) + (long)grow * e.ldc + tn0 / 2 + c0, v);
-              else store8(reinterpret_cast<T*>(e.C) + (long)grow * e.ldc + tn0 / 2 + c0, v);
+              if (p.out_f32) store8(reinterpret_cast<float*>(e.C) + (o_c + c0), v);
+              else store8(reinterpret_cast<T*>(e.C) + (o_c + c0), v);
             }
+            __builtin_amdgcn_sched_barrier(0);
           });
-          if (grow < p.M) {
-            float v4[4] = {acc[4][i][0], acc[4][i][1], acc[4][i][2], acc[4][i][3]};
-            const int c0 = 64 + 4 * lg;
-            if (p.out_f32) store4(reinterpret_cast<float*>(e.C) + (long)grow * e.ldc + tn0 / 2 + c0, v4);
-            else store4(reinterpret_cast<T*>(e.C) + (long)grow * e.ldc + tn0 / 2 + c0, v4);
+          {
+            float P4[4];
+            prod(std::integral_constant<int, 4>{}, P4);
+            if (grow < p.M) {
+              const unsigned c0 = 64 + 4 * lg;
+              if (p.out_f32) store4(reinterpret_cast<float*>(e.C) + (o_c + c0), P4);
+              else store4(reinterpret_cast<T*>(e.C) + (o_c + c0), P4);
+            }
           }
+          __builtin_amdgcn_sched_barrier(0);
         });
       }
       return;
     }
+    constexpr int NQ = NW / 2;
+    const bool pre = !slab && e.residual != nullptr;
+    // Units in ROW-major order (16 rows x all the tile's column groups, then the next 16 rows): the two 64-byte halves of a
+    // 128-byte line leave back to back.  Residual of unit (i, q): fetched when unit (i - 1, q) has consumed its own -- NQ units
+    // ahead, one register quad per q.  (Unconditional loads from clamped coordinates: a conditionally written register would be
+    // carried around the tile loop.)
+    uint4 rs[NQ] = {};
+    auto fetch = [&](auto Ic, auto Qc) __attribute__((always_inline)) {
+      constexpr int q = decltype(Qc)::value, i = decltype(Ic)::value;
+      int lr, lg;
+      lane_rc(lr, lg);
+      const int grow = row0 + lr + 16 * i, gcol = tn0 + 32 * q + 16 * (lg & 1) + 8 * (lg >> 1);
+      const unsigned off = (grow < p.M && gcol < p.N) ? (unsigned)grow * ldr_u + (unsigned)gcol : 0u;
+      rs[q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(e.residual) + off);
+    };
+    if (pre) w4_for<0, NQ>([&](auto Qc) { fetch(std::integral_constant<int, 0>{}, Qc); });
     w4_for<0, 4>([&](auto Ic) {
       constexpr int i = decltype(Ic)::value;
-      const int grow = row_w + 16 * i;
-      w4_for<0, NW / 2>([&](auto Qc) {
+      w4_for<0, NQ>([&](auto Qc) {
         constexpr int q = decltype(Qc)::value;
-        float v[8];
-        cols8(std::integral_constant<int, 2 * q>{}, std::integral_constant<int, 2 * q + 1>{}, Ic, v);
-        const int gcol = tn0 + 32 * q + 16 * (lg & 1) + 8 * (lg >> 1);
-        if (grow < p.M && gcol < p.N) {
-          if (slab) store8(slab + ((long)tz * p.M + grow) * p.N + gcol, v);    // split-K partial: raw accumulators
-          else epilogue8<T>(e, v, grow, gcol);
+        float fa[4], fb[4], v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { fa[r] = w4_get<(2 * q < 8)>(acc[2 * q][i][r]); fb[r] = w4_get<(2 * q + 1 < 8)>(acc[2 * q + 1][i][r]); }
+        swap8(fa, fb, v);
+        int lr, lg;
+        lane_rc(lr, lg);
+        const int cq = 32 * q + 16 * (lg & 1) + 8 * (lg >> 1);         // this lane's 8 columns inside the tile
+        const int grow = row0 + lr + 16 * i, gcol = tn0 + cq;
+        const bool in = grow < p.M && gcol < p.N;
+        if (slab) {
+          if (in) store8(slab + (((unsigned)tz * (unsigned)p.M + (unsigned)grow) * ldn_u + (unsigned)gcol), v);   // split-K partial
+        } else {
+          float b[8];
+          if (e.bias) {
+            load8(reinterpret_cast<const float*>(eb + cq * 4), b);     // (LDS: no vmcnt involved)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += b[k];
+          }
+          if (rb_lds) {
+            load8(reinterpret_cast<const T*>(eb + BN * 4 + cq * 2), b);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += b[k];
+          } else if (e.rowbias) {                                      // (a tile across batch elements: the slow way)
+            if (in) load8(reinterpret_cast<const T*>(e.rowbias) + (long)(grow / e.rows_per_batch) * e.ldrb + gcol, b);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += b[k];
+          }
+          const uint4 cur = rs[q];
+          if constexpr (i + 1 < 4) { if (pre) fetch(std::integral_constant<int, i + 1>{}, Qc); }
+          if (in) epilogue8_tail_bf16(e, v, (unsigned)grow * ldc_u + (unsigned)gcol, gcol, cur);
         }
+        __builtin_amdgcn_sched_barrier(0);
       });
     });
   };
 
   // ---- the tiles of this workgroup
   int slot = 0;                                               // ring slot of the stage being read (runs on across tiles)
+  int par = 0;                                                // parity of the tile (the epilogue operands' LDS block)
   for (int v = (int)blockIdx.x; v < nvirt; v += ngrid) {
     const Tile t = decode(v);
     const int tm0 = t.m0, tn0 = t.n0, tz = t.zsplit, tt = t.total;
+    make_xh0();
     zero_acc();
     first_reads();
     __builtin_amdgcn_sched_barrier(0);
@@ -706,7 +861,8 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
     w4_lgkm<0>();                                             // (nothing of the consumers' own is in flight past here)
     __builtin_amdgcn_sched_barrier(0);
     if (v == (int)blockIdx.x) W4_STAMP(2);
-    epilogue(tm0, tn0, tz);
+    epilogue(tm0, tn0, tz, par);
+    par ^= 1;
   }
 #ifdef W4_PROBE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -717,7 +873,7 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
 template <int NW, int MODE, int ABL = 0>
 int launch_w4_mode(const GemmParams& p0, hipStream_t stream, bool persist = false) {
   constexpr int BN = 16 * NW;
-  constexpr int SMEM = MODE == W4_CONV_HALO ? 2 * W4_HROWS * 128 + W4_R * (BN / 8) * 1024 : W4_R * (W4_BM / 8 + BN / 8) * 1024;
+  constexpr int SMEM = (MODE == W4_CONV_HALO ? 2 * W4_HROWS * 128 + W4_R * (BN / 8) * 1024 : W4_R * (W4_BM / 8 + BN / 8) * 1024) + 2048;
   auto kern = &gemm_w4_kernel<NW, MODE, ABL>;
   static bool attr_set = false;
   static int cus = 256;
@@ -730,6 +886,8 @@ int launch_w4_mode(const GemmParams& p0, hipStream_t stream, bool persist = fals
     attr_set = true;
   }
   if ((p0.a1_group_n && p0.a1_group_n % BN) || (p0.a2_group_n && p0.a2_group_n % BN)) return CL_EINVAL;   // a tile would straddle groups
+  // the epilogue's element offsets are 32-bit
+  if ((long)p0.M * p0.ldc >= (1L << 32) || (p0.residual && (long)p0.M * p0.ldr >= (1L << 32))) return CL_EINVAL;
   GemmParams p = p0;
   const int tm = (p.M + W4_BM - 1) / W4_BM, tn = (p.N + BN - 1) / BN;
   const long tiles = (long)tm * tn;
@@ -737,10 +895,13 @@ int launch_w4_mode(const GemmParams& p0, hipStream_t stream, bool persist = fals
   float* slab;
   gemm_pick_splitk(p, tiles, steps, 256, 4, &slab, stream);
   const long nvirt = tiles * p.splitk;
+  if (slab && (long)p.splitk * p.M * p.N >= (1L << 32)) return CL_EINVAL;
   // persistent form: one workgroup per CU (LDS admits no second one) walks virtual ids id, id + grid, ...; a multiple of 8 so that
-  // id mod 8 -- the XCD -- is the same for every tile of a workgroup.  The halo form is one tile per workgroup (launcher's rule).
+  // id mod 8 -- the XCD -- is the same for every tile of a workgroup.  The halo form hands images over between WHOLE K ranges only.
   long grid = nvirt;
-  if (persist && MODE != W4_CONV_HALO && nvirt > cus) grid = cus - cus % 8;
+  // (>= 3 stages per tile and no split-K: the loaders run two stages ahead, and a tile's epilogue operands / image must not be
+  // overwritten by the tile after next while it is still being read)
+  if (persist && nvirt > cus && p.splitk == 1 && steps >= 3) grid = cus - cus % 8;
   gemm_tag_note(grid, 64 * (W4_NC + W4_NL));
   hipLaunchKernelGGL(kern, dim3((unsigned)(grid + gemm_cur_tag())), dim3(64 * (W4_NC + W4_NL)), SMEM, stream, p, tm, tn, slab, (int)nvirt,
                      (int)grid);
@@ -763,9 +924,9 @@ int launch_w4_nw(const GemmParams& p, hipStream_t stream, bool persist) {
 #ifdef W4_PROBE
   if constexpr (NW == 10) {
     if (p.mode == GEMM_CONV_S1 && g_w4_abl_host) {
-      const bool halo = g_w4_halo_host && w4_halo_ok(p) && !persist;
+      const bool halo = g_w4_halo_host && w4_halo_ok(p);
       switch (g_w4_abl_host) {
-#define W4_CASE(a) case a: return halo ? launch_w4_mode<NW, W4_CONV_HALO, a>(p, stream) : launch_w4_mode<NW, W4_CONV_S1, a>(p, stream, persist);
+#define W4_CASE(a) case a: return halo ? launch_w4_mode<NW, W4_CONV_HALO, a>(p, stream, persist) : launch_w4_mode<NW, W4_CONV_S1, a>(p, stream, persist);
         W4_CASE(1) W4_CASE(2) W4_CASE(3) W4_CASE(4) W4_CASE(5) W4_CASE(6) W4_CASE(7) W4_CASE(37)
 #undef W4_CASE
         default: break;
@@ -774,9 +935,8 @@ int launch_w4_nw(const GemmParams& p, hipStream_t stream, bool persist) {
   }
   if (p.mode == GEMM_CONV_S1 && !g_w4_halo_host) return launch_w4_mode<NW, W4_CONV_S1>(p, stream, persist);
 #endif
-  // (persistent: the per-tap form -- the halo form's image hand-over is per workgroup, not per tile)
   if (p.mode == GEMM_CONV_S1)
-    return (w4_halo_ok(p) && !persist) ? launch_w4_mode<NW, W4_CONV_HALO>(p, stream) : launch_w4_mode<NW, W4_CONV_S1>(p, stream, persist);
+    return w4_halo_ok(p) ? launch_w4_mode<NW, W4_CONV_HALO>(p, stream, persist) : launch_w4_mode<NW, W4_CONV_S1>(p, stream, persist);
   return launch_w4_mode<NW, W4_CONV_ANY>(p, stream, persist);
 }
 

@@ -31,9 +31,9 @@ W320 = (33,)                                             # 128 x 320 full-N tile
 PERSIST = (25, 26, 27, 28, 29, 30)                      # persistent forms of 16 / 17 / 20 / 21 / 10 / 11 (linear only)
 W160 = (2, 5, 10, 12, 14, 16, 18, 20, 23, 25, 27, 29)   # 160-column tiles
 W128 = (1, 7, 11, 13, 15, 17, 19, 21, 22, 26, 28, 30)   # 128-column tiles
-GEGLU_OK = (2, 10, 12, 14, 16, 18, 20, 23, 25, 27, 29, 40, 44)  # a value / gate wave pair per 160-column tile (40: in-register pairing)
+GEGLU_OK = (2, 10, 12, 14, 16, 18, 20, 23, 25, 27, 29, 40, 44, 47)  # a value / gate wave pair per 160-column tile (40 / 47: in-register pairing)
 DEEP = (42, 43, 44, 45, 46)                              # generic kernel, 8-slot ring: 64x64 / 64x128 / 64x160 / 128x64 / 128x128
-W4 = (40, 41)                                            # loader / consumer kernel (gemm_w4.hip): 256 x 160 / 256 x 128 tiles
+W4 = (40, 41, 47, 48)                                    # loader / consumer kernel (gemm_w4.hip): 256 x 160 / 256 x 128 tiles; 47 / 48 = persistent
 
 
 class Recorder:
@@ -104,8 +104,10 @@ def candidates(key):
     for c in (1, 2, 5, 7, 22, 23) + FL + PERSIST + W4 + DEEP:
         if c in DEEP and ((c == 44 and N % 160) or (c in (43, 46) and N % 128 and N % 160 == 0) or (c in (42, 45) and N % 64) or M * N > 8192 * 2560):
             continue
-        if c in W4 and (not fl_ok or (c == 40 and N % 160) or (c == 41 and N % 128 and N % 160 == 0) or M < 1024):
+        if c in W4 and (not fl_ok or (c in (40, 47) and N % 160) or (c in (41, 48) and N % 128 and N % 160 == 0) or M < 1024):
             continue
+        if c in (47, 48) and M * N < 2 * 256 * 256 * 160:
+            continue                      # persistent: only where a workgroup would own several tiles
         if c in FL and not fl_ok:
             continue
         if c in PERSIST and not (fl_ok and mode == hip.LINEAR and M * N >= 256 * 160 * 512):

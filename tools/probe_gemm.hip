@@ -65,7 +65,7 @@ static void case_linear(const char* name, int dtype, int M, int N, int K1, int K
   C.init((size_t)M * N, odt, 1.0f, true);
   GemmParams p{}; p.A1 = A1.d; p.lda1 = K1; p.K1 = K1; p.W1 = W1.d; p.ldw1 = K1;
   if (K2) { p.A2 = A2.d; p.lda2 = K2; p.K2 = K2; p.W2 = W2.d; p.ldw2 = K2; }
-  p.M = M; p.N = N; p.mode = GEMM_LINEAR; p.zero_page = g_zero; p.bias = dbias;
+  p.M = M; p.N = N; p.mode = GEMM_LINEAR; p.zero_page = nullptr;  /* (as the product: linear calls carry no zero page) */ p.bias = dbias;
   if (rowb) { p.rowbias = RB.d; p.ldrb = N; p.rows_per_batch = rpb; }
   if (resid) { p.residual = R.d; p.ldr = N; }
   p.alpha = alpha; p.beta = beta; p.act = act; p.C = C.d; p.ldc = N; p.out_f32 = out_f32; p.atomic = atomic; p.splitk = splitk;
@@ -107,7 +107,7 @@ static void case_xs(const char* name, int M, int N, int K1, int K2, bool bias, i
   C.init((size_t)M * NO, dtype, 1.0f, true); C2.init((size_t)M * NO, dtype, 1.0f, true);
   GemmParams p{}; p.A1 = A1.d; p.lda1 = K1; p.K1 = K1; p.W1 = W1.d; p.ldw1 = K1;
   if (K2) { p.A2 = A2.d; p.lda2 = K2 * groups; p.K2 = K2; p.W2 = W2.d; p.ldw2 = K2; if (groups > 1) p.a2_group_n = N / groups; }
-  p.M = M; p.N = N; p.mode = GEMM_LINEAR; p.zero_page = g_zero; p.bias = dbias;
+  p.M = M; p.N = N; p.mode = GEMM_LINEAR; p.zero_page = nullptr; p.bias = dbias;
   p.alpha = alpha; p.alpha_n = alpha_n; p.C = C.d; p.ldc = NO; p.splitk = 1;
   if (beta != 0.f) { p.residual = R.d; p.ldr = NO; p.beta = beta; }
   if (geglu) p.act = ACT_GEGLU_SPLIT;
@@ -237,7 +237,7 @@ static void case_geglu(const char* name, int dtype, int M, int half, int K1, int
   C.init((size_t)M * half, odt, 1.0f, true);
   GemmParams p{}; p.A1 = A1.d; p.lda1 = K1; p.K1 = K1; p.W1 = Wp.d; p.ldw1 = K1;
   if (K2) { p.A2 = A2.d; p.lda2 = K2; p.K2 = K2; p.W2 = W2p.d; p.ldw2 = K2; }
-  p.M = M; p.N = N; p.mode = GEMM_LINEAR; p.zero_page = g_zero; p.bias = dbias; p.alpha = 1.f; p.act = ACT_GEGLU;
+  p.M = M; p.N = N; p.mode = GEMM_LINEAR; p.zero_page = nullptr; p.bias = dbias; p.alpha = 1.f; p.act = ACT_GEGLU;
   p.C = C.d; p.ldc = half; p.out_f32 = out_f32; p.splitk = 1;
   int rc = launch_gemm(p, dtype, 0);
   HIPCHK(hipDeviceSynchronize());
@@ -483,7 +483,7 @@ static void ab_case(const char* name, int mode, int M, int N, int K1, int B, int
   float* dbias; HIPCHK(hipMalloc(&dbias, N * 4)); HIPCHK(hipMemcpy(dbias, hb.data(), N * 4, hipMemcpyHostToDevice));
   GemmParams p{}; p.A1 = A.d; p.lda1 = K1; p.K1 = K1; p.W1 = Wt.d; p.ldw1 = taps * K1; p.M = M; p.N = N; p.mode = mode;
   if (K2) { p.A2 = A2.d; p.lda2 = K2; p.K2 = K2; p.W2 = W2.d; p.ldw2 = K2; }
-  p.B = B; p.Hin = H; p.Win = W; p.Hout = H; p.Wout = W; p.zero_page = g_zero; p.alpha = 1.f; p.ldc = N; p.splitk = 1; p.bias = dbias;
+  p.B = B; p.Hin = H; p.Win = W; p.Hout = H; p.Wout = W; p.zero_page = mode == GEMM_LINEAR ? nullptr : g_zero; p.alpha = 1.f; p.ldc = N; p.splitk = 1; p.bias = dbias;
   if (resid) { p.residual = R.d; p.ldr = N; p.beta = 1.f; }
   if (rowb_silu) { p.rowbias = RB.d; p.ldrb = N; p.rows_per_batch = rpb; p.act = ACT_SILU; }
   std::vector<void*> C(ncfg);
@@ -574,11 +574,12 @@ static void conv_sampled(const char* name, int cfg, int B, int H, int W, int C, 
 #ifdef W4_PROBE
 // s_memtime stamps of every tile (wave 0): entry | stage 0 landed | main loop done | stores retired, next to the wall time of the
 // same launch: cycles / wall = the clock the chip actually held
-static void w4_timing_case(const char* tag) {
-  const int M = 8 * 64 * 64, N = 320, K1 = 320;
+static void w4_timing_case(const char* tag, int B_ = 8, int H_ = 64, int N_ = 320, int C_ = 320) {
+  const int M = B_ * H_ * H_, N = N_, K1 = C_;
+  const int nst = 9 * C_ / 64;
   Buf A, Wt, Cb; A.init((size_t)M * K1, CL_BF16); Wt.init((size_t)N * 9 * K1, CL_BF16, 0.05f); Cb.init((size_t)M * N, CL_BF16, 1.f, true);
   GemmParams p{}; p.A1 = A.d; p.lda1 = K1; p.K1 = K1; p.W1 = Wt.d; p.ldw1 = 9 * K1; p.M = M; p.N = N; p.mode = GEMM_CONV_S1;
-  p.B = 8; p.Hin = 64; p.Win = 64; p.Hout = 64; p.Wout = 64; p.zero_page = g_zero; p.alpha = 1.f; p.C = Cb.d; p.ldc = N; p.splitk = 1;
+  p.B = B_; p.Hin = H_; p.Win = H_; p.Hout = H_; p.Wout = H_; p.zero_page = g_zero; p.alpha = 1.f; p.C = Cb.d; p.ldc = N; p.splitk = 1;
   const long nv = 256;
   unsigned long long* tb; HIPCHK(hipMalloc(&tb, nv * 32)); HIPCHK(hipMemset(tb, 0, nv * 32));
   g_gemm_force_cfg = 40;
@@ -600,8 +601,8 @@ static void w4_timing_case(const char* tag) {
   for (long i = 0; i < nv; ++i)
     for (int k = 0; k < 3; ++k) ph[k] += (double)(tt[i * 4 + k + 1] - tt[i * 4 + k]);
   const double tot = (ph[0] + ph[1] + ph[2]) / nv;
-  printf("[TIMING] %-52s wall %6.1f us | per tile: entry -> stage 0 landed %6.0f | main loop (45 stages) %6.0f = %5.0f per stage | epilogue %6.0f | "
-         "sum %6.0f cycles -> %.2f GHz\n", tag, ms * 1e3, ph[0] / nv, ph[1] / nv, ph[1] / nv / 45, ph[2] / nv, tot, tot / (ms * 1e3) * 1e-3);
+  printf("[TIMING] %-52s wall %6.1f us | per tile: entry -> stage 0 landed %6.0f | main loop (%d stages) %6.0f = %5.0f per stage | epilogue %6.0f | "
+         "sum %6.0f cycles -> %.2f GHz\n", tag, ms * 1e3, ph[0] / nv, nst, ph[1] / nv, ph[1] / nv / nst, ph[2] / nv, tot, tot / (ms * 1e3) * 1e-3);
   hipFree(tb); hipFree(A.d); hipFree(Wt.d); hipFree(Cb.d);
 }
 #endif
@@ -611,11 +612,12 @@ static void w4_timing_case(const char* tag) {
 namespace cl { void fl_timing_set(unsigned long long* buf); }
 // the same cycles-against-wall accounting for the ping-pong tile kernel (configuration 16): stamps 0 entry | 2 first stage landed |
 // 3 main loop done | 4 epilogue issued
-static void fl_timing_case16() {
-  const int M = 8 * 64 * 64, N = 320, K1 = 320;
+static void fl_timing_case16(int B_ = 8, int H_ = 64, int N_ = 320, int C_ = 320) {
+  const int M = B_ * H_ * H_, N = N_, K1 = C_;
+  const int nst = 9 * C_ / 64;
   Buf A, Wt, Cb; A.init((size_t)M * K1, CL_BF16); Wt.init((size_t)N * 9 * K1, CL_BF16, 0.05f); Cb.init((size_t)M * N, CL_BF16, 1.f, true);
   GemmParams p{}; p.A1 = A.d; p.lda1 = K1; p.K1 = K1; p.W1 = Wt.d; p.ldw1 = 9 * K1; p.M = M; p.N = N; p.mode = GEMM_CONV_S1;
-  p.B = 8; p.Hin = 64; p.Win = 64; p.Hout = 64; p.Wout = 64; p.zero_page = g_zero; p.alpha = 1.f; p.C = Cb.d; p.ldc = N; p.splitk = 1;
+  p.B = B_; p.Hin = H_; p.Win = H_; p.Hout = H_; p.Wout = H_; p.zero_page = g_zero; p.alpha = 1.f; p.C = Cb.d; p.ldc = N; p.splitk = 1;
   const long nv = 256;
   unsigned long long* tb; HIPCHK(hipMalloc(&tb, nv * 64)); HIPCHK(hipMemset(tb, 0, nv * 64));
   g_gemm_force_cfg = 16;
@@ -636,8 +638,8 @@ static void fl_timing_case16() {
   double ph[3] = {0, 0, 0};
   for (long i = 0; i < nv; ++i) { ph[0] += (double)(tt[i * 8 + 2] - tt[i * 8]); ph[1] += (double)(tt[i * 8 + 3] - tt[i * 8 + 2]); ph[2] += (double)(tt[i * 8 + 4] - tt[i * 8 + 3]); }
   const double tot = (ph[0] + ph[1] + ph[2]) / nv;
-  printf("[TIMING] %-52s wall %6.1f us | per tile: entry -> stage 0 landed %6.0f | main loop (45 stages) %6.0f = %5.0f per stage | epilogue %6.0f | "
-         "sum %6.0f cycles -> %.2f GHz\n", "cfg 16 (ping-pong tiles, stamps cost ~1 %)", ms * 1e3, ph[0] / nv, ph[1] / nv, ph[1] / nv / 45, ph[2] / nv, tot, tot / (ms * 1e3) * 1e-3);
+  printf("[TIMING] %-52s wall %6.1f us | per tile: entry -> stage 0 landed %6.0f | main loop (%d stages) %6.0f = %5.0f per stage | epilogue %6.0f | "
+         "sum %6.0f cycles -> %.2f GHz\n", "cfg 16 (ping-pong tiles, stamps cost ~1 %)", ms * 1e3, ph[0] / nv, nst, ph[1] / nv, ph[1] / nv / nst, ph[2] / nv, tot, tot / (ms * 1e3) * 1e-3);
   hipFree(tb); hipFree(A.d); hipFree(Wt.d); hipFree(Cb.d);
 }
 #endif
@@ -859,10 +861,18 @@ int main(int argc, char** argv) {
     conv_sampled("conv 320->320 @64^2 B32 sampled, persistent cfg 47 (4 tiles per CU)", 47, 32, 64, 64, 320, 320, 6000);
     conv_sampled("conv 128->128 @256^2 B2 sampled, persistent cfg 48", 48, 2, 256, 256, 128, 128, 6000);
     conv_sampled("conv 640->320 ragged 5x33x31 sampled, persistent cfg 47", 47, 5, 33, 31, 640, 320, 4000);
+    conv_sampled("conv 640->640 @32^2 B32 sampled, persistent halo cfg 47 (2 tiles per CU)", 47, 32, 32, 32, 640, 640, 6000);
+    conv_sampled("conv 320->320 @16^2 B160 sampled, persistent halo cfg 47", 47, 160, 16, 16, 320, 320, 6000);
+    conv_sampled("conv 128->128 @64^2 B24 sampled, persistent halo cfg 48", 48, 24, 64, 64, 128, 128, 6000);
+    conv_sampled("conv 64->160 @64^2 B20 sampled, persistent halo cfg 47 (one chunk per tile)", 47, 20, 64, 64, 64, 160, 6000);
+    conv_sampled("conv 320->320 @64^2 B17 sampled, persistent halo cfg 47 (ragged tile count)", 47, 17, 64, 64, 320, 320, 6000);
     const int ab[] = {16, 40, 47}, ab128[] = {17, 41, 48};
     ab_case("conv 320->320 @64^2 B8", GEMM_CONV_S1, 8 * 64 * 64, 320, 320, 8, 64, 64, 0, ab, 3, 7);
     ab_case("conv 320->320 @64^2 B8 rowbias+silu", GEMM_CONV_S1, 8 * 64 * 64, 320, 320, 8, 64, 64, 0, ab, 3, 3, false, true);
     ab_case("conv 320->320 @64^2 B32 (DDIM)", GEMM_CONV_S1, 32 * 64 * 64, 320, 320, 32, 64, 64, 0, ab, 3, 3);
+    ab_case("conv 640->640 @32^2 B32 (DDIM)", GEMM_CONV_S1, 32 * 32 * 32, 640, 640, 32, 32, 32, 0, ab, 3, 3);
+    ab_case("conv 1280->1280 @16^2 B32 (DDIM)", GEMM_CONV_S1, 32 * 16 * 16, 1280, 1280, 32, 16, 16, 0, ab, 3, 3);
+    ab_case("conv 960->320 @64^2 B32 (DDIM)", GEMM_CONV_S1, 32 * 64 * 64, 320, 960, 32, 64, 64, 0, ab, 3, 3);
     ab_case("conv 960->320 @64^2 B8", GEMM_CONV_S1, 8 * 64 * 64, 320, 960, 8, 64, 64, 0, ab, 3, 3);
     ab_case("conv 640->320 @64^2 B8 + residual", GEMM_CONV_S1, 8 * 64 * 64, 320, 640, 8, 64, 64, 0, ab, 3, 3, true);
     ab_case("conv 640->640 @32^2 B8", GEMM_CONV_S1, 8 * 32 * 32, 640, 640, 8, 32, 32, 0, ab, 3, 3);
@@ -914,6 +924,14 @@ w4_ablations:
     fl_timing_case16();
     w4_timing_case("full (again)");
     fl_timing_case16();
+    // one tile per CU at the lower resolutions (256 tiles, no split-K)
+    w4_timing_case("640->640 @32^2 B16 (90 stages)", 16, 32, 640, 640);
+    fl_timing_case16(16, 32, 640, 640);
+    w4_timing_case("1280->1280 @16^2 B32 (180 stages)", 32, 16, 1280, 1280);
+    fl_timing_case16(32, 16, 1280, 1280);
+    cl::w4_halo_set(0);
+    w4_timing_case("640->640 @32^2 B16, per-tap DMA", 16, 32, 640, 640);
+    cl::w4_halo_set(1);
 #endif
 #endif
     printf("probe_gemm --w4: %s (%d failures)\n", g_fail ? "FAILED" : "ALL PASS", g_fail);

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Offer the round-6 configurations -- 40 / 41 (loader / consumer kernel, gemm_w4.hip) and 42 .. 46 (generic kernel, 8-slot ring) --
+# Offer the round-6 configurations -- 40 / 41 / 47 / 48 (loader / consumer kernel, gemm_w4.hip; 47 / 48 persistent) and 42 .. 46
+# (generic kernel, 8-slot ring) --
 # to every signature of the training step, the DDIM step and the VAE, against the table as it stands (base + x-stationary overlay);
 # the rows they win become ctrlora_amd/gemm_tuned_gfx950_r06.json (a second overlay).  Then the bench with and without it.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -13,13 +14,13 @@ b["entries"] = sorted(rows.values())
 json.dump(b, open("$O/current.json", "w"))
 print("current table:", len(b["entries"]), "rows")
 PY
-CTRLORA_GEMM_R06=0 timeout 2400 python tools/gemm_autotune.py --merge $O/current.json --retry-cfgs 40,41,42,43,44,45,46 --out $O/merged.json --log $O/autotune_r06.log > $O/autotune_r06.out 2>&1
+CTRLORA_GEMM_R06=0 timeout 2400 python tools/gemm_autotune.py --merge $O/current.json --retry-cfgs 40,41,42,43,44,45,46,47,48 --out $O/merged.json --log $O/autotune_r06.log > $O/autotune_r06.out 2>&1
 tail -12 $O/autotune_r06.out
 python - <<PY
 import json
 t = json.load(open("$O/merged.json"))
-rows = [r for r in t["entries"] if r[7] in (40, 41, 42, 43, 44, 45, 46)]
-head = {"device": t.get("device"), "columns": t["columns"], "note": "signatures won by the round-6 configurations (40 / 41: loader / consumer tile kernel, csrc/gemm_w4.hip; 42 .. 46: generic kernel with an 8-slot ring), layered over gemm_tuned_gfx950.json and the x-stationary overlay; CTRLORA_GEMM_R06=0 skips it", "predicted_saving_ms": t.get("predicted_saving_ms")}
+rows = [r for r in t["entries"] if r[7] in (40, 41, 42, 43, 44, 45, 46, 47, 48)]
+head = {"device": t.get("device"), "columns": t["columns"], "note": "signatures won by the round-6 configurations (40 / 41 / 47 / 48: loader / consumer tile kernel, csrc/gemm_w4.hip, 47 / 48 its persistent form; 42 .. 46: generic kernel with an 8-slot ring), layered over gemm_tuned_gfx950.json and the x-stationary overlay; CTRLORA_GEMM_R06=0 skips it", "predicted_saving_ms": t.get("predicted_saving_ms")}
 with open("$O/gemm_tuned_gfx950_r06.json", "w") as f:
     f.write("{" + ", ".join(f"{json.dumps(k)}: {json.dumps(v)}" for k, v in head.items()) + ',\n"entries": [\n')
     f.write(",\n".join(json.dumps(r) for r in sorted(rows)))
