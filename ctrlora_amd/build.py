@@ -18,7 +18,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(ROOT, "build", "obj")
 LIB = os.path.join(HERE, "libctrlora_hip.so")
-SOURCES = ["gemm.hip", "gemm_xs.hip", "gemm_w4.hip", "wgrad.hip", "norm.hip", "elementwise.hip", "attention_fwd.hip", "attention_bwd.hip", "attention_tr.hip", "attention_fwd40.hip", "capi.hip"]
+SOURCES = ["gemm.hip", "gemm_xs.hip", "gemm_w4.hip", "wgrad.hip", "norm.hip", "norm_coop.hip", "elementwise.hip", "attention_fwd.hip", "attention_bwd.hip", "attention_tr.hip", "attention_fwd40.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 

@@ -55,6 +55,9 @@ int cl_debug_groupnorm_form(int three_pass, int one_pass) {
   g_gn_three_pass = three_pass ? 1 : 0; g_gn_one_pass = one_pass ? 1 : 0; return CL_OK;
 }
 
+int cl_debug_groupnorm_coop(int on) { g_gn_coop = on ? 1 : 0; return CL_OK; }
+int cl_debug_groupnorm_coop_timeouts(void) { return (int)gnc_timeouts(); }
+
 int cl_debug_wgrad_ring(int slots) { if (slots != 3 && slots != 4 && slots != 6) return CL_EINVAL; g_wgrad_ring = slots; return CL_OK; }
 int cl_debug_gemm_xs_rules(int on) { g_gemm_xs_rules = on ? 1 : 0; return CL_OK; }
 int cl_debug_gemm_tag(int on) { g_gemm_tag_on = on ? 1 : 0; return CL_OK; }

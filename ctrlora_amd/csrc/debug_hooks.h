@@ -15,6 +15,11 @@ int cl_debug_attention_fuse_delta(int on);
 /* GroupNorm launch forms: three_pass = 1 forces partial -> finalize -> apply; one_pass = 0 disables the one-launch
  * register-resident form (defaults 0, 1) */
 int cl_debug_groupnorm_form(int three_pass, int one_pass);
+/* 1 = GroupNorms whose groups span >= 1024 pixels run as one cooperative launch (csrc/norm_coop.hip: pixel slabs in
+ * registers, the workgroups of a sample meet at a counter); 0 (default: measured no faster, see norm_coop.hip) = the forms above only.  _timeouts: how many workgroups ever gave
+ * up waiting at that counter (0 unless something is broken; a timed-out launch produced wrong numbers) */
+int cl_debug_groupnorm_coop(int on);
+int cl_debug_groupnorm_coop_timeouts(void);
 /* Launch tags for the contraction kernels (profiling aid: which SHAPE is a gemm dispatch of a kernel trace?).  While on, every
  * cl_gemm product signature {dtype, mode, M, N, K1, K2, act, residual} gets a small integer tag in order of first appearance
  * (1 .. 255) and each kernel it launches gets `tag` extra workgroups that exit at once -- so a trace row's Grid_Size names the

@@ -863,6 +863,9 @@ __device__ __forceinline__ void fl_tile(const GemmParams& p, int tiles_m, int ti
                                                m0 + wm * WM, n0 + wn * WN, lane, slab, zsplit, wn,
                                                reinterpret_cast<float*>(smem) + (wave ^ 1) * (EROWS * EST));
   FL_STAMP(4);
+#ifdef FL_TIMING
+  if (g_fl_timing) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); FL_STAMP(7); }   // (timing builds: the tile's stores have retired)
+#endif
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int R, int PRIO = 0>

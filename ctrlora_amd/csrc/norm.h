@@ -40,6 +40,11 @@ struct LnBwdArgs {
 };
 
 long gn_ws_floats(int B, int HW, int C);
+// one-launch, one-pass cooperative form (norm_coop.hip); CL_EINVAL = not its case
+extern int g_gn_coop;
+int gnc_fwd(const GnArgs& a, int dtype, hipStream_t st);
+int gnc_bwd(const GnBwdArgs& a, int dtype, hipStream_t st);
+unsigned gnc_timeouts();
 int gn_fwd(const GnArgs& a, int dtype, hipStream_t st);
 int gn_bwd(const GnBwdArgs& a, int dtype, hipStream_t st);
 int ln_fwd(const LnArgs& a, int dtype, hipStream_t st);

@@ -607,6 +607,7 @@ static int gn_fwd_t(const GnArgs& a, hipStream_t st) {
 int gn_fwd(const GnArgs& a, int dtype, hipStream_t st) {
   if (a.C % 8 || a.C % a.G || a.ldx % 8 || a.ldy % 8 || a.C > 8192) return CL_EINVAL;
   if (a.C / 8 > 320 && (a.C / 8) % 320) return CL_EINVAL;  // uniform trip count across the block
+  if (gnc_fwd(a, dtype, st) == CL_OK) return CL_OK;        // groups spanning >= 1024 pixels: one launch, one pass (norm_coop.hip)
   return dtype == CL_BF16 ? gn_fwd_t<bf16_t>(a, st) : gn_fwd_t<float>(a, st);
 }
 
@@ -901,6 +902,7 @@ int gn_bwd(const GnBwdArgs& a, int dtype, hipStream_t st) {
   if (a.C / 8 > 320 && (a.C / 8) % 320) return CL_EINVAL;
   if (a.accum && a.ldacc % 8) return CL_EINVAL;
   if ((a.dgamma == nullptr) != (a.dbeta == nullptr)) return CL_EINVAL;
+  if (gnc_bwd(a, dtype, st) == CL_OK) return CL_OK;
   return dtype == CL_BF16 ? gn_bwd_t<bf16_t>(a, st) : gn_bwd_t<float>(a, st);
 }
 

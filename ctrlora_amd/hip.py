@@ -119,6 +119,8 @@ _DEBUG_SIGS = {
     "cl_debug_attention_variant": [_I],
     "cl_debug_attention_fuse_delta": [_I],
     "cl_debug_groupnorm_form": [_I, _I],
+    "cl_debug_groupnorm_coop": [_I],
+    "cl_debug_groupnorm_coop_timeouts": [],
     "cl_debug_gemm_tag": [_I],
     "cl_debug_gemm_xs_rules": [_I],
     "cl_debug_wgrad_ring": [_I],
@@ -146,6 +148,8 @@ def lib():
         gn1 = os.environ.get("CTRLORA_GN_ONE_PASS", "1") != "0"        # A/B switch: one-launch (register-resident) GroupNorm
         if gn3 or not gn1:
             L.cl_debug_groupnorm_form(int(gn3), int(gn1))
+        if os.environ.get("CTRLORA_GN_COOP", "0") == "1":              # A/B switch: cooperative one-pass GroupNorm (norm_coop.hip; off: no faster)
+            L.cl_debug_groupnorm_coop(1)
         L.cl_debug_gemm_xs_rules(int(XS_ENABLED))
         if os.environ.get("CTRLORA_WGRAD_RING"):                     # A/B switch: 4 = the round-1..4 ring depth
             L.cl_debug_wgrad_ring(int(os.environ["CTRLORA_WGRAD_RING"]))

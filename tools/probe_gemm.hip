@@ -719,6 +719,59 @@ static void persist_case(const char* name, int M, int N, int K1, int K2, int act
   hipFree(A.d); hipFree(Wt.d); hipFree(C0.d); hipFree(C1.d); if (K2) { hipFree(A2.d); hipFree(W2.d); }
 }
 
+
+// s_memtime breakdown of one short-K linear launch on the full-line tile kernels (FL_STAMP 0 entry | 1 set-up done, ring fill issued |
+// 2 stage 0 landed | 3 K loop done | 4 stores issued | 7 stores retired), per workgroup, plus the launch's own span (first entry ->
+// last retire) against the wall time per launch in a back-to-back train of launches.
+static void fl_timing_linear(const char* name, int M, int N, int K1, int K2, int cfg, int sk, bool resid) {
+  Buf A, Wt, A2, W2, Cb, R; A.init((size_t)M * K1, CL_BF16); Wt.init((size_t)N * K1, CL_BF16, 0.05f); Cb.init((size_t)M * N, CL_BF16, 1.f, true);
+  if (K2) { A2.init((size_t)M * K2, CL_BF16); W2.init((size_t)N * K2, CL_BF16, 0.05f); }
+  if (resid) R.init((size_t)M * N, CL_BF16);
+  GemmParams p{}; p.A1 = A.d; p.lda1 = K1; p.K1 = K1; p.W1 = Wt.d; p.ldw1 = K1; p.M = M; p.N = N; p.mode = GEMM_LINEAR;
+  if (K2) { p.A2 = A2.d; p.lda2 = K2; p.K2 = K2; p.W2 = W2.d; p.ldw2 = K2; }
+  if (resid) { p.residual = R.d; p.ldr = N; p.beta = 1.f; }
+  p.alpha = 1.f; p.C = Cb.d; p.ldc = N; p.splitk = sk;
+  const long nv = 1 << 16;
+  unsigned long long* tb; HIPCHK(hipMalloc(&tb, nv * 64)); HIPCHK(hipMemset(tb, 0, nv * 64));
+  g_gemm_force_cfg = cfg;
+  for (int i = 0; i < 10; ++i) launch_gemm(p, CL_BF16, 0);
+  HIPCHK(hipDeviceSynchronize());
+  hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipEventRecord(e0, 0));
+  for (int i = 0; i < 20; ++i) launch_gemm(p, CL_BF16, 0);
+  HIPCHK(hipEventRecord(e1, 0)); HIPCHK(hipEventSynchronize(e1));
+  float ms0; HIPCHK(hipEventElapsedTime(&ms0, e0, e1)); ms0 /= 20;
+  cl::fl_timing_set(tb);
+  for (int i = 0; i < 5; ++i) launch_gemm(p, CL_BF16, 0);
+  HIPCHK(hipEventRecord(e0, 0));
+  for (int i = 0; i < 10; ++i) launch_gemm(p, CL_BF16, 0);
+  HIPCHK(hipEventRecord(e1, 0)); HIPCHK(hipEventSynchronize(e1));
+  float ms; HIPCHK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
+  HIPCHK(hipDeviceSynchronize());
+  cl::fl_timing_set(nullptr);
+  g_gemm_force_cfg = -1;
+  std::vector<unsigned long long> tt(nv * 8);
+  HIPCHK(hipMemcpy(tt.data(), tb, nv * 64, hipMemcpyDeviceToHost));
+  double ph[5] = {0, 0, 0, 0, 0};
+  unsigned long long first = ~0ull, last = 0, last_start = 0;
+  long n = 0;
+  for (long i = 0; i < nv; ++i) {
+    const unsigned long long* t = &tt[i * 8];
+    if (!t[0] || !t[7]) continue;
+    ++n;
+    ph[0] += (double)(t[1] - t[0]); ph[1] += (double)(t[2] - t[1]); ph[2] += (double)(t[3] - t[2]); ph[3] += (double)(t[4] - t[3]);
+    ph[4] += (double)(t[7] - t[4]);
+    first = std::min(first, t[0]); last = std::max(last, t[7]); last_start = std::max(last_start, t[0]);
+  }
+  if (!n) { printf("[SHORTK] %-44s cfg %d: no stamps (not a full-line tile configuration)\n", name, cfg); return; }
+  const double tot = (ph[0] + ph[1] + ph[2] + ph[3] + ph[4]) / n;
+  printf("[SHORTK] %-44s cfg %2d sk %d: wall %5.1f us (%5.1f with stamps) | %4ld workgroups | per workgroup, cycles (100 MHz-independent: shader clock): "
+         "set-up %5.0f | ring fill %5.0f | K loop (%d stages) %6.0f | epilogue issue %5.0f | store drain %5.0f | sum %6.0f | "
+         "launch span %6.0f (last workgroup starts at %5.0f)\n", name, cfg, sk, ms0 * 1e3, ms * 1e3, n, ph[0] / n, ph[1] / n, (K1 + K2) / 64, ph[2] / n,
+         ph[3] / n, ph[4] / n, tot, (double)(last - first), (double)(last_start - first));
+  hipFree(tb);
+}
+
 int main(int argc, char** argv) {
   hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s  CUs=%d  arch=%s\n", prop.name, prop.multiProcessorCount, prop.gcnArchName);
@@ -842,6 +895,18 @@ int main(int argc, char** argv) {
     g_probe_act = 0;
     printf("%s\n", g_fail ? "XS PROBE: FAILURES" : "XS PROBE: all pass");
     return g_fail ? 1 : 0;
+  }
+  if (argc > 1 && !strcmp(argv[1], "--shortk")) {   // verdict r5 item 2: where the fixed cost of the short-K linears sits
+    const int cfgs[] = {35, 36, 1, 21, 24, 16, 10};
+    for (int c : cfgs) fl_timing_linear("linear 2048x1280x1280", 2048, 1280, 1280, 0, c, 1, false);
+    for (int c : cfgs) fl_timing_linear("linear 2048x1280x1280 + residual", 2048, 1280, 1280, 0, c, 1, true);
+    for (int c : cfgs) fl_timing_linear("linear 2048x1280x1280+128 (LoRA)", 2048, 1280, 1280, 128, c, 1, false);
+    for (int c : cfgs) fl_timing_linear("linear 512x1280x1280", 512, 1280, 1280, 0, c, 1, false);
+    for (int c : cfgs) fl_timing_linear("linear 8192x640x640", 8192, 640, 640, 0, c, 1, false);
+    for (int c : cfgs) fl_timing_linear("linear 32768x320x320", 32768, 320, 320, 0, c, 1, false);
+    // the same products with K cut to ONE stage: what a launch costs when there is nothing to compute
+    for (int c : {35, 36}) fl_timing_linear("linear 2048x1280x64 (one stage)", 2048, 1280, 64, 0, c, 1, false);
+    return 0;
   }
   if (argc > 1 && !strcmp(argv[1], "--w4")) {   // loader / consumer kernel: correctness, then interleaved A/B against the ping-pong tiles
     const bool quick = argc > 2 && !strcmp(argv[2], "quick");
