@@ -833,7 +833,13 @@ __global__ __launch_bounds__(64 * (W4_NC + W4_NL)) void gemm_w4_kernel(GemmParam
           }
           const uint4 cur = rs[q];
           if constexpr (i + 1 < 4) { if (pre) fetch(std::integral_constant<int, i + 1>{}, Qc); }
-          if (in) epilogue8_tail_bf16(e, v, (unsigned)grow * ldc_u + (unsigned)gcol, gcol, cur);
+          unsigned off_out = (unsigned)grow * ldc_u + (unsigned)gcol;
+          if constexpr (W4_ABL(8)) {   // probe only: the same bytes as ONE contiguous KB per store instruction (wrong placement)
+            int l3;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(l3));
+            off_out = (unsigned)tm0 * ldc_u + (unsigned)(tn0 / BN) * (W4_BM * BN) + (unsigned)(((wave * 4 + i) * NQ + q) * 512 + l3 * 8);
+          }
+          if (in) epilogue8_tail_bf16(e, v, off_out, gcol, cur);
         }
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -927,7 +933,7 @@ int launch_w4_nw(const GemmParams& p, hipStream_t stream, bool persist) {
       const bool halo = g_w4_halo_host && w4_halo_ok(p);
       switch (g_w4_abl_host) {
 #define W4_CASE(a) case a: return halo ? launch_w4_mode<NW, W4_CONV_HALO, a>(p, stream, persist) : launch_w4_mode<NW, W4_CONV_S1, a>(p, stream, persist);
-        W4_CASE(1) W4_CASE(2) W4_CASE(3) W4_CASE(4) W4_CASE(5) W4_CASE(6) W4_CASE(7) W4_CASE(37)
+        W4_CASE(1) W4_CASE(2) W4_CASE(3) W4_CASE(4) W4_CASE(5) W4_CASE(6) W4_CASE(7) W4_CASE(8) W4_CASE(37)
 #undef W4_CASE
         default: break;
       }

@@ -720,6 +720,7 @@ static void persist_case(const char* name, int M, int N, int K1, int K2, int act
 }
 
 
+#ifdef FL_TIMING
 // s_memtime breakdown of one short-K linear launch on the full-line tile kernels (FL_STAMP 0 entry | 1 set-up done, ring fill issued |
 // 2 stage 0 landed | 3 K loop done | 4 stores issued | 7 stores retired), per workgroup, plus the launch's own span (first entry ->
 // last retire) against the wall time per launch in a back-to-back train of launches.
@@ -771,6 +772,7 @@ static void fl_timing_linear(const char* name, int M, int N, int K1, int K2, int
          ph[3] / n, ph[4] / n, tot, (double)(last - first), (double)(last_start - first));
   hipFree(tb);
 }
+#endif
 
 int main(int argc, char** argv) {
   hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, 0));
@@ -896,6 +898,7 @@ int main(int argc, char** argv) {
     printf("%s\n", g_fail ? "XS PROBE: FAILURES" : "XS PROBE: all pass");
     return g_fail ? 1 : 0;
   }
+#ifdef FL_TIMING
   if (argc > 1 && !strcmp(argv[1], "--shortk")) {   // verdict r5 item 2: where the fixed cost of the short-K linears sits
     const int cfgs[] = {35, 36, 1, 21, 24, 16, 10};
     for (int c : cfgs) fl_timing_linear("linear 2048x1280x1280", 2048, 1280, 1280, 0, c, 1, false);
@@ -908,6 +911,7 @@ int main(int argc, char** argv) {
     for (int c : {35, 36}) fl_timing_linear("linear 2048x1280x64 (one stage)", 2048, 1280, 64, 0, c, 1, false);
     return 0;
   }
+#endif
   if (argc > 1 && !strcmp(argv[1], "--w4")) {   // loader / consumer kernel: correctness, then interleaved A/B against the ping-pong tiles
     const bool quick = argc > 2 && !strcmp(argv[2], "quick");
     const bool abl_only = argc > 2 && !strcmp(argv[2], "abl");
@@ -972,10 +976,11 @@ w4_ablations:
         }
       cl::w4_halo_set(1);
     }
-    const int abls[] = {0, 1, 2, 3, 4, 5, 6, 7, 37};
+    const int abls[] = {0, 1, 2, 3, 4, 5, 6, 7, 37, 8};
     const char* an[] = {"full", "no fragment reads", "no DMA", "no reads, no DMA", "no stores", "no reads + no stores", "no DMA + no stores",
-                        "skeleton: MFMA + barrier only", "DMA + barriers only (no MFMA, no reads, no stores)"};
-    for (int ai = 0; ai < 9; ++ai) {
+                        "skeleton: MFMA + barrier only", "DMA + barriers only (no MFMA, no reads, no stores)",
+                        "stores as one contiguous KB per instruction (hypothesis test: is the drain slow because of 64-byte row pieces?)"};
+    for (int ai = 0; ai < 10; ++ai) {
       cl::w4_abl_set(abls[ai]);
       printf("---- ablation %d: %s (results wrong by construction; FAIL lines below are expected)\n", abls[ai], an[ai]);
       const int keep = g_fail;
