@@ -174,7 +174,7 @@ def dominant_kernel_rocprof():
             return None
         avg = us / n
         return dict(us_per_launch=round(avg, 2), launches_per_step=int(n), tflops=round(60.4e3 / avg, 1),
-                    frac=round(60.4e3 / avg / PEAK_BF16_TFLOPS, 4), source=os.path.relpath(path, ROOT) + " (static)", **provenance(meta))
+                    frac=round(60.4e3 / avg / PEAK_BF16_TFLOPS, 4), table=os.path.relpath(path, ROOT) + " (static)", **provenance(meta))
     except Exception:
         return None
 

@@ -93,3 +93,20 @@ def test_eight_real_ranks_through_spawn_ranks_dry_run():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 8 and out["world"] == 8 and out["dry_run"] and out["allreduce_sum_correct_on_every_rank"]
     assert len(out["ms_per_step_by_rank"]) == 8 and all(v > 0 for v in out["ms_per_step_by_rank"])
+
+
+def test_static_artefacts_the_bench_quotes_carry_commit_and_source_hash(tmp_path):
+    """every static number in the bench line (HBM traffic of the dominant kernel, its in-step rocprof time, the
+    stock comparator) names the commit it was measured at and is flagged `stale` when csrc/gemm.hip has changed since."""
+    import json
+    import bench
+    r = bench.dominant_kernel_rocprof()
+    assert r is not None and {"us_per_launch", "table", "measured_at_commit", "source_sha256_then", "source_sha256_now", "stale"} <= set(r)
+    assert r["stale"] == (r["source_sha256_then"] != r["source_sha256_now"])
+    with open(os.path.join(bench.ROOT, "profiles", "dominant_kernel_traffic.json")) as f:
+        t = json.load(f)
+    p = bench.provenance(t)
+    assert p["measured_at_commit"] and p["source_sha256_then"] and p["stale"] == (p["source_sha256_then"] != bench.src_hash("ctrlora_amd/csrc/gemm.hip"))
+    assert bench.provenance({})["stale"] and bench.provenance(None)["stale"]            # nothing recorded = stale
+    ips, src = bench.stock_reference()
+    assert ips > 0 and src.startswith("profiles/")
