@@ -47,6 +47,7 @@ int attn_bwd(const AttnBwdArgs& a, int dtype, hipStream_t st);
 int attn_fwd_tr(const AttnFwdArgs& a, const void* V, long ldv, hipStream_t st);
 int attn_bwd_tr(const AttnBwdArgs& a, hipStream_t st);
 extern int g_attn_fuse_delta;   // 1 = the dQ kernel forms delta (default), 0 = separate attn_delta launch
+extern int g_attn_variant_dkv4;
 extern int g_attn_variant;   // probe hook: 0 = heuristic, 1 = tile-synchronous kernels only (no ping-pong schedule)
 // pre-scaled-Q forward for d_head 40 (attention_fwd40.hip)
 bool attn_fwd40_applies(const AttnFwdArgs& a);

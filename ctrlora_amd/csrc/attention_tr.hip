@@ -600,7 +600,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hyb_kernel(AttnFwdArgs p, con
 // carry -delta / 1.0 and dP arrives as dP - delta.  Per score pair that leaves exp2, exp2, one packed multiply (5 -> 3 VALU).
 // The pieces come from row_ws (written by the dQ kernel, which runs first) as the pad chunk of the Q / dO tiles.
 template <int DH, int KF, bool TAIL, bool PRIO = false, bool FOLD = false>
-__global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_tr_kernel(AttnBwdArgs p) {
+__global__ __launch_bounds__(256, (DH <= 80 && KF <= 2 ? 2 : 1)) void attn_bwd_dkv_tr_kernel(AttnBwdArgs p) {
   using G = Geo<DH>;
   constexpr int CPR = G::CPR, KSTEPS = G::KSTEPS, DN = G::DN, ROWB = G::ROWB, TILE = G::TILE, TI = G::TI;
   static_assert(!FOLD || (DH == 40 && !TAIL), "the fold uses the pad chunk of the 96-byte pitch, whole tiles only");
@@ -1089,6 +1089,7 @@ static int set_lds(K kern, int bytes) {
   return CL_OK;
 }
 
+int g_attn_variant_dkv4 = 0;   // probe hook: variant 21 = dK/dV with four key fragments per wave (fold kernels)
 int g_attn_variant = 0;    // probe hook (csrc/debug_hooks.h): 1 = tile-synchronous kernels only, 11 = backward with s_setprio,
                            // 13 / 14 = hybrid forward with fragment lookahead 3 / 2 (also: skip the pre-scaled-Q forward)
 
@@ -1206,8 +1207,16 @@ static int launch_bwd_tr(const AttnBwdArgs& a, hipStream_t st) {
         done_f = true;
       }
       hipLaunchKernelGGL((attn_bwd_dq_tr_kernel<DH, KF, TK, true, false, true>), dim3(a.N / 128, a.H, a.B), dim3(256), LDS_DQ3, st, a);
-      if (a.dK)
+      if (a.dK) {
+        // probe (cl_debug_attention_variant(21)): FOUR key fragments per wave (64 keys, one wave per SIMD: the Q / dO fragments of a
+        // tile are read once per 64 keys instead of once per 32) -- VERDICT r5 item 4
+        if (g_attn_variant_dkv4 && a.Nkv % 256 == 0) {
+          static bool done4 = false;
+          if (!done4) { if (set_lds(&attn_bwd_dkv_tr_kernel<DH, 4, TQ, false, true>, LDS_DKV3)) return CL_ELAUNCH; done4 = true; }
+          hipLaunchKernelGGL((attn_bwd_dkv_tr_kernel<DH, 4, TQ, false, true>), dim3(a.Nkv / 256, a.H, a.B), dim3(256), LDS_DKV3, st, a);
+        } else
         hipLaunchKernelGGL((attn_bwd_dkv_tr_kernel<DH, KF, TQ, false, true>), dim3(a.Nkv / 128, a.H, a.B), dim3(256), LDS_DKV3, st, a);
+      }
       CL_CHECK_LAUNCH();
       return CL_OK;
     }

@@ -46,7 +46,9 @@ int cl_gemm_tune_size(void) { return gemm_tune_size(); }
 int cl_debug_attention_variant(int v) {
   switch (v) {
     case 0: case 1: case 11: case 13: case 14:
-      g_attn_variant = v; return CL_OK;
+      g_attn_variant = v; g_attn_variant_dkv4 = 0; return CL_OK;
+    case 21:                               // = 0 with the four-fragment dK/dV probe kernel
+      g_attn_variant = 0; g_attn_variant_dkv4 = 1; return CL_OK;
     default: return CL_EINVAL;
   }
 }

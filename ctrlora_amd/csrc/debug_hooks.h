@@ -9,7 +9,7 @@ extern "C" {
 /* attention schedule: 0 = default; 1 = tile-synchronous kernels only; 11 = backward with s_setprio;
  * 13 / 14 = hybrid forward (fragment lookahead 3 / 2) also where the pre-scaled-Q forward (attention_fwd40.hip) would
  * apply.  Unknown codes: CL_EINVAL, nothing changes. */
-int cl_debug_attention_variant(int variant);
+int cl_debug_attention_variant(int variant);   /* also 21 = 0 with the dK/dV kernel at FOUR key fragments per wave (round 6 probe: slower) */
 /* 1 (default) = the dQ kernel forms delta itself; 0 = separate attn_delta launch */
 int cl_debug_attention_fuse_delta(int on);
 /* GroupNorm launch forms: three_pass = 1 forces partial -> finalize -> apply; one_pass = 0 disables the one-launch

@@ -411,7 +411,8 @@ def test_attention_schedules_agree():
     for dh, N, B in ((40, 4096, 2), (80, 1024, 4)):
         errs = {}
         for name, variant, pre in (("sync", 1, False), ("hybrid", 14, False), ("sync+prescaled", 1, True),
-                                   ("hybrid+prescaled", 14, True), ("default+prescaled", 0, True)):
+                                   ("hybrid+prescaled", 14, True), ("default+prescaled", 0, True),
+                                   ("dkv 64 keys per wave (round-6 probe)+prescaled", 21, True)):
             errs[name] = _attention_case(dh, N, N, B, pre, variant=variant, q_std=1.3)
         _record("attention_schedules", dh=dh, N=N, **{k: v["o"] for k, v in errs.items()})
         worst = {k: max(v["o"], v["dq"], v["dk"], v["dv"]) for k, v in errs.items()}
