@@ -1,4 +1,5 @@
-// Loader / consumer tile kernel for the MFMA-bound contractions (bf16; launch configurations 40 / 41 of gemm.hip).
+// Loader / consumer tile kernel for the MFMA-bound contractions (bf16; launch configurations 40 / 41 of gemm.hip, and 47 / 48:
+// the same with one PERSISTENT workgroup per CU).
 //
 //   out[M,N] = epilogue( A1[M,K1].W1[N,K1]^T  (+ A2[M,K2].W2[N,K2]^T) )          linear, or implicit 3x3 conv over NHWC
 //
@@ -11,7 +12,9 @@
 // same FLOPs as v_mfma_f32_16x16x32_bf16 hold 1.88 GHz = 1.94 PF/s (a quarter of the accumulator traffic per FLOP); and every
 // KB moved beside the MFMAs comes out of the clock: +1 ds_read_b128 per 32-cycle MFMA slot -8.5 %, +1 LDS-DMA (1 KiB) per four
 // slots -7.5 %.  Costs ADD -- measured on the first form of this kernel (one 32x32x16 wave per SIMD, 64 x 160 per wave): MFMA
-// alone 29.5 us, + fragment reads +10, + DMA +17, + stores +11 = 64 us at 1.56 GHz against the ping-pong kernel's 55 at 2.08.
+// alone 29.5 us, + fragment reads +10, + DMA +17, + stores +11 = 64 us at 1.56 GHz against the ping-pong kernel's 55.  (s_memtime stamps in both kernels, later: the
+// ping-pong kernel's main loop is 1527 cycles per stage at 1.6 GHz, this kernel's final form 1606 at 1.68 GHz -- the same
+// 0.95 us per stage, i.e. both sit on the power limit of their operand traffic)
 // So the levers are joules, not issue slots: the cheaper MFMA shape, fewer DMA bytes per FLOP, no stall that is not hidden.
 //
 // Structure: two KINDS of wave, for the whole tile.
@@ -44,9 +47,24 @@
 //     (ky (W + 1) + kx), and only the 20 KB weight tile streams per stage.  K is walked chunk-major (chunk, tap) instead of
 //     tap-major.  LDS-DMA instructions per stage and SIMD: 13 -> 6.4; two image buffers (the next chunk's lands under this one's
 //     nine stages, its pieces riding on taps 2 .. 8: the loaders run two stages ahead, and the buffer they fill was read until the
-//     previous chunk's last tap) + the 3-slot weight ring = 158 KB.  The loaders SPECIALISE: waves 4-5 stream nothing but weight
+//     previous chunk's last tap) + the 3-slot weight ring + the epilogue operands' 2 KB = 160 KB.  (At the 32x32 / 16x16 levels the
+//     weight matrix outgrows an XCD's L2 and two stages of look-ahead no longer cover its latency: 2290 cycles per stage; the
+//     tuner keeps those on the ping-pong kernel.)  The loaders SPECIALISE: waves 4-5 stream nothing but weight
 //     tiles (L2-resident: every CU of the grid reads the same 1.8 MB), waves 6-7 nothing but image pieces (HBM / Infinity Cache) --
 //     vmcnt retires in order, and a weight tile must not wait behind an image piece nobody needs before the next chunk.
+//   * PERSISTENT form (configurations 47 / 48; whole-K tiles of >= 3 stages, more virtual tiles than CUs): grid = CUs rounded down
+//     to a multiple of 8, a workgroup walks tile ids id, id + grid, ... (all on its XCD) and the stages of ALL its tiles are one
+//     sequence for the ring: the loaders are two stages into the next tile while the consumers store the finished one, the
+//     halo image is handed over between tiles (its pieces for the next tile's first chunk ride on the last chunk's taps).
+//     Where it wins (tools/gemm_autotune.py, profiles/r06_tune/): launches with several tiles per CU -- the first stage's
+//     3x3 convs, DDIM-size linears.  One tile per CU (the training step's 64x64 convs at batch 8): the ping-pong kernel stays.
+//   * EPILOGUE: vmcnt retires in order, so ANY load behind a store -- a bias row, a residual vector, a scratch reload of an
+//     address the compiler parked before the main loop -- waits for every store before it; measured 12 us of a 59 us tile.
+//     Hence: a tile's bias floats / row-bias come to a 1 KB LDS block by one DMA issued with the tile's first stage (double-
+//     buffered by tile parity); accumulators leave the AGPR half by explicit v_accvgpr_read; each 16-row x 32-column unit
+//     re-derives its coordinates from v_mbcnt; the residual is fetched one row block ahead; no scratch anywhere (a tested
+//     property: tests/test_isa_gemm_w4.py).  What remains is the store issue rate of four waves (~190 cycles per
+//     global_store_dwordx4 and wave: 16.4 K cycles per tile where the ping-pong kernel's eight waves take 9.5 K).
 // All waves of a workgroup share one register allocation: 512 threads = two waves per SIMD = 256 registers; with accumulation
 // registers in use hipcc splits them 128 | 128, so 128 accumulators live in "a" registers, 32 in "v" beside 52 fragment registers.
 #include <type_traits>
