@@ -20,6 +20,12 @@ for p in "$@"; do
         hipcc $FLAGS -fPIC -DATTN_BWD_ABL=$a -c $C/attention_tr.hip -o build/abl/attention_tr_abl$a.o
         hipcc --offload-arch=gfx950 -shared -fPIC $(ls build/obj/*.o | grep -v attention_tr.o) build/abl/attention_tr_abl$a.o -o build/abl/libctrlora_hip_abl$a.so
       done ;;
+    preload)        # the product library with the command processor preloading kernel arguments into SGPRs (A/B: tools/r06_preload_ab.sh)
+      mkdir -p build/preload
+      for f in gemm gemm_xs gemm_w4 wgrad norm norm_coop elementwise attention_fwd attention_bwd attention_tr attention_fwd40 capi; do
+        hipcc $FLAGS -fPIC -mllvm -amdgpu-kernarg-preload-count=16 -c $C/$f.hip -o build/preload/$f.o &
+      done; wait
+      hipcc --offload-arch=gfx950 -shared -fPIC build/preload/*.o -o build/preload/libctrlora_hip_preload.so ;;
     *) echo "unknown probe $p"; exit 1 ;;
   esac
 done
