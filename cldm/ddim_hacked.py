@@ -310,3 +310,101 @@ class DDIMSampler(object):
         hip.ddim_step(x, e_c.float().contiguous(), None if e_u is None else e_u.float().contiguous(), noise.contiguous(),
                       self.coef_table, index, float(unconditional_guidance_scale), x_prev, pred_x0)
         return x_prev, pred_x0
+
+    # ------------------------------------------------------------------ inversion / img2img helpers
+    def _eps_pair(self, x, t, c, scale, uc):
+        """(eps_cond, eps_uncond or None) for one inversion step.  With guidance the reference evaluates ONE batch of 2B
+        ordered [unconditional; conditional] (cldm/ddim_hacked.py:257-262); tensors and same-structure dict conditionings
+        are batched that way here, anything else runs as two passes (the samples are independent)."""
+        if scale == 1.:
+            return self.model.apply_model(x, t, c), None
+        assert uc is not None
+        b = x.shape[0]
+        both = torch.cat((uc, c)) if torch.is_tensor(c) and torch.is_tensor(uc) else _cat_conds(uc, c)
+        if both is not None:
+            e = self.model.apply_model(torch.cat((x, x)), torch.cat((t, t)), both)
+            return e[b:].contiguous(), e[:b].contiguous()
+        return self.model.apply_model(x, t, c), self.model.apply_model(x, t, uc)
+
+    @torch.no_grad()
+    def encode(self, x0, c, t_enc, use_original_steps=False, return_intermediates=None,
+               unconditional_guidance_scale=1.0, unconditional_conditioning=None, callback=None):
+        """Deterministic DDIM inversion x0 -> x_{t_enc} (reference cldm/ddim_hacked.py:234-279):
+            x_next = sqrt(a_next / a) x + sqrt(a_next) (sqrt(1 / a_next - 1) - sqrt(1 / a - 1)) eps.
+        This is the sampler's own update with the roles of the two alphas exchanged and sigma = 0
+        (sqrt(a_next) (x - sqrt(1 - a) eps) / sqrt(a) + sqrt(1 - a_next) eps), so every step is ONE launch of the fused
+        guidance + update kernel on a table {a, a_next, 0, sqrt(1 - a)} instead of the reference's six elementwise
+        launches; the two forms differ by fp32 rounding only (tests: <= 2e-6 per step against the oracle's restatement of
+        the reference arithmetic).  Returns (x_encoded, {'x_encoded', 'intermediate_steps'[, 'intermediates']})."""
+        from ctrlora_amd import hip
+        steps_all = np.arange(self.ddpm_num_timesteps) if use_original_steps else self.ddim_timesteps
+        assert t_enc <= steps_all.shape[0]
+        n = int(t_enc)
+        if use_original_steps:
+            a_next, a_cur = self.alphas_cumprod[:n], self.alphas_cumprod_prev[:n]
+        else:
+            a_next, a_cur = self.ddim_alphas[:n], self.ddim_alphas_prev[:n]
+        as64 = lambda v: torch.as_tensor(np.asarray(v.detach().cpu() if torch.is_tensor(v) else v, dtype=np.float64))
+        a_next, a_cur = as64(a_next), as64(a_cur)
+        table = torch.stack([a_cur, a_next, torch.zeros(n, dtype=torch.float64), torch.sqrt(1. - a_cur)], dim=1)
+        table = table.to(torch.float32).contiguous().to(x0.device)
+        x = x0.float().contiguous()
+        b = x.shape[0]
+        kept, kept_at = [], []
+        every = (n // return_intermediates) if return_intermediates else 0
+        for i in range(n):
+            t = torch.full((b,), int(steps_all[i]), device=self.model.device, dtype=torch.long)
+            e_c, e_u = self._eps_pair(x, t, c, unconditional_guidance_scale, unconditional_conditioning)
+            x_new = torch.empty_like(x)
+            hip.ddim_step(x, e_c.float().contiguous(), None if e_u is None else e_u.float().contiguous(), None, table, i,
+                          float(unconditional_guidance_scale), x_new, None)
+            x = x_new
+            if return_intermediates and ((i % every == 0 and i < n - 1) or i >= n - 2):
+                kept.append(x)
+                kept_at.append(i)
+            if callback:
+                callback(i)
+        out = {"x_encoded": x, "intermediate_steps": kept_at}
+        if return_intermediates:
+            out.update({"intermediates": kept})
+        return x, out
+
+    @torch.no_grad()
+    def stochastic_encode(self, x0, t, use_original_steps=False, noise=None):
+        """q(x_t | x0) on the DDIM (or, use_original_steps, the DDPM) tables (reference cldm/ddim_hacked.py:282-295);
+        t indexes the table.  The forward-process kernel of the training path (cl_qsample) does the arithmetic."""
+        if use_original_steps:
+            sa, s1m = self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod
+        else:
+            sa, s1m = torch.sqrt(self.ddim_alphas), self.ddim_sqrt_one_minus_alphas
+        if noise is None:
+            noise = torch.randn_like(x0)
+        if not x0.is_cuda:
+            from ldm.modules.diffusionmodules.util import extract_into_tensor
+            as_t = lambda v: v if torch.is_tensor(v) else torch.as_tensor(np.asarray(v))
+            return (extract_into_tensor(as_t(sa), t, x0.shape) * x0 + extract_into_tensor(as_t(s1m), t, x0.shape) * noise)
+        from ctrlora_amd import hip
+        dev32 = lambda v: torch.as_tensor(np.asarray(v) if not torch.is_tensor(v) else v).to(x0.device, torch.float32).contiguous()
+        out = torch.empty_like(x0, dtype=torch.float32)
+        return hip.qsample(x0.float().contiguous(), noise.float().contiguous(), t.long().contiguous().to(x0.device),
+                           dev32(sa), dev32(s1m), out)
+
+    @torch.no_grad()
+    def decode(self, x_latent, cond, t_start, unconditional_guidance_scale=1.0, unconditional_conditioning=None,
+               use_original_steps=False, callback=None):
+        """The last t_start steps of the sampler from a given latent (reference cldm/ddim_hacked.py:298-317)."""
+        if use_original_steps:
+            raise NotImplementedError("option not used by the CtrLoRA sampling scripts")
+        timesteps = self.ddim_timesteps[:t_start]
+        total_steps = timesteps.shape[0]
+        print(f"Running DDIM Sampling with {total_steps} timesteps")
+        x_dec = x_latent
+        for i, step in enumerate(np.flip(timesteps)):
+            index = total_steps - i - 1
+            ts = torch.full((x_latent.shape[0],), int(step), device=x_latent.device, dtype=torch.long)
+            x_dec, _ = self.p_sample_ddim(x_dec, cond, ts, index=index,
+                                          unconditional_guidance_scale=unconditional_guidance_scale,
+                                          unconditional_conditioning=unconditional_conditioning)
+            if callback:
+                callback(i)
+        return x_dec

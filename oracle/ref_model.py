@@ -283,6 +283,72 @@ def ddim_sample(eps_fn, sched, S, x_T, scale=1.0, uncond=False, eta=0.0, noises=
     return img, steps
 
 
+def ddim_encode(eps_fn, sched, S, x0, t_enc, scale=1.0, uncond=False, keep=None):
+    """DDIMSampler.encode (ddim_hacked.py:234-279), DDIM tables (use_original_steps=False): deterministic inversion.
+    The dtypes follow the reference: alphas_next = ddim_alphas (fp32 tensor), alphas = torch.tensor(ddim_alphas_prev) (fp64), so
+    the two coefficients are formed in fp64 from 0-dim tensors and meet the fp32 sample at the multiply.
+    eps_fn(x, t_long, cond: bool); keep: optional list receiving x_next after every step."""
+    ds = make_ddim_schedule(sched, S, 0.0)
+    assert t_enc <= ds["timesteps"].shape[0]
+    alphas_next = ds["alphas"][:t_enc]
+    alphas = torch.tensor(ds["alphas_prev"][:t_enc])
+    x_next = x0
+    for i in range(t_enc):
+        t = torch.full((x0.shape[0],), int(ds["timesteps"][i]), dtype=torch.long)
+        e = eps_fn(x_next, t, True)
+        if scale != 1.0:
+            assert uncond
+            e_u = eps_fn(x_next, t, False)
+            e = e_u + scale * (e - e_u)
+        xw = (alphas_next[i] / alphas[i]).sqrt() * x_next
+        we = alphas_next[i].sqrt() * ((1 / alphas_next[i] - 1).sqrt() - (1 / alphas[i] - 1).sqrt()) * e
+        x_next = xw + we
+        if keep is not None:
+            keep.append(x_next)
+    return x_next
+
+
+def ddim_encode_keep_steps(t_enc, return_intermediates):
+    """Which step indices DDIMSampler.encode records as intermediates (ddim_hacked.py:267-272)."""
+    out = []
+    for i in range(t_enc):
+        if return_intermediates and i % (t_enc // return_intermediates) == 0 and i < t_enc - 1:
+            out.append(i)
+        elif return_intermediates and i >= t_enc - 2:
+            out.append(i)
+    return out
+
+
+def ddim_stochastic_encode(sched, S, x0, t, noise, use_original_steps=False):
+    """DDIMSampler.stochastic_encode (ddim_hacked.py:282-295): q(x_t | x0) with t indexing the DDIM (or DDPM) table."""
+    if use_original_steps:
+        # the SAMPLER's own tables (ddim_hacked.py:37-38): fp32 square roots of the fp32 alphas_cumprod -- not DDPM's
+        # (fp64 square roots rounded to fp32), which differ in the last bit
+        ac = sched["alphas_cumprod"]
+        sa, s1m = torch.sqrt(ac), torch.sqrt(1.0 - ac)
+    else:
+        ds = make_ddim_schedule(sched, S, 0.0)
+        sa, s1m = torch.sqrt(ds["alphas"]), torch.as_tensor(np.asarray(ds["sqrt_one_minus_alphas"]))
+    ex = lambda a: a.gather(-1, t).reshape(x0.shape[0], *((1,) * (x0.dim() - 1)))
+    return ex(sa) * x0 + ex(s1m) * noise
+
+
+def ddim_decode(eps_fn, sched, S, x_latent, t_start, scale=1.0, uncond=False, eta=0.0, noises=None):
+    """DDIMSampler.decode (ddim_hacked.py:298-317): p_sample_ddim over the first t_start DDIM timesteps, flipped."""
+    ds = make_ddim_schedule(sched, S, eta)
+    ts = ds["timesteps"][:t_start]
+    x = x_latent
+    for i, step in enumerate(np.flip(ts)):
+        index = ts.shape[0] - i - 1
+        t = torch.full((x.shape[0],), int(step), dtype=torch.long)
+        e_c = eps_fn(x, t, True)
+        e_u = eps_fn(x, t, False) if (uncond and scale != 1.0) else None
+        nz = noises[i] if noises is not None else None
+        x, _ = ddim_step(x, e_c, e_u, scale, ds["alphas"][index], ds["alphas_prev"][index], ds["sigmas"][index],
+                         ds["sqrt_one_minus_alphas"][index], nz)
+    return x
+
+
 def adamw_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, wd=1e-2):
     """torch.optim.AdamW defaults as used by configure_optimizers
     (cldm/cldm_ctrlora_finetune.py:105): decoupled weight decay, bias-corrected moments."""

@@ -495,6 +495,54 @@ def test_lora_modules_standalone_on_gpu():
     assert rel_l2(lin(g["x"].cuda()), g["y_fused"]) < 1e-5
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_lora_modules_standalone_are_differentiable(dtype, tol):
+    """The reference's LoRACompatibleLinear / LoRALinearLayer are ordinary autograd modules (cldm/lora.py:70-80, 285-291): the
+    stand-alone mirror must give the gradients of x, W, b, A (down) and B (up) -- every product on the HIP GEMM kernel --
+    that torch autograd gives for the same expression in fp64."""
+    _need_gpu()
+    from cldm.lora import LoRACompatibleLinear, LoRALinearLayer
+    torch.manual_seed(0)
+    lin = LoRACompatibleLinear(96, 64, lora_layer=LoRALinearLayer(96, 64, rank=32, network_alpha=16.0)).cuda()
+    torch.nn.init.normal_(lin.lora_layer.up.weight, std=0.05)
+    x = torch.randn(5, 7, 96, device="cuda").to(dtype).requires_grad_(True)
+    y = lin(x, scale=0.7)
+    assert y.requires_grad and y.dtype == dtype
+    go = torch.randn_like(y)
+    y.backward(go)
+    # fp64 reference of the same expression on the values the kernel saw
+    W, b = lin.weight.detach().double(), lin.bias.detach().double()
+    A, B = lin.lora_layer.down.weight.detach().double(), lin.lora_layer.up.weight.detach().double()
+    if dtype == torch.bfloat16:
+        W, A, B = (t.to(dtype).double() for t in (W, A, B))
+    xr = x.detach().double().requires_grad_(True)
+    ps = [t.requires_grad_(True) for t in (W, b, A, B)]
+    s = 0.7 * 16.0 / 32
+    yr = torch.nn.functional.linear(xr, ps[0], ps[1]) + s * torch.nn.functional.linear(torch.nn.functional.linear(xr, ps[2]), ps[3])
+    yr.backward(go.double())
+    assert rel_l2(y.detach().double(), yr.detach()) < tol
+    got = dict(x=x.grad, W=lin.weight.grad, b=lin.bias.grad, A=lin.lora_layer.down.weight.grad, B=lin.lora_layer.up.weight.grad)
+    want = dict(x=xr.grad, W=ps[0].grad, b=ps[1].grad, A=ps[2].grad, B=ps[3].grad)
+    for k in got:
+        assert got[k] is not None and got[k].shape == want[k].shape, k
+        assert rel_l2(got[k].double(), want[k]) < tol, (k, rel_l2(got[k].double(), want[k]))
+    # the LoRA layer alone (LoRALinearLayer.forward) and a frozen base weight: only what requires grad gets one
+    lora = LoRALinearLayer(96, 64, rank=32).cuda()
+    torch.nn.init.normal_(lora.up.weight, std=0.05)
+    lora.down.weight.requires_grad_(False)
+    x2 = torch.randn(3, 96, device="cuda", dtype=dtype)
+    out = lora(x2)
+    out.float().pow(2).sum().backward()
+    assert lora.down.weight.grad is None and lora.up.weight.grad is not None
+    ur = lora.up.weight.detach().double().requires_grad_(True)
+    dn = lora.down.weight.detach().double()
+    if dtype == torch.bfloat16:
+        dn = dn.to(dtype).double()
+    ref = torch.nn.functional.linear(torch.nn.functional.linear(x2.double(), dn), ur.to(dtype).double() if dtype == torch.bfloat16 else ur)
+    ref.pow(2).sum().backward()
+    assert rel_l2(lora.up.weight.grad.double(), ur.grad) < 2 * tol
+
+
 def test_graphed_ddim_with_image_hint_resamples_the_posterior_on_the_device():
     """DDIMSampler's hipGraph path with a real (3-channel) condition image and a non-Identity first stage: the
     VAE posterior of the hint is encoded once per run, but SAMPLED in every apply_model call (reference:

@@ -42,6 +42,31 @@ def main():
     if nsteps:
         print(f"steady state: {nsteps} steps -> {len(rows)/nsteps:.1f} dispatches, {tot/1e6/nsteps:.3f} ms GPU busy, "
               f"{(t1-t0)/1e6/nsteps:.3f} ms wall per step")
+    if "--gaps" in sys.argv:
+        # timeline coverage: time with >= 1 kernel running (union of intervals), time with >= 2, and the idle gaps between kernels
+        ev = sorted([(s, 1) for _, s, e in rows] + [(e, -1) for _, s, e in rows])
+        depth, last, cover, over, gaps = 0, ev[0][0], 0, 0, []
+        for t, d in ev:
+            if depth >= 1: cover += t - last
+            if depth >= 2: over += t - last
+            if depth == 0 and t > last: gaps.append(t - last)
+            depth += d; last = t
+        k = max(1, nsteps or 1)
+        wall = t1 - t0
+        # the largest gaps with the kernels on either side (copies / memsets / event waits of the graph are not kernels: they show here)
+        srt = sorted(rows, key=lambda r: r[1])
+        big, end_so_far, last_name = [], srt[0][2], srt[0][0]
+        for n, s_, e_ in srt[1:]:
+            if s_ > end_so_far: big.append((s_ - end_so_far, short(last_name)[:60], short(n)[:60]))
+            if e_ > end_so_far: end_so_far, last_name = e_, n
+        big.sort(reverse=True)
+        for g_, a_, b_ in big[:16 * k if False else 24]:
+            print(f"  gap {g_/1e3:8.1f} us   after {a_:60s} before {b_}")
+        gaps.sort()
+        k = max(1, nsteps or 1)
+        print(f"timeline: covered {cover/1e6/k:.3f} ms, two or more kernels at once {over/1e6/k:.3f} ms, idle {(wall-cover)/1e6/k:.3f} ms per step "
+              f"({100*(wall-cover)/wall:.1f} % of the wall) in {len(gaps)/k:.0f} gaps per step; gap median {gaps[len(gaps)//2]/1e3:.2f} us, "
+              f"p90 {gaps[int(len(gaps)*0.9)]/1e3:.2f} us, max {gaps[-1]/1e3:.1f} us" if gaps else "timeline: no gaps")
     print(f"{'name':110s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>9s} {'%':>6s}")
     for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
         print(f"{n:110s} {c:7d} {t/1e6:10.3f} {t/c/1e3:9.2f} {100*t/tot:6.2f}")
