@@ -376,7 +376,8 @@ class DDIMSampler(object):
         if use_original_steps:
             sa, s1m = self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod
         else:
-            sa, s1m = torch.sqrt(self.ddim_alphas), self.ddim_sqrt_one_minus_alphas
+            # (square roots on the host: correctly rounded, the values the reference's tables hold on CPU)
+            sa, s1m = torch.sqrt(self.ddim_alphas.cpu()), self.ddim_sqrt_one_minus_alphas
         if noise is None:
             noise = torch.randn_like(x0)
         if not x0.is_cuda:

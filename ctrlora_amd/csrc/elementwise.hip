@@ -175,9 +175,13 @@ __global__ void timestep_embed_kernel(const long* __restrict__ t, const float* _
 __global__ void qsample_kernel(const float* __restrict__ z, const float* __restrict__ noise,
                                const long* __restrict__ t, const float* __restrict__ sqrt_ac,
                                const float* __restrict__ sqrt_1mac, float* __restrict__ out, long per, long n) {
+  // two rounded products and a rounded sum, as torch evaluates a * z + b * noise: with the default contraction the sum
+  // becomes an FMA and differs from the reference's x_noisy / stochastic_encode in the last bit of some elements
+#pragma clang fp contract(off)
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const long tb = t[i / per];
-    out[i] = sqrt_ac[tb] * z[i] + sqrt_1mac[tb] * noise[i];
+    const float a = sqrt_ac[tb] * z[i], b = sqrt_1mac[tb] * noise[i];
+    out[i] = a + b;
   }
 }
 // loss += sum((eps - target)^2) / n ; d_eps = 2 (eps - target) / n * gscale
