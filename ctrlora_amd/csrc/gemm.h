@@ -11,7 +11,19 @@ enum GemmMode {
   GEMM_CONV_UP2 = 3, // 3x3 over the nearest-x2 upsampled input (Upsample, openaimodel.py:115-117)
   GEMM_CONV_T2 = 4,  // 3x3 over the zero-stuffed x2 grid (= data-gradient of GEMM_CONV_S2)
   GEMM_CONV_S2A = 5, // 3x3, stride 2, pad (0,1,0,1): the VAE encoder's Downsample (ldm/modules/diffusionmodules/model.py:80-84)
+  // Phase-decomposed forms of UP2 / T2 (full-line kernel only).  An output pixel (2y + a, 2x + b) of either product touches
+  // only a 2 x 2 (UP2) or (1 + a) x (1 + b) (T2) window of SOURCE pixels, so each of the four output phases (a, b) is a small
+  // stride-1 window product on the source grid -- 4 K1 (UP2: the 3x3 taps that fall on the same source pixel are summed
+  // into one weight) or on average 2.25 K1 (T2: the taps whose zero-stuffed input is non-zero) deep instead of 9 K1.
+  // A1 = source NHWC [B, Hin, Win, K1]; M = 4 B Hin Win, internal row order [phase = 2a + b][b][y][x] (B Hin Win a multiple of
+  // the tile height), mapped to output row ((b Hin + y) 2 + a) 2 Win + 2 x + b in the epilogue (C, residual, rowbias);
+  // W1 = phase-packed weights, phase ph at element offset N K1 * {0, 4, 8, 12} (UP2P) / {0, 1, 3, 5} (T2P), rows [N][taps][K1],
+  // tap t = ty * ntx + tx reading source pixel (y + dy0 + ty, x + dx0 + tx): UP2P dy0 = a - 1, dx0 = b - 1, 2 x 2 taps;
+  // T2P dy0 = dx0 = 0, (1 + a) x (1 + b) taps.  ldw1 is ignored.
+  GEMM_CONV_UP2P = 6,
+  GEMM_CONV_T2P = 7,
 };
+__host__ __device__ inline bool gemm_phase_mode(int mode) { return mode == GEMM_CONV_UP2P || mode == GEMM_CONV_T2P; }
 
 enum GemmAct {
   ACT_NONE = 0, ACT_SILU = 1,

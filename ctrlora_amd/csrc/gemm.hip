@@ -459,7 +459,20 @@ __device__ __forceinline__ void fl_tile(const GemmParams& p, int tiles_m, int ti
   const int m0 = (pid / tiles_n) * BM, n0 = (pid % tiles_n) * BN;
 
   const int cpt = p.K1 / KPS;  // stages per tap
-  const int ks1 = (MODE == FL_LINEAR ? 1 : 9) * cpt;
+  // phase-decomposed UP2 / T2 (gemm.h): this tile's phase, its window of source pixels and its weight block
+  int ph_mq = 0, ph = 0, ph_ntx = 3, ph_dy0 = 0, ph_dx0 = 0, ntaps = 9;
+  long ph_woff = 0;
+  if constexpr (MODE == FL_CONV_ANY) {
+    if (gemm_phase_mode(p.mode)) {
+      ph_mq = p.B * p.Hin * p.Win;
+      ph = m0 / ph_mq;
+      const int a = ph >> 1, b = ph & 1;
+      if (p.mode == GEMM_CONV_UP2P) { ph_ntx = 2; ntaps = 4; ph_dy0 = a - 1; ph_dx0 = b - 1; ph_woff = (long)ph * 4 * p.N * p.K1; }
+      else { ph_ntx = 1 + b; ntaps = (1 + a) * (1 + b); ph_woff = (long)p.N * p.K1 * (ph == 0 ? 0 : ph == 1 ? 1 : ph == 2 ? 3 : 5); }
+    }
+  }
+  const long ldw1 = ph_mq ? (long)ntaps * p.K1 : p.ldw1;
+  const int ks1 = (MODE == FL_LINEAR ? 1 : ntaps) * cpt;
   const int ks2 = (MODE == FL_LINEAR) ? p.K2 / KPS : 0;
   int kbeg = 0, kend = ks1 + ks2;
   if (p.splitk > 1) {
@@ -490,8 +503,10 @@ __device__ __forceinline__ void fl_tile(const GemmParams& p, int tiles_m, int ti
                   : (const char*)p.A1 + ((long)r * p.lda1 + (p.a1_group_n ? (long)(n0 / p.a1_group_n) * p.K1 : 0)) * sizeof(T) +
                         chunk + (long)kbeg * 128;
     } else {
-      const int ox = r % p.Wout; const int t = r / p.Wout;
-      const int oy = t % p.Hout, ob = t / p.Hout;
+      const int rq = ph_mq ? r - ph * ph_mq : r;            // phase modes: rows live on the SOURCE grid
+      const int gw = ph_mq ? p.Win : p.Wout, gh = ph_mq ? p.Hin : p.Hout;
+      const int ox = rq % gw; const int t = rq / gw;
+      const int oy = t % gh, ob = t / gh;
       if constexpr (MODE == FL_CONV_S1) {
         pa[j] = (const char*)p.A1 + ((((long)ob * p.Hin + oy) * p.Win + ox) * p.lda1) * sizeof(T) + chunk;
         uint32_t m = 0;
@@ -520,7 +535,7 @@ __device__ __forceinline__ void fl_tile(const GemmParams& p, int tiles_m, int ti
     w2[j] = (MODE == FL_LINEAR && p.W2) ? (const char*)p.W2 + ((long)n * p.ldw2) * sizeof(T) + chunk : nullptr;
     pw[j] = (MODE == FL_LINEAR && kbeg >= ks1)
                 ? w2[j] + (long)(kbeg - ks1) * 128
-                : (const char*)p.W1 + ((long)n * p.ldw1) * sizeof(T) + chunk + (long)kbeg * 128;
+                : (const char*)p.W1 + (ph_woff + (long)n * ldw1) * sizeof(T) + chunk + (long)kbeg * 128;
   }
   const char* zpage = (const char*)p.zero_page + lslot * 16;
 
@@ -567,9 +582,11 @@ __device__ __forceinline__ void fl_tile(const GemmParams& p, int tiles_m, int ti
       const int sy = (p.mode == GEMM_CONV_S2 || p.mode == GEMM_CONV_S2A) ? 2 : 1;
       const int po = (p.mode == GEMM_CONV_S2A) ? 0 : 1;     // left / top padding
       const bool virt = (p.mode == GEMM_CONV_UP2) | (p.mode == GEMM_CONV_T2);
+      const int pty = ph_ntx == 2 ? tap >> 1 : tap, ptx = ph_ntx == 2 ? tap & 1 : 0;   // phase modes: window tap
 #pragma unroll
       for (int j = 0; j < AJ; ++j) {
-        const int vy = ay[j] * sy + ky - po, vx = ax[j] * sy + kx - po;
+        const int vy = ph_mq ? ay[j] + ph_dy0 + pty : ay[j] * sy + ky - po;
+        const int vx = ph_mq ? ax[j] + ph_dx0 + ptx : ax[j] * sy + kx - po;
         bool ok; int iy, ix;
         if (virt) {
           ok = ((unsigned)vy < (unsigned)(2 * p.Hin)) & ((unsigned)vx < (unsigned)(2 * p.Win));
@@ -1080,9 +1097,11 @@ static int launch_fl_mode(const GemmParams& p0, hipStream_t stream) {
   const int kps = 128 / (int)sizeof(T);
   const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
   const long tiles = (long)tm * tn;
-  const int steps = ((MODE == FL_LINEAR ? 1 : 9) * p.K1 + p.K2) / kps;
+  const int steps = ((MODE == FL_LINEAR ? 1 : p.mode == GEMM_CONV_UP2P ? 4 : 9) * p.K1 + p.K2) / kps;
   float* slab;
-  pick_splitk(p, tiles, steps, R == 3 ? (BM == 128 ? g_fl128_split_want : 256) : 512, 4, &slab, stream);
+  if (gemm_phase_mode(p.mode) && (p.B * p.Hin * p.Win) % BM) return CL_EINVAL;   // a tile lies inside one phase
+  if (p.mode == GEMM_CONV_T2P) { p.splitk = 1; slab = nullptr; }   // (its phases are 1 / 2 / 2 / 4 taps deep: no uniform K split)
+  else pick_splitk(p, tiles, steps, R == 3 ? (BM == 128 ? g_fl128_split_want : 256) : 512, 4, &slab, stream);
   const long nvirt = tiles * p.splitk;
   if constexpr (PERSIST) {
     // as many workgroups as stay resident together (LDS-bound: one per CU above 80 KB, else two), a multiple of 8
@@ -1364,6 +1383,31 @@ int launch_gemm(const GemmParams& p, int dtype, hipStream_t stream) {
   if (p.rowbias && p.rows_per_batch <= 0) return CL_EINVAL;
   if (p.act == ACT_GEGLU && (p.N % 160 || p.rowbias || p.residual || p.atomic || p.alpha != 1.0f)) return CL_EINVAL;
   t_tag = tag_for(p, dtype);
+  if (gemm_phase_mode(p.mode)) {
+    // phase-decomposed UP2 / T2 (gemm.h): the full-line kernel's generic-conv form only.  256-row tiles where the grid fills
+    // the chip (or splits K to: UP2P), else 128-row tiles; g_gemm_force_cfg 8 / 9 / 10 / 11 impose 256 x {160, 128} / 128 x {160, 128}.
+    const int kps = dtype == CL_BF16 ? 64 : 32;
+    const long mq = (long)p.B * p.Hin * p.Win;
+    if (p.K1 % kps || p.K2 || p.atomic || p.act == ACT_GEGLU || p.a1_group_n || p.a2_group_n || p.M != 4 * mq || mq % 128 ||
+        p.Hout != 2 * p.Hin || p.Wout != 2 * p.Win || p.N < 96)
+      return CL_EINVAL;
+    const int bn = (p.N % 160 == 0) ? 160 : 128;
+    bool big = false;   // measured (tools/time_conv_phase.py): 128-row tiles win by 3-12 % at every production shape (uneven phase depths, 2 workgroups per CU)
+    if (g_gemm_force_cfg == 8 || g_gemm_force_cfg == 9) big = mq % 256 == 0;
+    if (g_gemm_force_cfg == 10 || g_gemm_force_cfg == 11) big = false;
+    const bool n160 = g_gemm_force_cfg >= 8 && g_gemm_force_cfg <= 11 ? (g_gemm_force_cfg % 2 == 0 && p.N % 160 == 0) : bn == 160;
+    t_force_sk = g_gemm_force_splitk;
+    int rc;
+    if (dtype == CL_BF16) {
+      rc = big ? (n160 ? launch_fl<bf16_t, 256, 160, 4, 2, 3>(p, stream) : launch_fl<bf16_t, 256, 128, 4, 2, 3>(p, stream))
+               : (n160 ? launch_fl<bf16_t, 128, 160, 2, 2, 2>(p, stream) : launch_fl<bf16_t, 128, 128, 2, 2, 2>(p, stream));
+    } else {
+      rc = big ? (n160 ? launch_fl<float, 256, 160, 4, 2, 3>(p, stream) : launch_fl<float, 256, 128, 4, 2, 3>(p, stream))
+               : (n160 ? launch_fl<float, 128, 160, 2, 2, 2>(p, stream) : launch_fl<float, 128, 128, 2, 2, 2>(p, stream));
+    }
+    t_force_sk = 0;
+    return rc;
+  }
   if (p.act == ACT_GEGLU_SPLIT || p.ln_gamma)   // natural-order GEGLU rows / LayerNorm prologue: the x-stationary kernel only (gemm_xs.hip)
     return dtype == CL_BF16 ? launch_gemm_xs(p, stream, g_gemm_force_splitk) : CL_EINVAL;
   if (p.a1_group_n < 0 || p.a2_group_n < 0) return CL_EINVAL;

@@ -10,11 +10,17 @@ struct EpiArgs {
   const float* bias; const void* rowbias; long ldrb; int rows_per_batch;
   const void* residual; long ldr; float alpha, beta; int act;
   void* C; long ldc; int out_f32; int atomic; int M, N; int alpha_n;
+  int ph_mq, ph_win;   // phase-decomposed conv modes (gemm.h): rows per phase, source width; 0 = rows are output rows
 };
 
 // apply the epilogue to 8 consecutive columns of one row and store
 template <typename T>
 __device__ __forceinline__ void epilogue8(const EpiArgs& e, float v[8], int grow, int gcol) {
+  if (e.ph_mq) {   // internal row [phase][b][y][x] -> output pixel (2y + a, 2x + b) of the interleaved grid
+    const int ph = grow / e.ph_mq, r = grow - ph * e.ph_mq;
+    const int q = r / e.ph_win, x = r - q * e.ph_win;
+    grow = (q * 2 + (ph >> 1)) * (2 * e.ph_win) + 2 * x + (ph & 1);
+  }
   if (e.bias) {
     const float4 b0 = *reinterpret_cast<const float4*>(e.bias + gcol);
     const float4 b1 = *reinterpret_cast<const float4*>(e.bias + gcol + 4);
@@ -81,6 +87,7 @@ __device__ __forceinline__ EpiArgs epi_of(const GemmParams& p) {
   e.bias = p.bias; e.rowbias = p.rowbias; e.ldrb = p.ldrb; e.rows_per_batch = p.rows_per_batch;
   e.residual = p.residual; e.ldr = p.ldr; e.alpha = p.alpha; e.beta = p.beta; e.act = p.act;
   e.C = p.C; e.ldc = p.ldc; e.out_f32 = p.out_f32; e.atomic = p.atomic; e.M = p.M; e.N = p.N; e.alpha_n = p.alpha_n;
+  e.ph_mq = gemm_phase_mode(p.mode) ? p.B * p.Hin * p.Win : 0; e.ph_win = p.Win;
   return e;
 }
 

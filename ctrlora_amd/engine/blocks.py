@@ -18,11 +18,10 @@ Reference modules restated (behaviour, not code):
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
-
-import os
 
 from .. import hip
 from .packing import Conv3W, LinearW, NormW, rup
@@ -281,8 +280,31 @@ class LayerNormOp:
 
 # --------------------------------------------------------------------------- conv helpers
 
+# Phase-decomposed Upsample conv / Downsample data gradient (hip.CONV_UP2P / CONV_T2P: 2.25x / 4x fewer MACs, same results):
+# frozen convs whose channels are whole 128-byte lines and whose source grid fills 128-row tiles.  CTRLORA_CONV_PHASE=0: A/B switch.
+CONV_PHASE = os.environ.get("CTRLORA_CONV_PHASE", "1") != "0"
+
+
+def _phase_ok(ctx: Ctx, cw: Conv3W, B, Hs, Ws, k1, n, t2=False):
+    kq = 64 if ctx.dtype == torch.bfloat16 else 32
+    ok = CONV_PHASE and cw.tW is None and (B * Hs * Ws) % 128 == 0 and k1 % kq == 0 and n >= 96
+    if ok and t2:
+        # the data-gradient form has phases 1 / 2 / 2 / 4 taps deep and therefore no K split: it needs the tile grid alone to
+        # fill the chip (8 x 8 x 1280 at batch 8: 128 tiles, 95 us against the nine-tap mode's split-K 83 us -- profiles/r06_phase/)
+        ok = (4 * B * Hs * Ws // 128) * ((n + 159) // 160) >= 192
+    return bool(ok)
+
+
 def conv3_fwd(ctx: Ctx, cw: Conv3W, x, B, Hin, Win, mode=hip.CONV_S1, out=None, rowbias=None, residual=None,
               out_f32=False):
+    if mode == hip.CONV_UP2 and _phase_ok(ctx, cw, B, Hin, Win, cw.Ip, cw.Op):
+        M = 4 * B * Hin * Win
+        if out is None:
+            out = ctx.new(M, cw.Op, torch.float32 if out_f32 else None)
+        hip.gemm(x, cw.phase_weights("up2"), out, bias=cw.bias, rowbias=rowbias, rows_per_batch=4 * Hin * Win, residual=residual,
+                 beta=1.0 if residual is not None else 0.0, mode=hip.CONV_UP2P, conv=(B, Hin, Win, 2 * Hin, 2 * Win), k1=cw.Ip,
+                 out_f32=out_f32, N=cw.Op)
+        return out
     if mode in (hip.CONV_S2, hip.CONV_S2A):
         Ho, Wo = Hin // 2, Win // 2
     elif mode == hip.CONV_UP2:
@@ -311,6 +333,10 @@ def conv3_bwd_data(ctx: Ctx, cw: Conv3W, dy, B, Hdy, Wdy, fwd_mode=hip.CONV_S1, 
         M = B * 4 * Hdy * Wdy
         if out is None:
             out = ctx.new(M, cw.Ip)
+        if _phase_ok(ctx, cw, B, Hdy, Wdy, cw.Op, cw.Ip, t2=True):     # only the taps whose zero-stuffed input is non-zero
+            hip.gemm(dy, cw.phase_weights("t2"), out, residual=accum, beta=1.0 if accum is not None else 0.0,
+                     mode=hip.CONV_T2P, conv=(B, Hdy, Wdy, 2 * Hdy, 2 * Wdy), k1=cw.Op, N=cw.Ip)
+            return out
         hip.gemm(dy, cw.Wd, out, residual=accum, beta=1.0 if accum is not None else 0.0, mode=hip.CONV_T2,
                  conv=(B, Hdy, Wdy, 2 * Hdy, 2 * Wdy), k1=cw.Op, N=cw.Ip)
         return out

@@ -253,7 +253,43 @@ class Conv3W:
         self.bias = torch.zeros(self.Op, dtype=torch.float32, device=device)
         self.tW: Optional[Trainable] = None     # trainable weight (Base-ControlNet pre-training), master [O][9][Ip]
         self.tb: Optional[Trainable] = None
+        self._phase = {}                        # phase-packed forms (phase_weights), built on first use, dropped by load()
         self.load(W, bias)
+
+    def phase_weights(self, kind: str) -> torch.Tensor:
+        """Weights of the phase-decomposed products (include/ctrlora_hip.h: CL_GEMM_CONV_UP2P / T2P), built once from the packed
+        forward weights of a FROZEN conv.
+
+        'up2' (Upsample.conv over the nearest-x2 input, openaimodel.py:108-118): output pixel (2y + a, 2x + b) reads source
+        rows {y - 1, y} (a = 0: tap ky = 0 | taps 1 + 2) or {y, y + 1} (a = 1: taps 0 + 1 | tap 2), columns likewise: the 3x3
+        taps that land on one source pixel are SUMMED (fp32, one rounding to the compute dtype).  [4 phases][Op][2x2][Ip].
+        't2' (data gradient of Downsample's stride-2 conv, :150; in = 2 out + k - 1): an even input row gets tap ky = 1 of
+        output row y, an odd one tap 2 of row y and tap 0 of row y + 1.  Phase (a, b): [Ip][(1 + a)(1 + b)][Op], concatenated."""
+        if kind in self._phase:
+            return self._phase[kind]
+        assert self.tW is None, "phase-packed weights are built once: frozen convs only"
+        W = self.Wp.float().view(self.Op, 3, 3, self.Ip)                     # [o][ky][kx][i]
+        if kind == "up2":
+            grp = {(0, 0): [0], (0, 1): [1, 2], (1, 0): [0, 1], (1, 1): [2]}
+            out = torch.empty(4, self.Op, 4, self.Ip, dtype=torch.float32, device=W.device)
+            for a in range(2):
+                for b in range(2):
+                    for ty in range(2):
+                        for tx in range(2):
+                            out[2 * a + b, :, 2 * ty + tx] = W[:, grp[(a, ty)]][:, :, grp[(b, tx)]].sum(dim=(1, 2))
+            packed = out.reshape(-1)
+        elif kind == "t2":
+            taps = {0: [1], 1: [2, 0]}                                        # window offset 0, +1 -> forward tap index
+            blocks = []
+            for a in range(2):
+                for b in range(2):
+                    blk = torch.stack([W[:, ky, kx].t() for ky in taps[a] for kx in taps[b]], dim=1)   # [Ip][nt][Op]
+                    blocks.append(blk.reshape(-1))
+            packed = torch.cat(blocks)
+        else:
+            raise ValueError(kind)
+        self._phase[kind] = packed.to(self.Wp.dtype).contiguous().view(1, -1)     # (ldw1 is not used by these modes)
+        return self._phase[kind]
 
     def attach_trainable(self, tW: Trainable, tb: Trainable):
         assert self.O == self.Op, "trainable 3x3 convs have O % 32 == 0"
@@ -272,6 +308,7 @@ class Conv3W:
     def load(self, W: torch.Tensor, bias: torch.Tensor):
         """(Re)pack in place: [O][ky][kx][I] and the tap-flipped data-gradient form [I][2-ky][2-kx][O]."""
         device = self.Wp.device
+        self._phase = {}
         W = W.to(device=device, dtype=torch.float32)
         assert W.shape[0] == self.O and W.shape[1] == self.I
         Wpad = torch.zeros(self.Op, self.Ip, 3, 3, dtype=torch.float32, device=device)

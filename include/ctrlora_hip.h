@@ -76,8 +76,16 @@ enum cl_gemm_mode {
   CL_GEMM_CONV_S2 = 2,  /* 3x3 stride 2 pad 1                                                */
   CL_GEMM_CONV_UP2 = 3, /* 3x3 over nearest-x2 upsampled input                               */
   CL_GEMM_CONV_T2 = 4,  /* 3x3 over zero-stuffed x2 grid: data-gradient of CL_GEMM_CONV_S2   */
-  CL_GEMM_CONV_S2A = 5  /* 3x3 stride 2, pad (0,1,0,1): AutoencoderKL's Downsample
+  CL_GEMM_CONV_S2A = 5, /* 3x3 stride 2, pad (0,1,0,1): AutoencoderKL's Downsample
                            (ldm/modules/diffusionmodules/model.py:80-84)                        */
+  /* Phase-decomposed forms of UP2 / T2 with the same results (Upsample.forward, openaimodel.py:108-118; the data gradient of
+   * Downsample's stride-2 conv, :150): output pixel (2y + a, 2x + b) depends on a 2 x 2 (UP2) / (1 + a) x (1 + b) (T2) window
+   * of source pixels only, so the four phases (a, b) are stride-1 window products 4 K1 / on average 2.25 K1 deep instead
+   * of 9 K1.  A1 = source NHWC [B,Hin,Win,K1]; M = 4 B Hin Win (B Hin Win a multiple of 128), Hout = 2 Hin, Wout = 2 Win;
+   * C / residual / rowbias rows are OUTPUT pixels (the kernel interleaves the phases); W1 = phase-packed weights
+   * (ctrlora_amd/engine/packing.py: Conv3W.phase_weights), ldw1 ignored.  bf16 / fp32, K1 whole 128-byte lines, no K2.   */
+  CL_GEMM_CONV_UP2P = 6,
+  CL_GEMM_CONV_T2P = 7
 };
 
 typedef struct cl_gemm_params {
