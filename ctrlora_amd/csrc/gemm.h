@@ -22,6 +22,11 @@ enum GemmMode {
   // T2P dy0 = dx0 = 0, (1 + a) x (1 + b) taps.  ldw1 is ignored.
   GEMM_CONV_UP2P = 6,
   GEMM_CONV_T2P = 7,
+  // 4x4 window, stride 2, pad 1 (full-line kernel only): the data gradient of UP2 (nearest x2 + 3x3 conv) taken directly on
+  // the SOURCE grid -- source pixel y receives from upsampled rows 2y - 1 .. 2y + 2, with the 3x3 taps that coincide summed
+  // (16 K1 deep at M / 4 rows = 4 K1 M instead of the 9 K1 M of a stride-1 data gradient on the upsampled grid + a 2x2 pool).
+  // A1 = dy NHWC [B, Hin, Win, K1] on the upsampled grid, Hout = Hin / 2, Wout = Win / 2, W1 = [N][4][4][K1] (ldw1 = 16 K1).
+  GEMM_CONV_S2K4 = 8,
 };
 __host__ __device__ inline bool gemm_phase_mode(int mode) { return mode == GEMM_CONV_UP2P || mode == GEMM_CONV_T2P; }
 

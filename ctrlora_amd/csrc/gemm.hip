@@ -460,7 +460,7 @@ __device__ __forceinline__ void fl_tile(const GemmParams& p, int tiles_m, int ti
 
   const int cpt = p.K1 / KPS;  // stages per tap
   // phase-decomposed UP2 / T2 (gemm.h): this tile's phase, its window of source pixels and its weight block
-  int ph_mq = 0, ph = 0, ph_ntx = 3, ph_dy0 = 0, ph_dx0 = 0, ntaps = 9;
+  int ph_mq = 0, ph = 0, ph_ntx = 3, ph_dy0 = 0, ph_dx0 = 0, ntaps = (MODE == FL_CONV_ANY && p.mode == GEMM_CONV_S2K4) ? 16 : 9;
   long ph_woff = 0;
   if constexpr (MODE == FL_CONV_ANY) {
     if (gemm_phase_mode(p.mode)) {
@@ -578,8 +578,9 @@ __device__ __forceinline__ void fl_tile(const GemmParams& p, int tiles_m, int ti
 #pragma unroll
       for (int j = 0; j < AJ; ++j) { glds16(cur[j], As + (j * NW + wave) * 1024); cur[j] += 128; }
     } else {
-      const int ky = tap / 3, kx = tap - ky * 3;
-      const int sy = (p.mode == GEMM_CONV_S2 || p.mode == GEMM_CONV_S2A) ? 2 : 1;
+      const bool k4 = p.mode == GEMM_CONV_S2K4;              // 4 x 4 window
+      const int ky = k4 ? tap >> 2 : tap / 3, kx = k4 ? tap & 3 : tap - ky * 3;
+      const int sy = (p.mode == GEMM_CONV_S2 || p.mode == GEMM_CONV_S2A || k4) ? 2 : 1;
       const int po = (p.mode == GEMM_CONV_S2A) ? 0 : 1;     // left / top padding
       const bool virt = (p.mode == GEMM_CONV_UP2) | (p.mode == GEMM_CONV_T2);
       const int pty = ph_ntx == 2 ? tap >> 1 : tap, ptx = ph_ntx == 2 ? tap & 1 : 0;   // phase modes: window tap
@@ -1097,7 +1098,7 @@ static int launch_fl_mode(const GemmParams& p0, hipStream_t stream) {
   const int kps = 128 / (int)sizeof(T);
   const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
   const long tiles = (long)tm * tn;
-  const int steps = ((MODE == FL_LINEAR ? 1 : p.mode == GEMM_CONV_UP2P ? 4 : 9) * p.K1 + p.K2) / kps;
+  const int steps = ((MODE == FL_LINEAR ? 1 : p.mode == GEMM_CONV_UP2P ? 4 : p.mode == GEMM_CONV_S2K4 ? 16 : 9) * p.K1 + p.K2) / kps;
   float* slab;
   if (gemm_phase_mode(p.mode) && (p.B * p.Hin * p.Win) % BM) return CL_EINVAL;   // a tile lies inside one phase
   if (p.mode == GEMM_CONV_T2P) { p.splitk = 1; slab = nullptr; }   // (its phases are 1 / 2 / 2 / 4 taps deep: no uniform K split)
@@ -1383,17 +1384,22 @@ int launch_gemm(const GemmParams& p, int dtype, hipStream_t stream) {
   if (p.rowbias && p.rows_per_batch <= 0) return CL_EINVAL;
   if (p.act == ACT_GEGLU && (p.N % 160 || p.rowbias || p.residual || p.atomic || p.alpha != 1.0f)) return CL_EINVAL;
   t_tag = tag_for(p, dtype);
-  if (gemm_phase_mode(p.mode)) {
-    // phase-decomposed UP2 / T2 (gemm.h): the full-line kernel's generic-conv form only.  256-row tiles where the grid fills
-    // the chip (or splits K to: UP2P), else 128-row tiles; g_gemm_force_cfg 8 / 9 / 10 / 11 impose 256 x {160, 128} / 128 x {160, 128}.
+  if (gemm_phase_mode(p.mode) || p.mode == GEMM_CONV_S2K4) {
+    // phase-decomposed UP2 / T2 and the 4x4 stride-2 window (gemm.h): the full-line kernel's generic-conv form only;
+    // g_gemm_force_cfg 8 / 9 / 10 / 11 impose 256 x {160, 128} / 128 x {160, 128} tiles.
     const int kps = dtype == CL_BF16 ? 64 : 32;
     const long mq = (long)p.B * p.Hin * p.Win;
-    if (p.K1 % kps || p.K2 || p.atomic || p.act == ACT_GEGLU || p.a1_group_n || p.a2_group_n || p.M != 4 * mq || mq % 128 ||
-        p.Hout != 2 * p.Hin || p.Wout != 2 * p.Win || p.N < 96)
+    if (p.K1 % kps || p.K2 || p.atomic || p.act == ACT_GEGLU || p.a1_group_n || p.a2_group_n || p.N < 96) return CL_EINVAL;
+    if (p.mode == GEMM_CONV_S2K4) {
+      if (p.Hin != 2 * p.Hout || p.Win != 2 * p.Wout || p.M != (long)p.B * p.Hout * p.Wout || p.ldw1 != 16L * p.K1) return CL_EINVAL;
+    } else if (p.M != 4 * mq || mq % 128 || p.Hout != 2 * p.Hin || p.Wout != 2 * p.Win) {
       return CL_EINVAL;
+    }
     const int bn = (p.N % 160 == 0) ? 160 : 128;
-    bool big = false;   // measured (tools/time_conv_phase.py): 128-row tiles win by 3-12 % at every production shape (uneven phase depths, 2 workgroups per CU)
-    if (g_gemm_force_cfg == 8 || g_gemm_force_cfg == 9) big = mq % 256 == 0;
+    // 128-row tiles (two workgroups per CU, split-K from the launcher's rule) measured 3-12 % ahead of 256-row tiles at every
+    // production shape of all three modes (tools/time_conv_phase.py, profiles/r06_phase/time_conv_phase.log)
+    bool big = false;
+    if (g_gemm_force_cfg == 8 || g_gemm_force_cfg == 9) big = p.mode == GEMM_CONV_S2K4 || mq % 256 == 0;
     if (g_gemm_force_cfg == 10 || g_gemm_force_cfg == 11) big = false;
     const bool n160 = g_gemm_force_cfg >= 8 && g_gemm_force_cfg <= 11 ? (g_gemm_force_cfg % 2 == 0 && p.N % 160 == 0) : bn == 160;
     t_force_sk = g_gemm_force_splitk;

@@ -340,6 +340,14 @@ def conv3_bwd_data(ctx: Ctx, cw: Conv3W, dy, B, Hdy, Wdy, fwd_mode=hip.CONV_S1, 
         hip.gemm(dy, cw.Wd, out, residual=accum, beta=1.0 if accum is not None else 0.0, mode=hip.CONV_T2,
                  conv=(B, Hdy, Wdy, 2 * Hdy, 2 * Wdy), k1=cw.Op, N=cw.Ip)
         return out
+    if fwd_mode == hip.CONV_UP2 and _phase_ok(ctx, cw, B, Hdy // 2, Wdy // 2, cw.Op, cw.Ip) and Hdy % 2 == 0 and Wdy % 2 == 0:
+        # the gradient formed on the SOURCE grid: a 4x4 stride-2 window over dy with the coincident taps summed (16 K deep at
+        # M / 4 rows instead of 9 K at M rows + a pooling pass)
+        if out is None:
+            out = ctx.new(B * Hdy * Wdy // 4, cw.Ip)
+        hip.gemm(dy, cw.phase_weights("up2d"), out, residual=accum, beta=1.0 if accum is not None else 0.0, mode=hip.CONV_S2K4,
+                 conv=(B, Hdy, Wdy, Hdy // 2, Wdy // 2), k1=cw.Op, N=cw.Ip)
+        return out
     if fwd_mode == hip.CONV_UP2:     # dy on the upsampled grid -> stride-1 data gradient -> 2x2 sum pool
         M = B * Hdy * Wdy
         dup = ctx.new(M, cw.Ip)

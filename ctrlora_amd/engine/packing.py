@@ -286,6 +286,16 @@ class Conv3W:
                     blk = torch.stack([W[:, ky, kx].t() for ky in taps[a] for kx in taps[b]], dim=1)   # [Ip][nt][Op]
                     blocks.append(blk.reshape(-1))
             packed = torch.cat(blocks)
+        elif kind == "up2d":
+            # data gradient of 'up2' on the source grid (CL_GEMM_CONV_S2K4): window row ky4 = 0..3 <-> upsampled row 2y - 1 + ky4,
+            # which the forward reached from (phase a, window tap ty) = (1, 1), (0, 1), (1, 0), (0, 0): taps {2}, {1, 2}, {0, 1}, {0}
+            grp4 = [[2], [1, 2], [0, 1], [0]]
+            out = torch.empty(self.Ip, 4, 4, self.Op, dtype=torch.float32, device=W.device)
+            for ky4 in range(4):
+                for kx4 in range(4):
+                    out[:, ky4, kx4] = W[:, grp4[ky4]][:, :, grp4[kx4]].sum(dim=(1, 2)).t()
+            self._phase[kind] = out.reshape(self.Ip, 16 * self.Op).to(self.Wp.dtype).contiguous()
+            return self._phase[kind]
         else:
             raise ValueError(kind)
         self._phase[kind] = packed.to(self.Wp.dtype).contiguous().view(1, -1)     # (ldw1 is not used by these modes)

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTRLORA_LIB") or os.path.join(_HERE, "libctrlora_hip.so")   # (CTRLORA_LIB: A/B builds of the same ABI)
 
 BF16, F32 = 0, 1
-LINEAR, CONV_S1, CONV_S2, CONV_UP2, CONV_T2, CONV_S2A, CONV_UP2P, CONV_T2P = 0, 1, 2, 3, 4, 5, 6, 7
+LINEAR, CONV_S1, CONV_S2, CONV_UP2, CONV_T2, CONV_S2A, CONV_UP2P, CONV_T2P, CONV_S2K4 = 0, 1, 2, 3, 4, 5, 6, 7, 8
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_GEGLU_SPLIT = 0, 1, 2, 3
 
 

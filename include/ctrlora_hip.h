@@ -85,7 +85,12 @@ enum cl_gemm_mode {
    * C / residual / rowbias rows are OUTPUT pixels (the kernel interleaves the phases); W1 = phase-packed weights
    * (ctrlora_amd/engine/packing.py: Conv3W.phase_weights), ldw1 ignored.  bf16 / fp32, K1 whole 128-byte lines, no K2.   */
   CL_GEMM_CONV_UP2P = 6,
-  CL_GEMM_CONV_T2P = 7
+  CL_GEMM_CONV_T2P = 7,
+  /* 4x4 window, stride 2, pad 1: the data gradient of CL_GEMM_CONV_UP2 formed on the source grid (each source pixel receives
+   * from upsampled rows / columns 2y - 1 .. 2y + 2; coincident 3x3 taps summed) -- 16 K1 deep at M / 4 rows instead of a
+   * stride-1 data gradient on the upsampled grid plus a 2x2 sum pool.  A1 = dy NHWC [B,Hin,Win,K1] (upsampled grid),
+   * Hout = Hin / 2, Wout = Win / 2, M = B Hout Wout, W1 = [N][4][4][K1], ldw1 = 16 K1 (Conv3W.phase_weights("up2d")).       */
+  CL_GEMM_CONV_S2K4 = 8
 };
 
 typedef struct cl_gemm_params {

@@ -133,6 +133,39 @@ def test_downsample_data_gradient_phase_form_matches_autograd_and_the_nine_tap_f
     assert rel_l2(outs[True], outs[False]) < (1e-6 if dtype == torch.float32 else 3e-3)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 4e-3)])
+@pytest.mark.parametrize("case", UP_CASES)
+def test_upsample_conv_data_gradient_on_the_source_grid_matches_autograd(case, dtype, tol):
+    """d/dx of conv3x3(nearest_x2(x)) (openaimodel.py:108-118 under autograd) as ONE 4x4 stride-2 window product on the source
+    grid (CL_GEMM_CONV_S2K4) against fp64 autograd and against the stride-1 data gradient + 2x2 sum pool it replaces."""
+    _need_gpu()
+    from ctrlora_amd import hip
+    from ctrlora_amd.engine import blocks
+    B, H, W, Cin, Cout = case
+    if dtype == torch.bfloat16 and Cout % 64:
+        pytest.skip("bf16 needs whole 128-byte channel lines")
+    g, w, b, cw, ctx, rnd = _setup(B, H, W, Cin, Cout, dtype, B + H + Cout)
+    dy = torch.randn(B, Cout, 2 * H, 2 * W, generator=g)
+    dyt = _tok(dy, dtype)
+    xin = torch.zeros(B, Cin, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(F.interpolate(xin, scale_factor=2, mode="nearest"), rnd(w), None, padding=1).backward(_img(dyt, B, 2 * H, 2 * W))
+    ref = xin.grad
+    outs = {}
+    for phase in (True, False):
+        blocks.CONV_PHASE = phase
+        try:
+            dx = blocks.conv3_bwd_data(ctx, cw, dyt, B, 2 * H, 2 * W, fwd_mode=hip.CONV_UP2)
+            dx2 = blocks.conv3_bwd_data(ctx, cw, dyt, B, 2 * H, 2 * W, fwd_mode=hip.CONV_UP2)
+        finally:
+            blocks.CONV_PHASE = True
+        assert torch.equal(dx, dx2) and dx.shape == (B * H * W, cw.Ip)
+        outs[phase] = _img(dx, B, H, W)[:, :Cin]
+    e_new, e_old = rel_l2(outs[True], ref), rel_l2(outs[False], ref)
+    print(f"[conv phase] up2 data gradient {case} {dtype}: source-grid form {e_new:.2e}, stride-1 + pool form {e_old:.2e}")
+    assert e_new < tol and e_old < 2 * tol          # (the old form rounds the upsampled-grid gradient to bf16 before pooling)
+    assert e_new < 1.5 * e_old + 1e-6
+
+
 def test_phase_forms_fall_back_where_they_do_not_apply():
     """Trainable convs (pre-training repacks their weights every step), grids that do not fill a 128-row tile and channel
     counts that are not whole lines keep the nine-tap modes; the library refuses malformed phase calls instead of guessing."""

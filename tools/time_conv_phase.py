@@ -32,7 +32,8 @@ def main():
     rows = []
     for kind, B, H, C in [("up2", 8, 8, 1280), ("up2", 8, 16, 1280), ("up2", 8, 32, 640),
                           ("up2", 32, 8, 1280), ("up2", 32, 16, 1280), ("up2", 32, 32, 640),
-                          ("t2", 8, 32, 320), ("t2", 8, 16, 640), ("t2", 8, 8, 1280)]:
+                          ("t2", 8, 32, 320), ("t2", 8, 16, 640), ("t2", 8, 8, 1280),
+                          ("up2d", 8, 8, 1280), ("up2d", 8, 16, 1280), ("up2d", 8, 32, 640)]:
         w = torch.randn(C, C, 3, 3) * 0.01
         cw = Conv3W(w, torch.zeros(C), dt, "cuda", True)
         x = torch.randn(B * H * H, C, device="cuda").to(dt)
@@ -40,8 +41,13 @@ def main():
         if kind == "up2":
             fn = lambda: blocks.conv3_fwd(ctx, cw, x, B, H, H, mode=hip.CONV_UP2, out=out)
             macs9 = 4 * B * H * H * C * 9 * C
-        else:
+        elif kind == "t2":
             fn = lambda: blocks.conv3_bwd_data(ctx, cw, x, B, H, H, fwd_mode=hip.CONV_S2, out=out)
+            macs9 = 4 * B * H * H * C * 9 * C
+        else:     # data gradient of the Upsample conv: dy on the 2H x 2H grid -> dx on H x H
+            dyu = torch.randn(4 * B * H * H, C, device="cuda").to(dt)
+            dxl = torch.empty(B * H * H, C, dtype=dt, device="cuda")
+            fn = lambda: blocks.conv3_bwd_data(ctx, cw, dyu, B, 2 * H, 2 * H, fwd_mode=hip.CONV_UP2, out=dxl)
             macs9 = 4 * B * H * H * C * 9 * C
         blocks.CONV_PHASE = False
         t_old = timed(fn)
