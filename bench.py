@@ -155,7 +155,7 @@ def dominant_kernel_rocprof():
     """The same launch INSIDE the replayed training step, from this round's rocprofv3 kernel trace joined with the launch tags
     (tools/prof_shapes.py -> profiles/r05_final/train_shapes_in_step.txt): static here, published beside the live HIP-event figure
     because hot isolated launches run ~8 % faster than the launch does in the step."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", r, "train_shapes_in_step.txt") for r in ("r06_final", "r05_final"))
+    path = next((q for q in (os.path.join(ROOT, "profiles", r, "train_shapes_in_step.txt") for r in ("r06_final3", "r06_final", "r05_final"))
                  if os.path.exists(q)), "")
     meta = None
     try:
