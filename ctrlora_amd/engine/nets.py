@@ -262,6 +262,17 @@ class _Conv:
     def __init__(self, cw: Conv3W, mode: int):
         self.cw, self.mode = cw, mode
         self.cout = cw.O
+        # the source-grid forms of Upsample / Downsample (blocks._phase_ok) use weights derived from the packed ones: built here,
+        # not on first use, so that a first call inside a hipGraph capture does not record the packing kernels into the graph
+        # (a conv that is made trainable afterwards never uses them)
+        from .blocks import CONV_PHASE
+        if CONV_PHASE and cw.tW is None:
+            if mode == hip.CONV_UP2:
+                cw.phase_weights("up2")
+                if cw.Wd is not None:
+                    cw.phase_weights("up2d")
+            elif mode == hip.CONV_S2 and cw.Wd is not None:
+                cw.phase_weights("t2")
 
     def fwd(self, ctx, x, env, out=None):
         y = conv3_fwd(ctx, self.cw, x, env.B, env.H, env.W, mode=self.mode, out=out)
