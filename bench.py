@@ -660,7 +660,7 @@ def cpu_baseline(rank_lora=32, threads=32):
     Bounded sample (~20-40 s of host work); the reference itself additionally recomputes activations
     (checkpoint()) and forms ~0.9 G dead weight gradients, so it is slower than this port."""
     from oracle import arch, ref_model as R
-    n_thr = max(1, min(threads, os.cpu_count() or 1))
+    n_thr = max(1, min(threads, cpus_available()))
     torch.set_num_threads(n_thr)
     cfg = arch.ArchCfg(lora_rank=rank_lora)
     sd_cn = arch.make_state(arch.controlnet_shapes(cfg), 0)
@@ -805,6 +805,39 @@ def dist_dry_run(args, world, rank, local):
     return 0 if int(okt) else 1
 
 
+_T0 = time.perf_counter()
+
+
+def cpus_available() -> int:
+    """CPUs this process may actually use: the smaller of its affinity mask and its cgroup CPU quota (a GPU box of the pool
+    reports 256 CPUs to os.cpu_count() and to the affinity mask under a quota of 16)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    try:   # cgroup v1
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and per > 0:
+            n = min(n, max(1, q // per))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def _tick(label):
+    """CTRLORA_BENCH_TRACE_TIMES=1: wall-clock marks on stderr (where does a launch spend its time outside the timed region?)."""
+    if os.environ.get("CTRLORA_BENCH_TRACE_TIMES") == "1":
+        print(f"[bench +{time.perf_counter() - _T0:7.1f} s] {label}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -855,13 +888,22 @@ def main():
         return dist_dry_run(args, world, rank, local)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    if world == 1 and "RANK" not in os.environ:
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), 16, cpus_available())))   # host side of the model build
     if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import datetime
-        # N ranks build their 1.3 G-parameter model on the host at the same time: share the cores instead of N-fold
-        # oversubscription (the first collective waits for the slowest rank)
-        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
+        # N ranks build their 1.3 G-parameter model on the host at the same time: share the cores this process may actually
+        # run on (cpus_available(): affinity mask and cgroup quota, not os.cpu_count() -- under a 16-CPU quota cpu_count() = 256 threads
+        # per rank spin against each other -- a ONE-rank torchrun launch took 476 s to build the model that a plain launch
+        # builds in 10 s, profiles/r06_verify/torchrun_timing.txt) and cap the share: the build does not scale past ~16 threads
+        avail = cpus_available()
+        _tick(f"cpu_count {os.cpu_count()}, usable {avail}, torch threads before {torch.get_num_threads()}, "
+              f"OMP_NUM_THREADS={os.environ.get('OMP_NUM_THREADS')}")
+        torch.set_num_threads(max(1, min(16, avail // world)))
+        _tick("init_process_group ...")
         dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=900))
+        _tick("process group up")
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     if args.ddim_only:
         print(json.dumps(ddim_bench(device, dtype, tiny=args.tiny, loops=args.ddim_loops, warm_loops=args.ddim_warm,
@@ -884,6 +926,7 @@ def main():
     model = build_model(f"ctrlora_finetune_sd15_rank{args.rank_lora}.yaml", 0, tiny=args.tiny).to(device).train()
     model.set_engine_dtype(dtype)
     model.learning_rate = 1e-5
+    _tick("model built")
     if world > 1:
         from ctrlora_amd.parallel import GradAllReduce
         model.dp = GradAllReduce([model.control_model.executor()])
@@ -928,12 +971,14 @@ def main():
         opt.step()
         return loss
 
+    _tick("step ready (graph captured)" if graphed is not None else "step ready (eager)")
     for i in range(args.warmup):
         loss = step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    _tick("warm-up done")
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
@@ -942,6 +987,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    _tick("timed region done")
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -1085,8 +1131,10 @@ def main():
             if ddim is not None:
                 out["ddim"]["cpu_baseline"] = ddim_b
         print(json.dumps(out))
+    _tick("line printed")
     if dist.is_initialized():
         dist.destroy_process_group()
+    _tick("process group destroyed")
 
 
 if __name__ == "__main__":
