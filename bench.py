@@ -905,13 +905,17 @@ def main():
         dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=900))
         _tick("process group up")
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    def _leave():      # (single-leg runs under a rank environment: shut the process group down like the main path does)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
     if args.ddim_only:
         print(json.dumps(ddim_bench(device, dtype, tiny=args.tiny, loops=args.ddim_loops, warm_loops=args.ddim_warm,
                                     extras=not args.ddim_core_only)))
-        return
+        return _leave()
     if args.probe_only:
         print(json.dumps(conv_kernel_probe(device, dtype, iters=200)))
-        return
+        return _leave()
     if args.pretrain_only:
         if world > 1:
             out = pretrain_bench_dp(device, dtype, world, rank, B=args.batch, tiny=args.tiny)
@@ -921,7 +925,7 @@ def main():
             dist.destroy_process_group()
             return
         print(json.dumps(pretrain_bench(device, dtype, B=args.batch, tiny=args.tiny)))
-        return
+        return _leave()
 
     model = build_model(f"ctrlora_finetune_sd15_rank{args.rank_lora}.yaml", 0, tiny=args.tiny).to(device).train()
     model.set_engine_dtype(dtype)
