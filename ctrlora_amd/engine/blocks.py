@@ -212,6 +212,15 @@ def conv3_bwd_weight(ctx: Ctx, cw: Conv3W, x, dy, B, Hin, Win, mode=hip.CONV_S1)
     assert mode in (hip.CONV_S1, hip.CONV_S2)
     Ho, Wo = Hin // stride, Win // stride
     g = cw.tW.grad.view(cw.O, 9 * cw.Ip)
+    if WGRAD_ROW3 and ctx.dtype == torch.bfloat16 and stride == 1 and (B * Hin * Win) % 32 == 0 and Win % 64 == 0:
+        # the three taps of a kernel row as ONE problem (cl_wgrad_desc.tap = 16 + ky): dy is read three times instead of nine,
+        # the shifted x tiles of a row share their pixels (csrc/wgrad.hip: wgrad_row3_kernel).  Taken at the 64x64 level only:
+        # 246 -> 208 us per 320 -> 320 conv there, but 151 -> 160 / 146 -> 163 / 50 -> 96 us at the 32x32 / 16x16 / 8x8 levels,
+        # where one 8-wave workgroup per CU loses to three 4-wave ones (tools/time_wgrad_row3.py, profiles/r06_row3/)
+        for ky in range(3):
+            ctx.queue_wgrad(dy, x, g[:, 3 * ky * cw.Ip:(3 * ky + 1) * cw.Ip], 1.0, conv=(16 + ky, Hin, Win, Ho, Wo, 1, 1))
+        hip.colsum(dy, cw.tb.grad.view(1, cw.O), 1, dy.shape[0], 1.0)
+        return
     for t in range(9):
         gs = g[:, t * cw.Ip:(t + 1) * cw.Ip]
         if ctx.dtype == torch.bfloat16:
@@ -283,6 +292,8 @@ class LayerNormOp:
 # Phase-decomposed Upsample conv / Downsample data gradient (hip.CONV_UP2P / CONV_T2P: 2.25x / 4x fewer MACs, same results):
 # frozen convs whose channels are whole 128-byte lines and whose source grid fills 128-row tiles.  CTRLORA_CONV_PHASE=0: A/B switch.
 CONV_PHASE = os.environ.get("CTRLORA_CONV_PHASE", "1") != "0"
+# pre-training's 3x3 weight gradients: one problem per kernel ROW (three taps) instead of one per tap; =0: nine single-tap problems
+WGRAD_ROW3 = os.environ.get("CTRLORA_WGRAD_ROW3", "1") != "0"
 
 
 def _phase_ok(ctx: Ctx, cw: Conv3W, B, Hs, Ws, k1, n, t2=False):

@@ -272,6 +272,52 @@ def test_conv_tap_weight_gradient_production_shapes(B, H, Cin, Cout, stride):
         assert float(dW.view(Cout, 9, Ip)[:, :, Cin:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(8, 64, 64, 320, 320), (8, 32, 32, 640, 640), (8, 16, 16, 1280, 1280), (8, 8, 8, 1280, 1280),
+                                            (2, 16, 8, 96, 160), (1, 8, 32, 64, 352), (3, 32, 64, 32, 64), (2, 64, 64, 4, 320)])
+def test_conv_weight_gradient_three_taps_per_problem_vs_fp64_and_the_single_tap_form(B, H, W, Cin, Cout):
+    """cl_wgrad_desc.tap = 16 + ky: the three taps of a kernel row of a stride-1 conv from ONE problem (wgrad_row3_kernel: dy tile
+    loaded once per step, one x tile with a halo pixel per image-row segment) vs torch's conv weight gradient in fp64 on the
+    same bf16 values, and vs the nine single-tap problems on the same call (same products, another summation order).  Grids:
+    the four levels of the batch-8 step (W = 64 / 32: a step inside one image row; W = 16 / 8: a step spans 2 / 4 rows, across
+    sample boundaries at the 8x8 level), non-square grids, ragged channel counts, split and unsplit m."""
+    _need_gpu()
+    from ctrlora_amd import hip
+    from ctrlora_amd.engine.packing import rup
+    g = torch.Generator().manual_seed(B * H + W + Cin)
+    Ip = rup(Cin, 32)
+    x = torch.zeros(B * H * W, Ip)
+    x[:, :Cin] = torch.randn(B * H * W, Cin, generator=g)
+    dy = torch.randn(B * H * W, Cout, generator=g) * 0.1
+    xb, dyb = _bf(x).cuda(), _bf(dy).cuda()
+    dW3 = torch.full((Cout, 9 * Ip), 0.25, dtype=torch.float32, device="cuda")       # accumulates INTO the gradient buffer
+    dW9 = torch.full((Cout, 9 * Ip), 0.25, dtype=torch.float32, device="cuda")
+    hip.weight_grad_tn_group([(dyb, xb, dW3[:, 3 * ky * Ip:(3 * ky + 1) * Ip], 0.5, (16 + ky, H, W, H, W, 1, 1)) for ky in range(3)])
+    hip.weight_grad_tn_group([(dyb, xb, dW9[:, tp * Ip:(tp + 1) * Ip], 0.5, (tp, H, W, H, W, 1, 1)) for tp in range(9)])
+    dW3b = torch.full((Cout, 9 * Ip), 0.25, dtype=torch.float32, device="cuda")
+    hip.weight_grad_tn_group([(dyb, xb, dW3b[:, 3 * ky * Ip:(3 * ky + 1) * Ip], 0.5, (16 + ky, H, W, H, W, 1, 1)) for ky in range(3)])
+    torch.cuda.synchronize()
+    assert torch.equal(dW3, dW3b)                                                     # deterministic (slabs + fixed-order reduce)
+    x64 = xb.double().view(B, H, W, Ip)[..., :Cin].permute(0, 3, 1, 2).contiguous()
+    dy64 = dyb.double().view(B, H, W, Cout).permute(0, 3, 1, 2).contiguous()
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, device="cuda", requires_grad=True)
+    torch.nn.functional.conv2d(x64, w, padding=1).backward(dy64)
+    ref = torch.zeros(Cout, 3, 3, Ip, dtype=torch.float64, device="cuda")
+    ref[..., :Cin] = w.grad.permute(0, 2, 3, 1)
+    ref = 0.25 + 0.5 * ref.view(Cout, 9 * Ip)
+    e3, e9 = rel_l2(dW3 - 0.25, ref - 0.25), rel_l2(dW9 - 0.25, ref - 0.25)
+    per_tap = max(rel_l2(dW3[:, tp * Ip:tp * Ip + Cin] - 0.25, ref[:, tp * Ip:tp * Ip + Cin] - 0.25) for tp in range(9))
+    _record("conv_row3_wgrad", shape=[B, H, W, Cin, Cout], rel=e3, single_tap_rel=e9, worst_tap=per_tap)
+    assert e3 < 1e-5 and per_tap < 1e-5 and e9 < 1e-5, (e3, e9, per_tap)
+    if Ip > Cin:
+        assert float((dW3.view(Cout, 9, Ip)[:, :, Cin:] - 0.25).abs().max()) == 0.0
+    # descriptors the kernel does not cover are refused, not guessed at
+    bad = torch.zeros(Cout, 9 * Ip, dtype=torch.float32, device="cuda")
+    with pytest.raises(hip.HipError):
+        hip.weight_grad_tn_group([(dyb, xb, bad[:, :Ip], 1.0, (16, H, W, H // 2, W // 2, 2, 1))])   # stride 2
+    with pytest.raises(hip.HipError):
+        hip.weight_grad_tn_group([(dyb, xb, bad[:, :Ip], 1.0, (19, H, W, H, W, 1, 1))])             # no such kernel row
+
+
 # ------------------------------------------------------------------------------ pre-training at SD1.5 width
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
