@@ -220,13 +220,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const WgradGroup grp, 
 // halo pixel on either side of every image-row segment -- and runs three MFMA batches off it, each reading the x
 // fragments one LDS row further on: a third of the dy traffic, 1.1x instead of 3x the x traffic, the dy fragment reads
 // shared by three batches.  8 waves (2 x 4) own a 128 (n) x 128 (k) tile of each of the three taps (wave: 64 x 32 per tap,
-// 96 accumulator registers); x tile = 64 LDS rows of 256 bytes, row of (step row r, tap kx) = (r / seg) (seg + 2) + r % seg + kx
-// with seg = min(W, 32) (a step is 32 / seg whole image-row segments: W a multiple of 32, or 32 a multiple of W).
+// 96 accumulator registers); x tile = 40 LDS rows of 256 bytes, row of (step row r, tap kx) = (r / seg) (seg + 2) + r % seg + kx
+// with seg = min(W, 32) (40 rows at most; a step is 32 / seg whole image-row segments: W a multiple of 32, or 32 a multiple of W).
 // dW points at tap (ky, 0) of the [N][3][3][K] gradient: tap kx lies K floats further on.
 template <int R>
 __global__ __launch_bounds__(512, 2) void wgrad_row3_kernel(const WgradGroup grp, const void* __restrict__ zero_page) {
   constexpr int DYT = 32 * 256;            // dy tile: 32 rows x 256 bytes
-  constexpr int XT = 64 * 256;             // x tile: 64 rows (34 .. 40 used)
+  constexpr int XT = 40 * 256;             // x tile: 40 rows (34 / 36 / 40 used at W >= 32 / 16 / 8): ten 4-row DMA instructions
   constexpr int SLOT = DYT + XT;
   static_assert(R * SLOT >= 8 * 32 * 36 * 4, "epilogue staging must fit in the ring");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -255,7 +255,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_row3_kernel(const WgradGroup grp
   if (total <= 0) return;
 
   auto swz = [](int row) { return ((row & 3) | (((row >> 3) & 1) << 2)) << 1; };
-  // ---- DMA sources.  dy: instruction `wave` (rows 4 wave .. 4 wave + 3); x: instructions 2 wave, 2 wave + 1 of 16
+  // ---- DMA sources.  dy: instruction `wave` (rows 4 wave .. 4 wave + 3); x: instruction `wave`, and 8 + wave for waves 0, 1
+  // (ten instructions = 40 rows; waves 0 and 1 count three DMA instructions per step, the others two)
   const int lr4 = lane >> 4, lslot = lane & 15;
   const char* zsrc = (const char*)zero_page + (lslot & 3) * 16;
   const int dyrow = 4 * wave + lr4;
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_row3_kernel(const WgradGroup grp
   int xs_[2], xj_[2]; bool xq_[2]; const char* sx[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int q = (2 * wave + j) * 4 + lr4;                            // x-tile row
+    const int q = (wave + 8 * j) * 4 + lr4;                            // x-tile row (j = 1: waves 0, 1 only)
     xs_[j] = q / rps; xj_[j] = q - xs_[j] * rps; xq_[j] = xs_[j] < nseg;
     sx[j] = (const char*)(x + min(k0 + (lslot ^ swz(q)) * 8, K - 8));
   }
@@ -273,12 +274,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_row3_kernel(const WgradGroup grp
     glds16(m < M ? sdy + m * lddy * 2 : zsrc, base + wave * 1024);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
+      if (j == 1 && wave >= 2) break;                                   // (wave-uniform)
       const int mc = step * 32 + xs_[j] * seg;                         // first pixel of this row's segment
       const int ox0 = mc % Wd, t2 = mc / Wd, oy = t2 % Hd, ob = t2 / Hd;
       const int iy = oy + ky - 1, ix = ox0 - 1 + xj_[j];
       const bool ok = xq_[j] & (mc < M) & ((unsigned)iy < (unsigned)Hd) & ((unsigned)ix < (unsigned)Wd);
       const long xr = ((long)ob * Hd + iy) * Wd + ix;
-      glds16(ok ? sx[j] + xr * ldx * 2 : zsrc, base + DYT + (2 * wave + j) * 1024);
+      glds16(ok ? sx[j] + xr * ldx * 2 : zsrc, base + DYT + (wave + 8 * j) * 1024);
     }
   };
 
@@ -313,39 +315,58 @@ __global__ __launch_bounds__(512, 2) void wgrad_row3_kernel(const WgradGroup grp
   for (int s = 0; s < R - 1; ++s)
     if (s < total) issue(sbeg + s, s);
   for (int s = 0; s < total; ++s) {
-    if (s + R - 1 <= total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * 3) : "memory");   // 3 DMA instructions per wave and step
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // own DMA of step s landed; R - 2 newer steps stay in flight: 3 DMA instructions per step in waves 0 and 1, 2 in the others
+    if (s + R - 1 <= total) {
+      if (wave < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * 3) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * 2) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (s + R - 1 < total) issue(sbeg + s + R - 1, (s + R - 1) % R);
     const uint32_t sb = lds0 + (s % R) * SLOT;
     u32x4_t af[4], bfr[3][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const u32x2_t lo = lds_read_tr16(sb + aoff[i]), hi = lds_read_tr16(sb + aoff[i] + 1024);
-      af[i] = u32x4_t{lo.x, lo.y, hi.x, hi.y};
-    }
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
+    auto read_b = [&](int t) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const u32x2_t lo = lds_read_tr16(sb + boff[t][i][0]), hi = lds_read_tr16(sb + boff[t][i][1]);
         bfr[t][i] = u32x4_t{lo.x, lo.y, hi.x, hi.y};
       }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(af[i]));
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
+    };
+    auto landed_b = [&](int t) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
       for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(bfr[t][i]));
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
+    };
+    auto mma_tap = [&](int t) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) Mma<bf16_t>::run(af[i], bfr[t][j], acc[t][i][j]);
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const u32x2_t lo = lds_read_tr16(sb + aoff[i]), hi = lds_read_tr16(sb + aoff[i] + 1024);
+      af[i] = u32x4_t{lo.x, lo.y, hi.x, hi.y};
+    }
+    read_b(0);
+    landed_b(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(af[i]));
+    __builtin_amdgcn_sched_barrier(0);
+    read_b(1);                       // the next tap's fragments land under this tap's eight MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    mma_tap(0);
+    __builtin_amdgcn_sched_barrier(0);
+    landed_b(1);
+    read_b(2);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_tap(1);
+    __builtin_amdgcn_sched_barrier(0);
+    landed_b(2);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_tap(2);
   }
   __syncthreads();
 
@@ -417,18 +438,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradGroup grp)
 // the nine-tap groups of pre-training 284 -> 239 us at 320 -> 320 / 64x64, 186 -> 152 at 640 -> 640 / 32x32; 64-row steps
 // (two MFMA batches per barrier; 2-slot ring to keep two workgroups per CU) measured no better than 32-row steps: 277 / 181 us.
 int g_wgrad_blocks = 512, g_wgrad_min_steps = 8, g_wgrad_ring = 3, g_wgrad_rows = 32;
+int g_wgrad_row3_blocks = 512;
 
 static int launch_group(WgradGroup& grp, int nblocks, int nred, const void* zero_page, hipStream_t stream, bool row3 = false) {
   if (row3) {   // groups of row-of-three-taps problems (tap = 16 + ky): their own kernel, 8 waves, 72 KB ring
     static bool attr_set = false;
-    constexpr int LDSB = 3 * (32 * 256 + 64 * 256);
+    // one 8-wave workgroup per CU (178 registers): the ring is what keeps DMA in flight -- 8 slots of 18 KB = seven steps ahead
+    // (with 3 slots the kernel ran at the L2 latency of two steps: 202 us for the 320 -> 320 conv at 64x64)
+    constexpr int RR = 8;
+    constexpr int LDSB = RR * (32 * 256 + 40 * 256);
     if (!attr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_row3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_row3_kernel<RR>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               LDSB) != hipSuccess)
         return CL_ELAUNCH;
       attr_set = true;
     }
-    hipLaunchKernelGGL((wgrad_row3_kernel<3>), dim3(nblocks), dim3(512), LDSB, stream, grp, zero_page);
+    hipLaunchKernelGGL((wgrad_row3_kernel<RR>), dim3(nblocks), dim3(512), LDSB, stream, grp, zero_page);
     if (nred > 0) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nred), dim3(256), 0, stream, grp);
     CL_CHECK_LAUNCH();
     return CL_OK;
@@ -506,7 +531,18 @@ static int launch_wgrad_group_kind(const WgradDesc* probs, int n, const void* ze
   for (int i = 0; i < n; ++i)
     if (probs[i].M > 0 && (probs[i].tap >= 16) == row3)
       steps_all += (long)((probs[i].N + 127) / 128) * ((probs[i].K + 127) / 128) * ((probs[i].M + rows - 1) / rows);
-  long per = (steps_all + g_wgrad_blocks - 1) / g_wgrad_blocks;
+  // (row problems: one 8-wave workgroup per CU -> one workgroup per CU's worth of splits; every split costs 3 N K floats of slab)
+  const int want_blocks = row3 ? g_wgrad_row3_blocks : g_wgrad_blocks;
+  long per = (steps_all + want_blocks - 1) / want_blocks;
+  if (row3 && tiles_all > 0) {
+    // one workgroup per CU: never a few workgroups more than a whole number of rounds (27 tiles x 19 splits = 513 workgroups ran
+    // as three rounds) -- the largest split count whose grid stays within want_blocks
+    long max_steps = 0;
+    for (int i = 0; i < n; ++i)
+      if (probs[i].M > 0 && probs[i].tap >= 16) max_steps = std::max(max_steps, (long)((probs[i].M + rows - 1) / rows));
+    const long smax = std::max(1L, want_blocks / tiles_all);
+    per = (max_steps + smax - 1) / smax;
+  }
   const long min_steps = std::max(1, g_wgrad_min_steps * 32 / rows);
   if (per < min_steps) per = min_steps;
 

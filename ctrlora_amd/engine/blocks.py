@@ -215,8 +215,9 @@ def conv3_bwd_weight(ctx: Ctx, cw: Conv3W, x, dy, B, Hin, Win, mode=hip.CONV_S1)
     if WGRAD_ROW3 and ctx.dtype == torch.bfloat16 and stride == 1 and (B * Hin * Win) % 32 == 0 and Win % 64 == 0:
         # the three taps of a kernel row as ONE problem (cl_wgrad_desc.tap = 16 + ky): dy is read three times instead of nine,
         # the shifted x tiles of a row share their pixels (csrc/wgrad.hip: wgrad_row3_kernel).  Taken at the 64x64 level only:
-        # 246 -> 208 us per 320 -> 320 conv there, but 151 -> 160 / 146 -> 163 / 50 -> 96 us at the 32x32 / 16x16 / 8x8 levels,
-        # where one 8-wave workgroup per CU loses to three 4-wave ones (tools/time_wgrad_row3.py, profiles/r06_row3/)
+        # 244 -> 144 us per 320 -> 320 conv there, parity at the 32x32 / 16x16 levels (152 -> 159, 147 -> 143 us) and 50 -> 57 us
+        # at the 8x8 level, where one 8-wave workgroup per CU has nothing over three 4-wave ones (tools/time_wgrad_row3.py,
+        # profiles/r06_row3/)
         for ky in range(3):
             ctx.queue_wgrad(dy, x, g[:, 3 * ky * cw.Ip:(3 * ky + 1) * cw.Ip], 1.0, conv=(16 + ky, Hin, Win, Ho, Wo, 1, 1))
         hip.colsum(dy, cw.tb.grad.view(1, cw.O), 1, dy.shape[0], 1.0)

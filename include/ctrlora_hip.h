@@ -174,7 +174,9 @@ typedef struct cl_wgrad_desc {
   /* tap >= 0: ONE TAP of a 3x3 convolution's weight gradient (Base-ControlNet pre-training trains the conv weights,
    * cldm/cldm_ctrlora_pretrain.py:174-182).  x is then the NHWC input [B*Hin*Win, K]; row m = (b, oy, ox) of dy pairs
    * with input pixel (oy*stride + tap/3 - pad, ox*stride + tap%3 - pad), zero outside the image; dW points at the tap's
-   * [N, K] slice of a [N][3][3][K] gradient (lddw = 9 K).  tap = -1: plain dy^T x (the other fields are ignored). */
+   * [N, K] slice of a [N][3][3][K] gradient (lddw = 9 K).  tap = -1: plain dy^T x (the other fields are ignored).
+   * tap = 16 + ky (stride 1, pad 1, Wout a multiple of 32 or a divisor of 32, M a multiple of 32): the THREE taps (ky, 0..2) of a
+   * kernel row from one problem -- dW points at tap (ky, 0), taps kx = 1, 2 lie K and 2 K floats further on in each row. */
   int tap, Hin, Win, Hout, Wout, stride, pad, reserved;
 } cl_wgrad_desc;
 int cl_weight_grad_tn_group(int dtype, int n, const cl_wgrad_desc* descs, const void* zero_page, void* stream);
